@@ -1,0 +1,368 @@
+"""Python face of the parity oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product package `cosypose_amd` never does.
+
+Three things live here:
+  * ctypes bindings to oracle/cosy_oracle.c (plain-C fp32 restatement of the
+    reference's hot path, each function citing the reference file:line);
+  * `roi_align_numpy`: a second, independently written restatement of
+    torchvision 0.4.2 roi_align used to cross-check the C one (the reference's
+    only third-party arithmetic on the path; PARITY UNPINNED, see the C header);
+  * `TorchRef`: the same path written with stock torch CPU ops (F.conv2d,
+    F.batch_norm ...) -- the arithmetic the reference's PyTorch-CPU path
+    executes -- used to time the CPU baseline and to validate the C restatement
+    at full size.
+"""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, '_build', 'libcosy_oracle.so')
+_SRC = os.path.join(_HERE, 'cosy_oracle.c')
+
+
+def build(force=False):
+    """gcc-compile the C restatement into oracle/_build/ (idempotent)."""
+    if not force and os.path.exists(_SO) and os.path.getmtime(_SO) >= os.path.getmtime(_SRC):
+        return _SO
+    os.makedirs(os.path.dirname(_SO), exist_ok=True)
+    cmd = ['gcc', '-O3', '-march=x86-64-v2', '-fopenmp', '-fPIC', '-shared', '-fno-fast-math',
+           '-ffp-contract=off', '-o', _SO, _SRC, '-lm']
+    subprocess.check_call(cmd)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.cosy_oracle_b3_param_count.restype = ctypes.c_long
+        _lib.cosy_oracle_b3_forward.restype = ctypes.c_int
+        _lib.cosy_oracle_scatter_argmin.restype = ctypes.c_int
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+def set_threads(n):
+    lib().cosy_oracle_set_threads(ctypes.c_int(int(n)))
+
+
+# ----------------------------------------------------------------------------
+# geometry
+# ----------------------------------------------------------------------------
+
+def project_points_robust(pts, K, TCO, z_min=0.1):
+    pts, pp = _f(pts); K, kp = _f(K); TCO, tp = _f(TCO)
+    B, P = pts.shape[:2]
+    uv = np.empty((B, P, 2), np.float32)
+    lib().cosy_oracle_project_points_robust(pp, kp, tp, B, P, ctypes.c_float(z_min), uv.ctypes.data_as(ctypes.c_void_p))
+    return uv
+
+
+def boxes_from_uv(uv):
+    uv, up = _f(uv)
+    B, P = uv.shape[:2]
+    out = np.empty((B, 4), np.float32)
+    lib().cosy_oracle_boxes_from_uv(up, B, P, out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def get_K_crop_resize(K, boxes, crop_resize):
+    K, kp = _f(K); boxes, bp = _f(boxes)
+    out = np.empty_like(K)
+    lib().cosy_oracle_get_K_crop_resize(kp, bp, K.shape[0], int(crop_resize[0]), int(crop_resize[1]),
+                                        out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def crop_geometry(pts, K, TCO, im_hw, out_hw, lamb=1.4):
+    """boxes_rend, boxes_crop, K_crop of PosePredictor.crop_inputs (pose.py:45-67)."""
+    pts, pp = _f(pts); K, kp = _f(K); TCO, tp = _f(TCO)
+    B, P = pts.shape[:2]
+    br = np.empty((B, 4), np.float32); bc = np.empty((B, 4), np.float32); kc = np.empty((B, 3, 3), np.float32)
+    lib().cosy_oracle_crop_geometry(pp, kp, tp, B, P, int(im_hw[0]), int(im_hw[1]), int(out_hw[0]), int(out_hw[1]),
+                                    ctypes.c_float(lamb), br.ctypes.data_as(ctypes.c_void_p),
+                                    bc.ctypes.data_as(ctypes.c_void_p), kc.ctypes.data_as(ctypes.c_void_p))
+    return br, bc, kc
+
+
+def roi_align(images, rois, output_size, sampling_ratio=4):
+    """torchvision-0.4.2 semantics.  images (N,C,h,w), rois (R,5) -> (R,C,PH,PW)."""
+    images, ip = _f(images); rois, rp = _f(rois)
+    N, C, h, w = images.shape
+    R = rois.shape[0]
+    PH, PW = int(output_size[0]), int(output_size[1])
+    out = np.empty((R, C, PH, PW), np.float32)
+    lib().cosy_oracle_roi_align(ip, N, C, h, w, rp, R, PH, PW, int(sampling_ratio), out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def roi_align_numpy(images, rois, output_size, sampling_ratio=4):
+    """Independent vectorised restatement of the same spec (fp32 step by step)."""
+    images = np.asarray(images, np.float32); rois = np.asarray(rois, np.float32)
+    N, C, h, w = images.shape
+    PH, PW = output_size
+    g = sampling_ratio
+    out = np.zeros((rois.shape[0], C, PH, PW), np.float32)
+    f32 = np.float32
+    for n, roi in enumerate(rois):
+        bi = int(roi[0]); x1, y1, x2, y2 = roi[1:]
+        rw = max(f32(x2 - x1), f32(1)); rh = max(f32(y2 - y1), f32(1))
+        bh = f32(rh / f32(PH)); bw = f32(rw / f32(PW))
+        ph = np.arange(PH, dtype=np.float32)[:, None]; iy = np.arange(g, dtype=np.float32)[None, :]
+        pw = np.arange(PW, dtype=np.float32)[:, None]; ix = np.arange(g, dtype=np.float32)[None, :]
+        ys = ((y1 + ph * bh).astype(np.float32) + ((iy + f32(.5)) * bh).astype(np.float32) / f32(g)).astype(np.float32).reshape(-1)
+        xs = ((x1 + pw * bw).astype(np.float32) + ((ix + f32(.5)) * bw).astype(np.float32) / f32(g)).astype(np.float32).reshape(-1)
+
+        def axis(v, size):
+            valid = ~((v < -1.0) | (v > size))
+            v = np.where(v <= 0, f32(0), v).astype(np.float32)
+            lo = v.astype(np.int32)
+            edge = lo >= size - 1
+            lo = np.where(edge, size - 1, lo); hi = np.where(edge, size - 1, lo + 1)
+            v = np.where(edge, lo.astype(np.float32), v)
+            l = (v - lo.astype(np.float32)).astype(np.float32); hh = (f32(1) - l).astype(np.float32)
+            return valid, lo, hi, l, hh
+        vy, yl, yh, ly, hy = axis(ys, h)
+        vx, xl, xh, lx, hx = axis(xs, w)
+        img = images[bi]
+        w1 = (hy[:, None] * hx[None, :]).astype(np.float32); w2 = (hy[:, None] * lx[None, :]).astype(np.float32)
+        w3 = (ly[:, None] * hx[None, :]).astype(np.float32); w4 = (ly[:, None] * lx[None, :]).astype(np.float32)
+        valid = (vy[:, None] & vx[None, :]).astype(np.float32)
+        val = (w1 * img[:, yl][:, :, xl] + w2 * img[:, yl][:, :, xh] + w3 * img[:, yh][:, :, xl] + w4 * img[:, yh][:, :, xh])
+        val = (val * valid).astype(np.float32).reshape(C, PH, g, PW, g)
+        # sequential fp32 accumulation in (iy, ix) order, as the C++ loop does
+        acc = np.zeros((C, PH, PW), np.float32)
+        for a in range(g):
+            for b in range(g):
+                acc = (acc + val[:, :, a, :, b]).astype(np.float32)
+        out[n] = acc / f32(g * g)
+    return out
+
+
+def update_pose(TCO, K_crop, pose9):
+    TCO, tp = _f(TCO); K_crop, kp = _f(K_crop); pose9, pp = _f(pose9)
+    out = np.empty_like(TCO)
+    lib().cosy_oracle_update_pose(tp, kp, pp, TCO.shape[0], out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def ortho6d_to_R(p6):
+    p6, pp = _f(p6)
+    out = np.empty((p6.shape[0], 3, 3), np.float32)
+    lib().cosy_oracle_ortho6d_to_R(pp, p6.shape[0], out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def tco_init_from_boxes(boxes, K, z=1.0):
+    boxes, bp = _f(boxes); K, kp = _f(K)
+    out = np.empty((boxes.shape[0], 4, 4), np.float32)
+    lib().cosy_oracle_tco_init_from_boxes(bp, kp, boxes.shape[0], ctypes.c_float(z), out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def tco_init_zup_autodepth(boxes, pts, K):
+    boxes, bp = _f(boxes); K, kp = _f(K); pts, pp = _f(pts)
+    out = np.empty((boxes.shape[0], 4, 4), np.float32)
+    lib().cosy_oracle_tco_init_zup_autodepth(bp, pp, kp, boxes.shape[0], pts.shape[1], out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def scatter_argmin(dists, ids, n_seg):
+    dists, dp = _f(dists); ids, ip = _i(ids)
+    out = np.empty(n_seg, np.int32)
+    rc = lib().cosy_oracle_scatter_argmin(dp, ip, dists.shape[0], out.ctypes.data_as(ctypes.c_void_p), int(n_seg))
+    assert rc == 0
+    return out
+
+
+# ----------------------------------------------------------------------------
+# EfficientNet-B3: parameter blob + forward
+# ----------------------------------------------------------------------------
+
+# (k, s, expand, cin, cout) -- SURVEY Appendix A / efficientnet_utils.py:259-264 scaled for B3
+B3_BLOCKS = [
+    (3, 1, 1, 40, 24), (3, 1, 1, 24, 24),
+    (3, 2, 6, 24, 32), (3, 1, 6, 32, 32), (3, 1, 6, 32, 32),
+    (5, 2, 6, 32, 48), (5, 1, 6, 48, 48), (5, 1, 6, 48, 48),
+    (3, 2, 6, 48, 96), (3, 1, 6, 96, 96), (3, 1, 6, 96, 96), (3, 1, 6, 96, 96), (3, 1, 6, 96, 96),
+    (5, 1, 6, 96, 136), (5, 1, 6, 136, 136), (5, 1, 6, 136, 136), (5, 1, 6, 136, 136), (5, 1, 6, 136, 136),
+    (5, 2, 6, 136, 232), (5, 1, 6, 232, 232), (5, 1, 6, 232, 232), (5, 1, 6, 232, 232), (5, 1, 6, 232, 232), (5, 1, 6, 232, 232),
+    (3, 1, 6, 232, 384), (3, 1, 6, 384, 384),
+]
+
+
+def state_dict_keys(prefix='backbone.'):
+    """Reference state_dict keys in flat-blob order (BN: weight,bias,running_mean,running_var)."""
+    bn = ('weight', 'bias', 'running_mean', 'running_var')
+    keys = [prefix + '_conv_stem.weight'] + [prefix + '_bn0.' + s for s in bn]
+    for i, (k, s, e, cin, cout) in enumerate(B3_BLOCKS):
+        p = f'{prefix}_blocks.{i}.'
+        if e != 1:
+            keys += [p + '_expand_conv.weight'] + [p + '_bn0.' + s for s in bn]
+        keys += [p + '_depthwise_conv.weight'] + [p + '_bn1.' + s for s in bn]
+        keys += [p + '_se_reduce.weight', p + '_se_reduce.bias', p + '_se_expand.weight', p + '_se_expand.bias']
+        keys += [p + '_project_conv.weight'] + [p + '_bn2.' + s for s in bn]
+    keys += [prefix + '_conv_head.weight'] + [prefix + '_bn1.' + s for s in bn]
+    keys += ['pose_fc.weight', 'pose_fc.bias']
+    return keys
+
+
+def flatten_state_dict(sd):
+    """PosePredictor state_dict (numpy or torch values) -> flat fp32 blob."""
+    parts = []
+    for k in state_dict_keys():
+        v = sd[k]
+        v = v.detach().cpu().numpy() if hasattr(v, 'detach') else np.asarray(v)
+        parts.append(v.astype(np.float32).reshape(-1))
+    blob = np.concatenate(parts)
+    assert blob.size == lib().cosy_oracle_b3_param_count(), (blob.size, lib().cosy_oracle_b3_param_count())
+    return blob
+
+
+def b3_out_hw(H, W):
+    oh, ow = ctypes.c_int(), ctypes.c_int()
+    lib().cosy_oracle_b3_out_hw(int(H), int(W), ctypes.byref(oh), ctypes.byref(ow))
+    return oh.value, ow.value
+
+
+def b3_forward(x, blob, want_taps=False):
+    """x (B,6,H,W) NCHW fp32 -> feat (B,1536), pose (B,9) [, taps (B,9,16)]."""
+    x, xp = _f(x); blob, bp = _f(blob)
+    B, C, H, W = x.shape
+    assert C == 6
+    feat = np.empty((B, 1536), np.float32); pose = np.empty((B, 9), np.float32)
+    taps = np.empty((B, 9, 16), np.float32) if want_taps else None
+    rc = lib().cosy_oracle_b3_forward(xp, B, H, W, bp, feat.ctypes.data_as(ctypes.c_void_p),
+                                      pose.ctypes.data_as(ctypes.c_void_p),
+                                      taps.ctypes.data_as(ctypes.c_void_p) if want_taps else None)
+    assert rc == 0, rc
+    return (feat, pose, taps) if want_taps else (feat, pose)
+
+
+def taps_from_stage_tensors(tensors):
+    """Same probe as the C forward's `taps`, from 9 stage tensors (each (C,H,W) numpy)."""
+    out = np.empty((9, 16), np.float32)
+    for i, t in enumerate(tensors):
+        f = np.asarray(t, np.float32).reshape(-1)
+        n = f.size
+        out[i, 0] = np.float32(f.astype(np.float64).sum() / n)
+        out[i, 1] = np.float32(np.abs(f.astype(np.float64)).sum() / n)
+        for q in range(14):
+            out[i, 2 + q] = f[(q * 2 + 1) * n // 29]
+    return out
+
+
+# ----------------------------------------------------------------------------
+# Whole loop: PosePredictor.forward (pose.py:89-132) on the C restatement
+# ----------------------------------------------------------------------------
+
+def pose_predictor_forward(images, K, obj_ids, TCO, points_table, blob, render_fn, n_iterations=1,
+                           render_size=(240, 320), backbone=None):
+    """images (B,3,h,w) already gathered per object (pose_predictor.py:41), points_table
+    (n_obj,2000,3) = mesh_db points after sample_points(2000, deterministic=True).
+    render_fn(n, TCO_input, K_crop) -> (B,3,H,W) in [0,1].  `backbone(x)->(feat,pose)`
+    defaults to the C forward; pass TorchRef(...).net_forward for speed."""
+    images = np.asarray(images, np.float32)
+    B, _, h, w = images.shape
+    pts = np.asarray(points_table, np.float32)[np.asarray(obj_ids)]
+    outputs = {}
+    TCO_in = np.asarray(TCO, np.float32)
+    for n in range(n_iterations):
+        br, bc, kc = crop_geometry(pts, K, TCO_in, (h, w), render_size)
+        rois = np.concatenate([np.arange(B, dtype=np.float32)[:, None], bc], 1)
+        crop = roi_align(images, rois, render_size, 4)
+        rend = np.asarray(render_fn(n, TCO_in, kc), np.float32)
+        x = np.concatenate([crop, rend], 1)
+        _, pose = (backbone(x) if backbone is not None else b3_forward(x, blob))
+        TCO_out = update_pose(TCO_in, kc, pose)
+        outputs[f'iteration={n + 1}'] = dict(TCO_input=TCO_in, TCO_output=TCO_out, K_crop=kc, pose=pose,
+                                             boxes_rend=br, boxes_crop=bc, images_crop=crop)
+        TCO_in = TCO_out
+    return outputs
+
+
+class TorchRef:
+    """The backbone + head on stock torch CPU ops, from a reference-keyed state_dict.
+
+    Mirrors EfficientNet.extract_features (efficientnet.py:174-190), MBConvBlock.forward
+    (:71-98), Conv2dStaticSamePadding(image_size=300) (efficientnet_utils.py:123-146) and
+    PosePredictor.net_forward (pose.py:81-87), eval mode."""
+
+    def __init__(self, sd, dtype=None):
+        import torch
+        self.torch = torch
+        self.sd = {k: (v if hasattr(v, 'detach') else torch.from_numpy(np.asarray(v))).float() for k, v in sd.items()
+                   if not k.endswith('num_batches_tracked')}
+
+    @staticmethod
+    def _pad(k, s):
+        if s == 1:
+            return (k - 1) // 2, (k - 1) // 2
+        tot = k - 2
+        return tot // 2, tot - tot // 2
+
+    def _conv(self, x, w, k, s, groups=1, bias=None):
+        F = self.torch.nn.functional
+        lo, hi = self._pad(k, s)
+        if lo or hi:
+            x = F.pad(x, (lo, hi, lo, hi))
+        return F.conv2d(x, w, bias, stride=s, groups=groups)
+
+    def _bn(self, x, p):
+        F = self.torch.nn.functional
+        sd = self.sd
+        return F.batch_norm(x, sd[p + '.running_mean'], sd[p + '.running_var'], sd[p + '.weight'], sd[p + '.bias'],
+                            False, 0.01, 1e-3)
+
+    def extract_features(self, x, stages=None):
+        torch = self.torch; sd = self.sd
+        sw = lambda t: t * torch.sigmoid(t)
+        x = sw(self._bn(self._conv(x, sd['backbone._conv_stem.weight'], 3, 2), 'backbone._bn0'))
+        if stages is not None:
+            stages.append(x)
+        ends = {1, 4, 7, 12, 17, 23, 25}
+        for i, (k, s, e, cin, cout) in enumerate(B3_BLOCKS):
+            p = f'backbone._blocks.{i}.'
+            inp = x
+            if e != 1:
+                x = sw(self._bn(self._conv(x, sd[p + '_expand_conv.weight'], 1, 1), p + '_bn0'))
+            x = sw(self._bn(self._conv(x, sd[p + '_depthwise_conv.weight'], k, s, groups=x.shape[1]), p + '_bn1'))
+            q = x.mean((2, 3), keepdim=True)
+            q = self._conv(sw(self._conv(q, sd[p + '_se_reduce.weight'], 1, 1, bias=sd[p + '_se_reduce.bias'])),
+                           sd[p + '_se_expand.weight'], 1, 1, bias=sd[p + '_se_expand.bias'])
+            x = torch.sigmoid(q) * x
+            x = self._bn(self._conv(x, sd[p + '_project_conv.weight'], 1, 1), p + '_bn2')
+            if s == 1 and cin == cout:
+                x = x + inp
+            if stages is not None and i in ends:
+                stages.append(x)
+        x = sw(self._bn(self._conv(x, sd['backbone._conv_head.weight'], 1, 1), 'backbone._bn1'))
+        if stages is not None:
+            stages.append(x)
+        return x
+
+    def net_forward(self, x):
+        torch = self.torch
+        with torch.no_grad():
+            x = torch.as_tensor(np.asarray(x, np.float32)) if not torch.is_tensor(x) else x
+            f = self.extract_features(x).flatten(2).mean(-1)
+            pose = torch.nn.functional.linear(f, self.sd['pose_fc.weight'], self.sd['pose_fc.bias'])
+        return f.numpy(), pose.numpy()

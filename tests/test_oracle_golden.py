@@ -1,0 +1,109 @@
+"""Pin the CPU oracle (oracle/cosy_oracle.c) against outputs of the REFERENCE's own Python
+(tests/golden/reference_golden.npz, made by tests/golden/generate_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from cosypose_amd import synthetic as syn
+from conftest import rel_err
+
+TOL = 2e-6   # fp32 restatement vs torch CPU: same formulas, different summation order at most
+
+
+def test_arch_tables_agree(oracle):
+    from cosypose_amd import arch
+    assert [tuple(b) for b in arch.B3_BLOCKS] == oracle.B3_BLOCKS
+    assert arch.param_count() == oracle.lib().cosy_oracle_b3_param_count() == 10798441
+    assert arch.feature_hw(240, 320) == oracle.b3_out_hw(240, 320) == (7, 10)   # static-pad quirk: not 8x10
+    assert arch.feature_hw(256, 256) == oracle.b3_out_hw(256, 256) == (8, 8)
+    assert list(syn.state_dict_shapes().keys()) == oracle.state_dict_keys()
+
+
+def _fn_inputs():
+    B, P, h, w = 6, 2000, 480, 640
+    pts = syn.make_mesh_points(11, B, P)
+    return pts, (h, w)
+
+
+def test_projection_boxes_Kcrop(oracle, golden):
+    pts, (h, w) = _fn_inputs()
+    K, TCO = golden['fn_K'], golden['fn_TCO']
+    uv = oracle.project_points_robust(pts, K, TCO)
+    assert rel_err(uv[:, ::97], golden['fn_uv_sample']) < TOL
+    br, bc, kc = oracle.crop_geometry(pts, K, TCO, (h, w), (240, 320))
+    assert rel_err(br, golden['fn_boxes_rend']) < TOL
+    assert rel_err(bc, golden['fn_boxes_crop']) < TOL
+    assert rel_err(kc, golden['fn_K_crop']) < TOL
+    assert rel_err(oracle.get_K_crop_resize(K, bc, (256, 256)), golden['fn_K_crop_sq']) < TOL
+
+
+def test_pose_update_and_inits(oracle, golden):
+    pts, _ = _fn_inputs()
+    assert rel_err(oracle.ortho6d_to_R(golden['fn_pose9'][:, :6]), golden['fn_dR']) < TOL
+    out = oracle.update_pose(golden['fn_TCO'], golden['fn_K_crop'], golden['fn_pose9'])
+    assert rel_err(out, golden['fn_TCO_out']) < TOL
+    assert rel_err(oracle.tco_init_from_boxes(golden['fn_det_boxes'], golden['fn_K']), golden['fn_TCO_init_v0']) < TOL
+    assert rel_err(oracle.tco_init_zup_autodepth(golden['fn_det_boxes'], pts, golden['fn_K']),
+                   golden['fn_TCO_init_zup']) < TOL
+
+
+def test_roi_align_two_restatements_agree(oracle, golden):
+    """torchvision 0.4.2 roi_align is absent here (PARITY UNPINNED): cross-check the C restatement
+    against an independently written numpy one, incl. boxes hanging outside the frame."""
+    img = syn.make_frames(13, 2, 60, 80)
+    rois = np.array([[0, 10.3, 5.2, 50.7, 40.1], [1, -20, -15, 30, 25], [1, 60, 40, 120, 90],
+                     [0, 5, 5, 5.2, 5.3], [0, -200, -200, -100, -100]], np.float32)
+    a = oracle.roi_align(img, rois, (12, 16), 4)
+    b = oracle.roi_align_numpy(img, rois, (12, 16), 4)
+    np.testing.assert_allclose(a, b, rtol=0, atol=2e-7)
+    assert np.all(a[4] == 0)            # fully outside -> zeros
+    assert np.isfinite(a).all()         # degenerate box is forced to >= 1x1 px, never NaN
+    # and the strided sample recorded when the reference's deepim_crops_robust ran on this stub
+    images = syn.make_frames(13, 6, 480, 640)
+    bc = golden['fn_boxes_crop']
+    rois = np.concatenate([np.arange(6, dtype=np.float32)[:, None], bc], 1)
+    crops = oracle.roi_align(images, rois, (240, 320), 4)
+    np.testing.assert_allclose(crops[:, :, ::7, ::11], golden['fn_crops_sample'], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize('name,hw,seed', [('240x320', (240, 320), 21), ('256x256', (256, 256), 22)])
+def test_backbone_vs_reference(oracle, golden, golden_sd, name, hw, seed):
+    x = np.random.RandomState(seed).random_sample((2, 6) + hw).astype(np.float32)
+    blob = oracle.flatten_state_dict(golden_sd)
+    feat, pose, taps = oracle.b3_forward(x, blob, want_taps=True)
+    g = golden[f'bb_{name}_taps']
+    assert np.abs(taps - g).max() / np.abs(g).max() < 1e-5
+    assert rel_err(feat, golden[f'bb_{name}_feat']) < 1e-5
+    assert rel_err(pose, golden[f'bb_{name}_pose']) < 1e-6
+    # and the torch-CPU functional restatement used for the CPU baseline
+    f2, p2 = oracle.TorchRef(golden_sd).net_forward(x)
+    assert rel_err(f2, golden[f'bb_{name}_feat']) < 1e-5
+    assert rel_err(p2, golden[f'bb_{name}_pose']) < 1e-6
+
+
+@pytest.mark.parametrize('name,B,n_it,hw,seed', [('b1_n1_480', 1, 1, (480, 640), 31), ('b3_n4_480', 3, 4, (480, 640), 32),
+                                                 ('b3_n1_540', 3, 1, (540, 720), 33)])
+def test_pose_predictor_forward_vs_reference(oracle, golden, golden_sd, mesh_table, name, B, n_it, hw, seed):
+    """the whole loop on the oracle == PosePredictor.forward of the reference."""
+    h, w = hw
+    obj = golden[f'fw_{name}_obj']
+    images = syn.make_frames(seed + 100, B, h, w); K = syn.make_K(B, h, w); TCO = syn.make_TCO(seed + 200, B)
+    calls = [0]
+
+    def render(n, TCO_in, K_crop):
+        r = syn.make_renders(seed * 1000 + calls[0], B, 240, 320); calls[0] += 1
+        return r
+    tr = oracle.TorchRef(golden_sd)
+    out = oracle.pose_predictor_forward(images, K, obj, TCO, mesh_table, None, render, n_it, (240, 320),
+                                        backbone=tr.net_forward)
+    for n in range(1, n_it + 1):
+        it = out[f'iteration={n}']
+        for k in ('TCO_input', 'TCO_output', 'K_crop', 'boxes_rend', 'boxes_crop', 'pose'):
+            assert rel_err(it[k], golden[f'fw_{name}_it{n}_{k}']) < 1e-5, (n, k)
+
+
+def test_scatter_argmin_vs_reference_cext(oracle, golden):
+    """Index op: bit-exact vs the reference's compiled C++ (cosypose_cext.cpp:218-245)."""
+    if 'cext_argmin' not in golden:
+        pytest.skip('cext goldens absent')
+    got = oracle.scatter_argmin(golden['cext_dists'], golden['cext_ids'], len(golden['cext_argmin']))
+    assert np.array_equal(got, golden['cext_argmin'])
