@@ -1,0 +1,76 @@
+"""ctypes binding of libcosyhip.so (the C ABI declared in include/cosyhip.h).
+
+There is no fallback: if the HIP library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+from .build import LIB
+
+COSY_F32, COSY_BF16 = 0, 1
+_lib = None
+
+_c = ctypes
+_P, _I, _F, _SZ = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
+
+_SIGNATURES = {
+    'cosy_version': ([], _I),
+    'cosy_last_error': ([], _c.c_char_p),
+    'cosy_effnet_b3_param_count': ([], _c.c_long),
+    'cosy_effnet_b3_out_hw': ([_I, _I, _c.POINTER(_I), _c.POINTER(_I)], _I),
+    'cosy_effnet_b3_create': ([_P, _SZ, _I, _I, _I, _I, _c.POINTER(_P)], _I),
+    'cosy_effnet_b3_destroy': ([_P], _I),
+    'cosy_effnet_b3_workspace_bytes': ([_P], _SZ),
+    'cosy_effnet_b3_set_input_nchw': ([_P, _P, _I, _P], _I),
+    'cosy_effnet_b3_features_nchw': ([_P, _I, _P, _P], _I),
+    'cosy_crop_pack': ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    'cosy_effnet_b3_forward': ([_P, _I, _P, _P, _P, _P], _I),
+    'cosy_crop_geometry': ([_P, _P, _P, _P, _P, _I, _I, _F, _I, _I, _I, _I, _F, _P, _P, _P, _P], _I),
+    'cosy_roi_align': ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P], _I),
+    'cosy_pose_update': ([_P, _P, _P, _I, _P, _P], _I),
+    'cosy_tco_init_from_boxes': ([_P, _P, _P, _I, _F, _P, _P], _I),
+    'cosy_tco_init_zup_autodepth': ([_P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
+    'cosy_scatter_argmin': ([_P, _P, _I, _I, _P, _P], _I),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+
+class CosyHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise CosyHipError(f'{LIB} not found: build it with `python -m cosypose_amd.build` '
+                               '(or __graft_entry__.build()); cosypose_amd has no CPU / eager fallback')
+        l = ctypes.CDLL(LIB)
+        for name, (args, res) in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = res
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise CosyHipError(f'libcosyhip error {rc}: {lib().cosy_last_error().decode()}')
+
+
+def ptr(t):
+    """Device pointer of a contiguous torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise CosyHipError('cosypose_amd runs on a ROCm device only (got a CPU tensor); there is no CPU fallback')

@@ -1,0 +1,375 @@
+// cosy_net_t: packed EfficientNet-B3(6ch) weights + activation workspace, and the layer schedule.
+// Also hosts the extern "C" boundary declared in include/cosyhip.h.
+#include "kernels_net.h"
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+
+namespace cosy {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// (k, s, expand, cin, cout): reference block strings cosypose/models/efficientnet_utils.py:259-264 scaled by
+// width 1.2 / depth 1.4 (round_filters :60-72, round_repeats :75-80).  Mirrors cosypose_amd/arch.py.
+struct BlkDef { int k, s, e, cin, cout; };
+static const BlkDef B3[26] = {
+    {3, 1, 1, 40, 24},   {3, 1, 1, 24, 24},
+    {3, 2, 6, 24, 32},   {3, 1, 6, 32, 32},   {3, 1, 6, 32, 32},
+    {5, 2, 6, 32, 48},   {5, 1, 6, 48, 48},   {5, 1, 6, 48, 48},
+    {3, 2, 6, 48, 96},   {3, 1, 6, 96, 96},   {3, 1, 6, 96, 96},   {3, 1, 6, 96, 96},   {3, 1, 6, 96, 96},
+    {5, 1, 6, 96, 136},  {5, 1, 6, 136, 136}, {5, 1, 6, 136, 136}, {5, 1, 6, 136, 136}, {5, 1, 6, 136, 136},
+    {5, 2, 6, 136, 232}, {5, 1, 6, 232, 232}, {5, 1, 6, 232, 232}, {5, 1, 6, 232, 232}, {5, 1, 6, 232, 232}, {5, 1, 6, 232, 232},
+    {3, 1, 6, 232, 384}, {3, 1, 6, 384, 384},
+};
+static const int STAGE_END[7] = {1, 4, 7, 12, 17, 23, 25};
+enum { STEM_C = 40, HEAD_IN = 384, HEAD_C = 1536, IN_C = 6, N_POSE = 9 };
+static const double BN_EPS = 1e-3;
+
+// Conv2dStaticSamePadding(image_size=300): padding is fixed from the constructor's image size, not the input
+// (efficientnet_utils.py:130-141): s=1 -> (k-1)/2 both sides; s=2 -> total k-2, lo = tot/2.
+static void static_pad(int k, int s, int* lo, int* hi) {
+    if (s == 1) { *lo = *hi = (k - 1) / 2; }
+    else { const int tot = k - 2; *lo = tot / 2; *hi = tot - tot / 2; }
+}
+static int out_dim(int n, int k, int s) { int lo, hi; static_pad(k, s, &lo, &hi); return (n + lo + hi - k) / s + 1; }
+static int se_ch(int cin) { return cin / 4 > 1 ? cin / 4 : 1; }
+
+static long param_count() {
+    long n = (long)STEM_C * IN_C * 9 + 4 * STEM_C;
+    for (int i = 0; i < 26; ++i) {
+        const BlkDef& b = B3[i];
+        const int cmid = b.cin * b.e, cse = se_ch(b.cin);
+        if (b.e != 1) n += (long)cmid * b.cin + 4 * cmid;
+        n += (long)cmid * b.k * b.k + 4 * cmid + (long)cse * cmid + cse + (long)cmid * cse + cmid + (long)b.cout * cmid + 4 * b.cout;
+    }
+    return n + (long)HEAD_C * HEAD_IN + 4 * HEAD_C + N_POSE * HEAD_C + N_POSE;
+}
+
+struct PwLayer { int K = 0, N = 0; PwCfg cfg{4, 2}; void* Wp = nullptr; float* scale = nullptr; float* bias = nullptr; };
+struct Block {
+    BlkDef d; int cmid, cse, H, W, Ho, Wo, pad_lo, n_tiles; bool skip;
+    PwLayer exp, proj;
+    float *dw_w, *dw_scale, *dw_bias, *se_wr, *se_br, *se_we, *se_be;
+};
+
+}  // namespace cosy
+
+struct cosy_net {
+    int dtype, H, W, maxB, esz, Hs, Ws, Hf, Wf;
+    float *stem_w, *stem_scale, *stem_bias, *fc_w, *fc_b;
+    cosy::Block blk[26];
+    cosy::PwLayer head;
+    void *X, *act[2], *E, *D, *Hd;
+    float *partial, *gate;
+    void* wbase; void* abase;
+    size_t wbytes, abytes;
+};
+
+namespace cosy {
+
+// simple bump allocator over one hipMalloc'd slab
+struct Bump {
+    char* base = nullptr; size_t off = 0;
+    void* take(size_t bytes) { off = (off + 255) & ~(size_t)255; void* p = base ? base + off : nullptr; off += bytes; return p; }
+};
+
+static void fold_bn(const float* bn, int C, int Cpad, std::vector<float>& scale, std::vector<float>& bias) {
+    scale.assign(Cpad, 0.f); bias.assign(Cpad, 0.f);
+    for (int c = 0; c < C; ++c) {
+        const double s = (double)bn[c] / sqrt((double)bn[3 * C + c] + BN_EPS);
+        scale[c] = (float)s;
+        bias[c] = (float)((double)bn[C + c] - (double)bn[2 * C + c] * s);
+    }
+}
+
+// One pass = sizing (bump.base == nullptr) or filling.  Returns the number of blob floats consumed.
+static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hipError_t* herr) {
+    const float* p0 = p;
+    auto up_f32 = [&](const std::vector<float>& v) -> float* {
+        float* d = (float*)bump.take(v.size() * sizeof(float));
+        if (fill) { hipError_t e = hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) *herr = e; }
+        return d;
+    };
+    auto mk_pw = [&](PwLayer& L, const float* w, int K, int N, const float* bn) {
+        L.K = K; L.N = N; L.cfg = pw_choose_cfg(N);
+        const size_t ne = pw_packed_elems(K, N, L.cfg, n->dtype);
+        L.Wp = bump.take(ne * n->esz);
+        const int npad = cdiv(N, pw_bn(L.cfg)) * pw_bn(L.cfg);
+        std::vector<float> sc, bi;
+        if (fill) {
+            std::vector<char> tmp(ne * n->esz);
+            pw_pack_weights(w, K, N, L.cfg, n->dtype, tmp.data());
+            hipError_t e = hipMemcpy(L.Wp, tmp.data(), tmp.size(), hipMemcpyHostToDevice);
+            if (e != hipSuccess) *herr = e;
+            fold_bn(bn, N, npad, sc, bi);
+        } else { sc.assign(npad, 0.f); bi.assign(npad, 0.f); }
+        L.scale = up_f32(sc); L.bias = up_f32(bi);
+    };
+    // stem: (40,6,3,3) -> [ky][kx][ci][co]
+    {
+        std::vector<float> w(9 * IN_C * STEM_C), sc, bi;
+        if (fill)
+            for (int co = 0; co < STEM_C; ++co)
+                for (int ci = 0; ci < IN_C; ++ci)
+                    for (int t = 0; t < 9; ++t) w[(t * IN_C + ci) * STEM_C + co] = p[(co * IN_C + ci) * 9 + t];
+        p += STEM_C * IN_C * 9;
+        if (fill) fold_bn(p, STEM_C, STEM_C, sc, bi); else { sc.assign(STEM_C, 0.f); bi.assign(STEM_C, 0.f); }
+        p += 4 * STEM_C;
+        n->stem_w = up_f32(w); n->stem_scale = up_f32(sc); n->stem_bias = up_f32(bi);
+    }
+    int h = n->Hs, w_ = n->Ws;
+    for (int i = 0; i < 26; ++i) {
+        Block& b = n->blk[i];
+        b.d = B3[i]; b.cmid = b.d.cin * b.d.e; b.cse = se_ch(b.d.cin);
+        b.H = h; b.W = w_; b.Ho = out_dim(h, b.d.k, b.d.s); b.Wo = out_dim(w_, b.d.k, b.d.s);
+        int hi; static_pad(b.d.k, b.d.s, &b.pad_lo, &hi);
+        b.skip = (b.d.s == 1 && b.d.cin == b.d.cout);  // id_skip, efficientnet.py:94
+        b.n_tiles = dw_num_tiles(b.cmid, b.Ho, b.Wo, b.d.k);
+        if (b.d.e != 1) {
+            mk_pw(b.exp, p, b.d.cin, b.cmid, p + (size_t)b.cmid * b.d.cin);
+            p += (size_t)b.cmid * b.d.cin + 4 * b.cmid;
+        }
+        {   // depthwise (Cmid,1,k,k) -> [tap][Cmid]
+            const int kk = b.d.k * b.d.k;
+            std::vector<float> w(kk * b.cmid), sc, bi;
+            if (fill)
+                for (int c = 0; c < b.cmid; ++c)
+                    for (int t = 0; t < kk; ++t) w[t * b.cmid + c] = p[c * kk + t];
+            p += (size_t)b.cmid * kk;
+            if (fill) fold_bn(p, b.cmid, b.cmid, sc, bi); else { sc.assign(b.cmid, 0.f); bi.assign(b.cmid, 0.f); }
+            p += 4 * b.cmid;
+            b.dw_w = up_f32(w); b.dw_scale = up_f32(sc); b.dw_bias = up_f32(bi);
+        }
+        {   // SE: reduce (Cse,Cmid), bias, expand (Cmid,Cse) -> stored transposed (Cse,Cmid), bias
+            std::vector<float> wr(p, p + (fill ? (size_t)b.cse * b.cmid : 0)); if (!fill) wr.assign((size_t)b.cse * b.cmid, 0.f);
+            p += (size_t)b.cse * b.cmid;
+            std::vector<float> br(b.cse, 0.f); if (fill) br.assign(p, p + b.cse);
+            p += b.cse;
+            std::vector<float> we((size_t)b.cse * b.cmid, 0.f);
+            if (fill)
+                for (int c = 0; c < b.cmid; ++c)
+                    for (int j = 0; j < b.cse; ++j) we[(size_t)j * b.cmid + c] = p[(size_t)c * b.cse + j];
+            p += (size_t)b.cmid * b.cse;
+            std::vector<float> be(b.cmid, 0.f); if (fill) be.assign(p, p + b.cmid);
+            p += b.cmid;
+            b.se_wr = up_f32(wr); b.se_br = up_f32(br); b.se_we = up_f32(we); b.se_be = up_f32(be);
+        }
+        mk_pw(b.proj, p, b.cmid, b.d.cout, p + (size_t)b.d.cout * b.cmid);
+        p += (size_t)b.d.cout * b.cmid + 4 * b.d.cout;
+        h = b.Ho; w_ = b.Wo;
+    }
+    n->Hf = h; n->Wf = w_;
+    mk_pw(n->head, p, HEAD_IN, HEAD_C, p + (size_t)HEAD_C * HEAD_IN);
+    p += (size_t)HEAD_C * HEAD_IN + 4 * HEAD_C;
+    {
+        std::vector<float> fw(N_POSE * HEAD_C, 0.f), fb(N_POSE, 0.f);
+        if (fill) { fw.assign(p, p + N_POSE * HEAD_C); fb.assign(p + N_POSE * HEAD_C, p + N_POSE * HEAD_C + N_POSE); }
+        p += N_POSE * HEAD_C + N_POSE;
+        n->fc_w = up_f32(fw); n->fc_b = up_f32(fb);
+    }
+    return (long)(p - p0);
+}
+
+static void layout_workspace(cosy_net* n, Bump& b) {
+    const size_t B = n->maxB, e = n->esz;
+    size_t act = (size_t)n->Hs * n->Ws * STEM_C, ex = 0, dw = 0, part = 0, gate = 0;
+    for (int i = 0; i < 26; ++i) {
+        const Block& k = n->blk[i];
+        act = std::max(act, (size_t)k.Ho * k.Wo * k.d.cout);
+        if (k.d.e != 1) ex = std::max(ex, (size_t)k.H * k.W * k.cmid);
+        dw = std::max(dw, (size_t)k.Ho * k.Wo * k.cmid);
+        part = std::max(part, (size_t)k.n_tiles * k.cmid);
+        gate = std::max(gate, (size_t)k.cmid);
+    }
+    n->X = b.take(B * n->H * n->W * 8 * e);
+    n->act[0] = b.take(B * act * e);
+    n->act[1] = b.take(B * act * e);
+    n->E = b.take(B * ex * e);
+    n->D = b.take(B * dw * e);
+    n->Hd = b.take(B * (size_t)n->Hf * n->Wf * HEAD_C * e);
+    n->partial = (float*)b.take(B * part * sizeof(float));
+    n->gate = (float*)b.take(B * gate * sizeof(float));
+}
+
+static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps, hipStream_t s) {
+    int rc;
+    int tap_i = 0;
+    auto tap = [&](const void* act, int HW, int C) -> int {
+        if (!taps) return COSY_OK;
+        return launch_taps(act, B, HW, C, n->dtype, taps, tap_i++, s);
+    };
+    if ((rc = launch_stem(n->X, n->stem_w, n->stem_scale, n->stem_bias, n->act[0], B, n->H, n->W, n->Hs, n->Ws, n->dtype, s))) return rc;
+    if ((rc = tap(n->act[0], n->Hs * n->Ws, STEM_C))) return rc;
+    int cur = 0, si = 0;
+    for (int i = 0; i < 26; ++i) {
+        const Block& b = n->blk[i];
+        const void* src = n->act[cur];
+        if (b.d.e != 1) {
+            PwArgs a{};
+            a.A = n->act[cur]; a.Wp = b.exp.Wp; a.out = n->E; a.scale = b.exp.scale; a.bias = b.exp.bias;
+            a.M = B * b.H * b.W; a.K = b.d.cin; a.N = b.cmid; a.HW = b.H * b.W; a.silu = 1;
+            if ((rc = launch_pw_gemm(a, b.exp.cfg, n->dtype, s))) return rc;
+            src = n->E;
+        }
+        DwArgs d{};
+        d.in = src; d.w = b.dw_w; d.scale = b.dw_scale; d.bias = b.dw_bias; d.out = n->D; d.partial = n->partial;
+        d.B = B; d.H = b.H; d.W = b.W; d.C = b.cmid; d.Ho = b.Ho; d.Wo = b.Wo; d.k = b.d.k; d.s = b.d.s; d.pad_lo = b.pad_lo;
+        if ((rc = launch_dwconv(d, n->dtype, s))) return rc;
+        SeArgs e{};
+        e.partial = n->partial; e.n_tiles = b.n_tiles; e.w_red = b.se_wr; e.b_red = b.se_br; e.w_exp = b.se_we; e.b_exp = b.se_be;
+        e.gate = n->gate; e.B = B; e.C = b.cmid; e.Cse = b.cse; e.HW = b.Ho * b.Wo;
+        if ((rc = launch_se(e, s))) return rc;
+        PwArgs a{};
+        a.A = n->D; a.Wp = b.proj.Wp; a.out = n->act[cur ^ 1]; a.scale = b.proj.scale; a.bias = b.proj.bias;
+        a.res = b.skip ? n->act[cur] : nullptr; a.gate = n->gate;
+        a.M = B * b.Ho * b.Wo; a.K = b.cmid; a.N = b.d.cout; a.HW = b.Ho * b.Wo; a.silu = 0;
+        if ((rc = launch_pw_gemm(a, b.proj.cfg, n->dtype, s))) return rc;
+        cur ^= 1;
+        if (si < 7 && i == STAGE_END[si]) { if ((rc = tap(n->act[cur], b.Ho * b.Wo, b.d.cout))) return rc; ++si; }
+    }
+    PwArgs a{};
+    a.A = n->act[cur]; a.Wp = n->head.Wp; a.out = n->Hd; a.scale = n->head.scale; a.bias = n->head.bias;
+    a.M = B * n->Hf * n->Wf; a.K = HEAD_IN; a.N = HEAD_C; a.HW = n->Hf * n->Wf; a.silu = 1;
+    if ((rc = launch_pw_gemm(a, n->head.cfg, n->dtype, s))) return rc;
+    if ((rc = tap(n->Hd, n->Hf * n->Wf, HEAD_C))) return rc;
+    return launch_pool_fc(n->Hd, n->fc_w, n->fc_b, feat, nullptr, pose, B, n->Hf * n->Wf, n->dtype, s);
+}
+
+}  // namespace cosy
+
+using namespace cosy;
+
+extern "C" {
+
+int cosy_version(void) { return COSY_VERSION; }
+const char* cosy_last_error(void) { return g_err; }
+long cosy_effnet_b3_param_count(void) { return param_count(); }
+
+int cosy_effnet_b3_out_hw(int H, int W, int* oh, int* ow) {
+    COSY_REQUIRE(H >= 32 && W >= 32 && oh && ow, "out_hw: bad arguments");
+    int h = out_dim(H, 3, 2), w = out_dim(W, 3, 2);
+    for (int i = 0; i < 26; ++i) { h = out_dim(h, B3[i].k, B3[i].s); w = out_dim(w, B3[i].k, B3[i].s); }
+    *oh = h; *ow = w;
+    return COSY_OK;
+}
+
+int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, int H, int W, int max_batch, cosy_net_t** out) {
+    COSY_REQUIRE(host_params && out, "create: null argument");
+    COSY_REQUIRE(dtype == COSY_F32 || dtype == COSY_BF16, "create: dtype %d not supported (0=f32, 1=bf16)", dtype);
+    COSY_REQUIRE(H >= 32 && W >= 32 && max_batch >= 1, "create: bad shape H=%d W=%d max_batch=%d", H, W, max_batch);
+    if ((long)n_floats != param_count()) {
+        set_error("create: parameter blob has %zu floats, expected %ld", n_floats, param_count());
+        return COSY_ESIZE;
+    }
+    cosy_net* n = (cosy_net*)calloc(1, sizeof(cosy_net));
+    if (!n) { set_error("create: host allocation failed"); return COSY_ENOMEM; }
+    n->dtype = dtype; n->H = H; n->W = W; n->maxB = max_batch; n->esz = dtype == COSY_F32 ? 4 : 2;
+    n->Hs = out_dim(H, 3, 2); n->Ws = out_dim(W, 3, 2);
+    hipError_t herr = hipSuccess;
+    Bump wb;
+    const long used = build_weights(n, host_params, wb, false, &herr);
+    if (used != param_count()) { set_error("create: internal blob walk mismatch %ld", used); free(n); return COSY_EINVAL; }
+    n->wbytes = wb.off + 256;
+    Bump ab;
+    layout_workspace(n, ab);
+    n->abytes = ab.off + 256;
+    if (hipMalloc(&n->wbase, n->wbytes) != hipSuccess || hipMalloc(&n->abase, n->abytes) != hipSuccess) {
+        set_error("create: hipMalloc of %zu + %zu bytes failed", n->wbytes, n->abytes);
+        if (n->wbase) (void)hipFree(n->wbase);
+        free(n);
+        return COSY_ENOMEM;
+    }
+    wb.base = (char*)n->wbase; wb.off = 0;
+    build_weights(n, host_params, wb, true, &herr);
+    ab.base = (char*)n->abase; ab.off = 0;
+    layout_workspace(n, ab);
+    if (herr == hipSuccess) herr = hipMemset(n->abase, 0, n->abytes);
+    if (herr != hipSuccess) {
+        set_error("create: weight upload failed: %s", hipGetErrorString(herr));
+        (void)hipFree(n->wbase); (void)hipFree(n->abase); free(n);
+        return COSY_EHIP;
+    }
+    *out = n;
+    return COSY_OK;
+}
+
+int cosy_effnet_b3_destroy(cosy_net_t* n) {
+    if (!n) return COSY_OK;
+    (void)hipFree(n->wbase); (void)hipFree(n->abase);
+    free(n);
+    return COSY_OK;
+}
+
+size_t cosy_effnet_b3_workspace_bytes(const cosy_net_t* n) { return n ? n->abytes + n->wbytes : 0; }
+
+int cosy_effnet_b3_set_input_nchw(cosy_net_t* n, const float* x, int B, cosy_stream_t stream) {
+    COSY_REQUIRE(n && x, "set_input: null argument");
+    COSY_REQUIRE(B >= 0 && B <= n->maxB, "set_input: batch %d exceeds max_batch %d", B, n->maxB);
+    return launch_pack_nchw(n->X, n->dtype, x, B, n->H, n->W, (hipStream_t)stream);
+}
+
+int cosy_crop_pack(cosy_net_t* n, const float* images, const int* im_id, const float* boxes_crop, const float* renders, int B,
+                   int N, int h, int w, cosy_stream_t stream) {
+    COSY_REQUIRE(n && images && boxes_crop && renders, "crop_pack: null argument");
+    COSY_REQUIRE(B >= 0 && B <= n->maxB, "crop_pack: batch %d exceeds max_batch %d", B, n->maxB);
+    return launch_crop_pack(n->X, n->dtype, images, im_id, boxes_crop, renders, B, N, h, w, n->H, n->W, (hipStream_t)stream);
+}
+
+int cosy_effnet_b3_forward(cosy_net_t* n, int B, float* feat, float* pose9, float* taps, cosy_stream_t stream) {
+    COSY_REQUIRE(n && pose9, "forward: null argument");
+    COSY_REQUIRE(B >= 0 && B <= n->maxB, "forward: batch %d exceeds max_batch %d", B, n->maxB);
+    return net_forward(n, B, feat, pose9, taps, (hipStream_t)stream);
+}
+
+int cosy_effnet_b3_features_nchw(cosy_net_t* n, int B, float* out, cosy_stream_t stream) {
+    COSY_REQUIRE(n && out, "features_nchw: null argument");
+    COSY_REQUIRE(B >= 0 && B <= n->maxB, "features_nchw: batch %d exceeds max_batch %d", B, n->maxB);
+    return launch_nhwc_to_nchw(n->Hd, B, n->Hf * n->Wf, HEAD_C, n->dtype, out, (hipStream_t)stream);
+}
+
+int cosy_crop_geometry(const float* pts_table, const int* obj_id, const float* K, const int* im_id, const float* TCO, int B, int P,
+                       float z_min, int im_h, int im_w, int out_h, int out_w, float lamb, float* boxes_rend, float* boxes_crop,
+                       float* K_crop, cosy_stream_t stream) {
+    COSY_REQUIRE(pts_table && obj_id && K && TCO && boxes_rend && boxes_crop && K_crop, "crop_geometry: null argument");
+    COSY_REQUIRE(B >= 0 && P >= 1, "crop_geometry: bad sizes B=%d P=%d", B, P);
+    return launch_crop_geometry(pts_table, obj_id, K, im_id, TCO, B, P, z_min, im_h, im_w, out_h, out_w, lamb, boxes_rend,
+                                boxes_crop, K_crop, (hipStream_t)stream);
+}
+
+int cosy_roi_align(const float* images, const int* im_id, const float* boxes, int B, int N, int C, int h, int w, int out_h,
+                   int out_w, int sampling_ratio, float* out, cosy_stream_t stream) {
+    COSY_REQUIRE(images && boxes && out, "roi_align: null argument");
+    return launch_roi_align(images, im_id, boxes, B, N, C, h, w, out_h, out_w, sampling_ratio, out, (hipStream_t)stream);
+}
+
+int cosy_pose_update(const float* TCO_in, const float* K_crop, const float* pose9, int B, float* TCO_out, cosy_stream_t stream) {
+    COSY_REQUIRE(TCO_in && K_crop && pose9 && TCO_out, "pose_update: null argument");
+    return launch_pose_update(TCO_in, K_crop, pose9, B, TCO_out, (hipStream_t)stream);
+}
+
+int cosy_tco_init_from_boxes(const float* boxes, const float* K, const int* im_id, int B, float z, float* TCO, cosy_stream_t stream) {
+    COSY_REQUIRE(boxes && K && TCO, "tco_init_from_boxes: null argument");
+    return launch_tco_init_from_boxes(boxes, K, im_id, B, z, TCO, (hipStream_t)stream);
+}
+
+int cosy_tco_init_zup_autodepth(const float* boxes, const float* pts_table, const int* obj_id, const float* K, const int* im_id,
+                                int B, int P, float* TCO, cosy_stream_t stream) {
+    COSY_REQUIRE(boxes && pts_table && obj_id && K && TCO, "tco_init_zup_autodepth: null argument");
+    return launch_tco_init_zup(boxes, pts_table, obj_id, K, im_id, B, P, TCO, (hipStream_t)stream);
+}
+
+int cosy_scatter_argmin(const float* dists, const int* ids, int M, int n_seg, int* out, cosy_stream_t stream) {
+    COSY_REQUIRE(dists && ids && out, "scatter_argmin: null argument");
+    return launch_scatter_argmin(dists, ids, M, n_seg, out, (hipStream_t)stream);
+}
+
+}  // extern "C"

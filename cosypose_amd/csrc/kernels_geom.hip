@@ -1,0 +1,379 @@
+// Geometry / crop kernels of the pose-refinement loop (gfx950, wave64).
+// fp32 throughout; FMA contraction is disabled so that results are bit-comparable with the
+// CPU oracle (oracle/cosy_oracle.c), which restates the reference's torch arithmetic.
+#include "cosy_common.h"
+#include <math.h>
+
+#pragma clang fp contract(off)
+
+namespace cosy {
+
+// ----------------------------------------------------------------------------------------
+// crop geometry: one wavefront per object.
+// project_points_robust + boxes_from_uv (camera_geometry.py:18-42), deepim_boxes
+// (cropping.py:7-47), get_K_crop_resize (camera_geometry.py:45-87).
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_min(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ void k_times_t(const float* K, const float* T, float* P) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float acc = 0.f;
+            for (int k = 0; k < 3; ++k) acc += K[i * 3 + k] * T[k * 4 + j];
+            P[i * 4 + j] = acc;
+        }
+}
+
+__device__ __forceinline__ void project1(const float* P, float x, float y, float z, float z_min, float& u, float& v) {
+    float s0 = P[0] * x + P[1] * y + P[2] * z + P[3] * 1.0f;
+    float s1 = P[4] * x + P[5] * y + P[6] * z + P[7] * 1.0f;
+    float s2 = P[8] * x + P[9] * y + P[10] * z + P[11] * 1.0f;
+    float zz = s2 > z_min ? s2 : z_min;
+    if (s2 != s2) zz = s2;
+    u = s0 / zz;
+    v = s1 / zz;
+}
+
+__global__ __launch_bounds__(64) void crop_geometry_kernel(const float* __restrict__ pts_table, const int* __restrict__ obj_id,
+                                                           const float* __restrict__ K, const int* __restrict__ im_id,
+                                                           const float* __restrict__ TCO, int P, float z_min, int im_h, int im_w,
+                                                           int out_h, int out_w, float lamb, float* __restrict__ boxes_rend,
+                                                           float* __restrict__ boxes_crop, float* __restrict__ K_crop) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* Kb = K + (size_t)(im_id ? im_id[b] : b) * 9;
+    const float* T = TCO + (size_t)b * 16;
+    float Kl[9], Tl[12], Pm[12];
+    for (int i = 0; i < 9; ++i) Kl[i] = Kb[i];
+    for (int i = 0; i < 12; ++i) Tl[i] = T[i];
+    k_times_t(Kl, Tl, Pm);
+    const float* pts = pts_table + (size_t)obj_id[b] * P * 3;
+    float x1 = INFINITY, y1 = INFINITY, x2 = -INFINITY, y2 = -INFINITY;
+    int nan = 0;
+    for (int p = lane; p < P; p += 64) {
+        float u, v;
+        project1(Pm, pts[p * 3], pts[p * 3 + 1], pts[p * 3 + 2], z_min, u, v);
+        nan |= (u != u) | (v != v);
+        x1 = fminf(x1, u); x2 = fmaxf(x2, u);
+        y1 = fminf(y1, v); y2 = fmaxf(y2, v);
+    }
+    x1 = wave_min(x1); y1 = wave_min(y1); x2 = wave_max(x2); y2 = wave_max(y2);
+    nan = __any(nan);
+    if (lane != 0) return;
+    if (nan) x1 = y1 = x2 = y2 = NAN;
+    float* br = boxes_rend + (size_t)b * 4;
+    br[0] = x1; br[1] = y1; br[2] = x2; br[3] = y2;
+    float xc, yc;
+    project1(Pm, 0.f, 0.f, 0.f, z_min, xc, yc);
+    const int wmax = im_h > im_w ? im_h : im_w, hmin = im_h > im_w ? im_w : im_h;
+    const float r = (float)((double)wmax / (double)hmin);
+    // obs_boxes == rend_boxes on this path (pose.py:55, cropping.py:69-72)
+    float xd = fmaxf(fabsf(x1 - xc), fabsf(x2 - xc));
+    float yd = fmaxf(fabsf(y1 - yc), fabsf(y2 - yc));
+    if (nan) xd = yd = NAN;
+    float width = fmaxf(xd, yd * r) * 2.f * lamb;
+    float height = fmaxf(xd / r, yd) * 2.f * lamb;
+    if (xd != xd || yd != yd) width = height = NAN;
+    float bx0 = xc - width / 2.f, by0 = yc - height / 2.f, bx1 = xc + width / 2.f, by1 = yc + height / 2.f;
+    float* bc = boxes_crop + (size_t)b * 4;
+    bc[0] = bx0; bc[1] = by0; bc[2] = bx1; bc[3] = by1;
+    // get_K_crop_resize: final_width = max(crop_resize), final_height = min(crop_resize)
+    const float fw = (float)(out_h > out_w ? out_h : out_w), fh = (float)(out_h > out_w ? out_w : out_h);
+    float cw = bx1 - bx0, ch = by1 - by0;
+    float cj = (bx0 + bx1) / 2.f, ci = (by0 + by1) / 2.f;
+    float cx = Kl[2] + (cw - 1.f) / 2.f - cj;
+    float cy = Kl[5] + (ch - 1.f) / 2.f - ci;
+    float center_x = (cw - 1.f) / 2.f, center_y = (ch - 1.f) / 2.f;
+    float dx = cx - center_x, dy = cy - center_y;
+    float sx = fw / cw, sy = fh / ch;
+    float scx = (fw - 1.f) / 2.f, scy = (fh - 1.f) / 2.f;
+    float* ko = K_crop + (size_t)b * 9;
+    for (int i = 0; i < 9; ++i) ko[i] = Kl[i];
+    ko[0] = sx * Kl[0];
+    ko[4] = sy * Kl[4];
+    ko[2] = scx + sx * dx;
+    ko[5] = scy + sy * dy;
+}
+
+int launch_crop_geometry(const float* pts_table, const int* obj_id, const float* K, const int* im_id, const float* TCO,
+                         int B, int P, float z_min, int im_h, int im_w, int out_h, int out_w, float lamb,
+                         float* boxes_rend, float* boxes_crop, float* K_crop, hipStream_t s) {
+    if (B == 0) return COSY_OK;
+    hipLaunchKernelGGL(crop_geometry_kernel, dim3(B), dim3(64), 0, s, pts_table, obj_id, K, im_id, TCO, P, z_min, im_h,
+                       im_w, out_h, out_w, lamb, boxes_rend, boxes_crop, K_crop);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// roi_align (torchvision 0.4.2 semantics: no `aligned`, roi size clamped to >= 1, taps outside
+// [-1, size] contribute 0, clamp at the borders).  One thread per output pixel, C channels.
+// ----------------------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ void roi_pixel(const float* __restrict__ img /* C planes of h*w */, int h, int w, float x1, float y1,
+                                          float bin_h, float bin_w, int ph, int pw, int g, float* acc) {
+    for (int c = 0; c < C; ++c) acc[c] = 0.f;
+    const size_t plane = (size_t)h * w;
+    for (int iy = 0; iy < g; ++iy) {
+        const float yy = y1 + ph * bin_h + ((float)iy + .5f) * bin_h / (float)g;
+        for (int ix = 0; ix < g; ++ix) {
+            const float xx = x1 + pw * bin_w + ((float)ix + .5f) * bin_w / (float)g;
+            float x = xx, y = yy;
+            if (y < -1.0f || y > (float)h || x < -1.0f || x > (float)w) continue;
+            if (y <= 0) y = 0;
+            if (x <= 0) x = 0;
+            int yl = (int)y, xl = (int)x, yh, xh;
+            if (yl >= h - 1) { yh = yl = h - 1; y = (float)yl; } else yh = yl + 1;
+            if (xl >= w - 1) { xh = xl = w - 1; x = (float)xl; } else xh = xl + 1;
+            const float ly = y - yl, lx = x - xl, hy = 1.f - ly, hx = 1.f - lx;
+            const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+            const int o1 = yl * w + xl, o2 = yl * w + xh, o3 = yh * w + xl, o4 = yh * w + xh;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float* p = img + c * plane;
+                acc[c] += w1 * p[o1] + w2 * p[o2] + w3 * p[o3] + w4 * p[o4];
+            }
+        }
+    }
+    const float count = (float)(g * g);
+    for (int c = 0; c < C; ++c) acc[c] = acc[c] / count;
+}
+
+__global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict__ images, const int* __restrict__ im_id,
+                                                        const float* __restrict__ boxes, int C, int h, int w, int PH, int PW,
+                                                        int g, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= PH * PW) return;
+    const int ph = pix / PW, pw = pix % PW;
+    const float* bx = boxes + (size_t)b * 4;
+    const float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
+    const float roi_w = fmaxf(x2 - x1, 1.f), roi_h = fmaxf(y2 - y1, 1.f);
+    const float bin_h = roi_h / (float)PH, bin_w = roi_w / (float)PW;
+    const float* img = images + (size_t)(im_id ? im_id[b] : b) * C * h * w;
+    for (int c = 0; c < C; ++c) {
+        float a[1];
+        roi_pixel<1>(img + (size_t)c * h * w, h, w, x1, y1, bin_h, bin_w, ph, pw, g, a);
+        out[(((size_t)b * C + c) * PH + ph) * PW + pw] = a[0];
+    }
+}
+
+int launch_roi_align(const float* images, const int* im_id, const float* boxes, int B, int N, int C, int h, int w,
+                     int out_h, int out_w, int sampling, float* out, hipStream_t s) {
+    (void)N;
+    if (B == 0) return COSY_OK;
+    COSY_REQUIRE(sampling > 0, "roi_align: sampling_ratio must be > 0 (the reference uses 4)");
+    hipLaunchKernelGGL(roi_align_kernel, dim3(cdiv(out_h * out_w, 256), B), dim3(256), 0, s, images, im_id, boxes, C, h, w,
+                       out_h, out_w, sampling, out);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+
+// crop (3 ch) + render (3 ch) -> one NHWC8 pixel of the network input (channels 6,7 = 0)
+template <typename T>
+__device__ __forceinline__ void store_px8(T* dst, const float* v);
+template <>
+__device__ __forceinline__ void store_px8<float>(float* dst, const float* v) {
+    ((f32x4*)dst)[0] = f32x4{v[0], v[1], v[2], v[3]};
+    ((f32x4*)dst)[1] = f32x4{v[4], v[5], 0.f, 0.f};
+}
+template <>
+__device__ __forceinline__ void store_px8<bf16_t>(bf16_t* dst, const float* v) {
+    bf16x8 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3], (bf16_t)v[4], (bf16_t)v[5], (bf16_t)0.f, (bf16_t)0.f};
+    *(bf16x8*)dst = o;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void crop_pack_kernel(T* __restrict__ x, const float* __restrict__ images,
+                                                        const int* __restrict__ im_id, const float* __restrict__ boxes,
+                                                        const float* __restrict__ renders, int h, int w, int PH, int PW) {
+    const int b = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= PH * PW) return;
+    const int ph = pix / PW, pw = pix % PW;
+    const float* bx = boxes + (size_t)b * 4;
+    const float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
+    const float roi_w = fmaxf(x2 - x1, 1.f), roi_h = fmaxf(y2 - y1, 1.f);
+    const float bin_h = roi_h / (float)PH, bin_w = roi_w / (float)PW;
+    const float* img = images + (size_t)(im_id ? im_id[b] : b) * 3 * h * w;
+    float v[6];
+    roi_pixel<3>(img, h, w, x1, y1, bin_h, bin_w, ph, pw, 4, v);
+    const float* r = renders + (size_t)b * 3 * PH * PW + pix;
+    v[3] = r[0]; v[4] = r[(size_t)PH * PW]; v[5] = r[(size_t)2 * PH * PW];
+    store_px8<T>(x + ((size_t)b * PH * PW + pix) * 8, v);
+}
+
+int launch_crop_pack(void* x, int dtype, const float* images, const int* im_id, const float* boxes, const float* renders,
+                     int B, int N, int h, int w, int H, int W, hipStream_t s) {
+    (void)N;
+    if (B == 0) return COSY_OK;
+    dim3 grid(cdiv(H * W, 256), B);
+    if (dtype == COSY_F32)
+        hipLaunchKernelGGL(crop_pack_kernel<float>, grid, dim3(256), 0, s, (float*)x, images, im_id, boxes, renders, h, w, H, W);
+    else
+        hipLaunchKernelGGL(crop_pack_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)x, images, im_id, boxes, renders, h, w, H, W);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_nchw_kernel(T* __restrict__ x, const float* __restrict__ src, int HW) {
+    const int b = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    float v[6];
+    for (int c = 0; c < 6; ++c) v[c] = src[((size_t)b * 6 + c) * HW + pix];
+    store_px8<T>(x + ((size_t)b * HW + pix) * 8, v);
+}
+
+int launch_pack_nchw(void* x, int dtype, const float* x_nchw6, int B, int H, int W, hipStream_t s) {
+    if (B == 0) return COSY_OK;
+    dim3 grid(cdiv(H * W, 256), B);
+    if (dtype == COSY_F32)
+        hipLaunchKernelGGL(pack_nchw_kernel<float>, grid, dim3(256), 0, s, (float*)x, x_nchw6, H * W);
+    else
+        hipLaunchKernelGGL(pack_nchw_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)x, x_nchw6, H * W);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// pose update: ortho6d -> dR (rotations.py:6-21), apply_imagespace_predictions (cosypose_ops.py:10-31)
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void pose_update_kernel(const float* __restrict__ TCO, const float* __restrict__ Kc,
+                                                         const float* __restrict__ pose9, int B, float* __restrict__ out) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float* T = TCO + (size_t)b * 16; const float* k = Kc + (size_t)b * 9; const float* p = pose9 + (size_t)b * 9;
+    float* o = out + (size_t)b * 16;
+    const float a0 = p[0], a1 = p[1], a2 = p[2], c0 = p[3], c1 = p[4], c2 = p[5];
+    const float na = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+    const float x0 = a0 / na, x1 = a1 / na, x2 = a2 / na;
+    float z0 = x1 * c2 - x2 * c1, z1 = x2 * c0 - x0 * c2, z2 = x0 * c1 - x1 * c0;
+    const float nz = sqrtf(z0 * z0 + z1 * z1 + z2 * z2);
+    z0 /= nz; z1 /= nz; z2 /= nz;
+    const float y0 = z1 * x2 - z2 * x1, y1 = z2 * x0 - z0 * x2, y2 = z0 * x1 - z1 * x0;
+    const float d[9] = {x0, y0, z0, x1, y1, z1, x2, y2, z2};
+    float Tl[16];
+    for (int i = 0; i < 16; ++i) Tl[i] = T[i];
+    float ol[16];
+    for (int i = 0; i < 16; ++i) ol[i] = Tl[i];
+    const float zsrc = Tl[11], ztgt = p[8] * zsrc;
+    ol[11] = ztgt;
+    ol[3] = (p[6] / k[0] + Tl[3] / zsrc) * ztgt;
+    ol[7] = (p[7] / k[4] + Tl[7] / zsrc) * ztgt;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float acc = 0.f;
+            for (int q = 0; q < 3; ++q) acc += d[i * 3 + q] * Tl[q * 4 + j];
+            ol[i * 4 + j] = acc;
+        }
+    for (int i = 0; i < 16; ++i) o[i] = ol[i];
+}
+
+int launch_pose_update(const float* TCO_in, const float* K_crop, const float* pose9, int B, float* TCO_out, hipStream_t s) {
+    if (B == 0) return COSY_OK;
+    hipLaunchKernelGGL(pose_update_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, TCO_in, K_crop, pose9, B, TCO_out);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// pose initialisation (cosypose_ops.py:121-173)
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void tco_init_boxes_kernel(const float* __restrict__ boxes, const float* __restrict__ K,
+                                                            const int* __restrict__ im_id, int B, float z, float* __restrict__ TCO) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float* bx = boxes + (size_t)b * 4; const float* k = K + (size_t)(im_id ? im_id[b] : b) * 9;
+    float* T = TCO + (size_t)b * 16;
+    const float uc = (bx[0] + bx[2]) / 2.f, vc = (bx[1] + bx[3]) / 2.f;
+    float o[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    o[3] = ((uc - k[2]) * z) / k[0];
+    o[7] = ((vc - k[5]) * z) / k[4];
+    o[11] = z;
+    for (int i = 0; i < 16; ++i) T[i] = o[i];
+}
+
+int launch_tco_init_from_boxes(const float* boxes, const float* K, const int* im_id, int B, float z, float* TCO, hipStream_t s) {
+    if (B == 0) return COSY_OK;
+    hipLaunchKernelGGL(tco_init_boxes_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, boxes, K, im_id, B, z, TCO);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+
+__global__ __launch_bounds__(64) void tco_init_zup_kernel(const float* __restrict__ boxes, const float* __restrict__ pts_table,
+                                                          const int* __restrict__ obj_id, const float* __restrict__ K,
+                                                          const int* __restrict__ im_id, int P, float* __restrict__ TCO) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* bx = boxes + (size_t)b * 4; const float* k = K + (size_t)(im_id ? im_id[b] : b) * 9;
+    const float uc = (bx[0] + bx[2]) / 2.f, vc = (bx[1] + bx[3]) / 2.f;
+    const float zg = 1.0f;
+    float T[16] = {0, 1, 0, 0, 0, 0, -1, 0, -1, 0, 0, zg, 0, 0, 0, 1};
+    T[3] = ((uc - k[2]) * zg) / k[0];
+    T[7] = ((vc - k[5]) * zg) / k[4];
+    const float* pts = pts_table + (size_t)obj_id[b] * P * 3;
+    float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+    for (int p = lane; p < P; p += 64) {
+        const float q0 = pts[p * 3], q1 = pts[p * 3 + 1], q2 = pts[p * 3 + 2];
+        const float cx = (T[0] * q0 + T[1] * q1 + T[2] * q2) + T[3];
+        const float cy = (T[4] * q0 + T[5] * q1 + T[6] * q2) + T[7];
+        xmin = fminf(xmin, cx); xmax = fmaxf(xmax, cx);
+        ymin = fminf(ymin, cy); ymax = fmaxf(ymax, cy);
+    }
+    xmin = wave_min(xmin); ymin = wave_min(ymin); xmax = wave_max(xmax); ymax = wave_max(ymax);
+    if (lane != 0) return;
+    const float dx3 = xmax - xmin, dy3 = ymax - ymin;
+    const float bdx = (bx[2] - bx[0]) + 1.f, bdy = (bx[3] - bx[1]) + 1.f;
+    const float zdx = k[0] * dx3 / bdx, zdy = k[4] * dy3 / bdy;
+    const float z = (zdy + zdx) / 2.f;
+    T[3] = ((uc - k[2]) * z) / k[0];
+    T[7] = ((vc - k[5]) * z) / k[4];
+    T[11] = z;
+    float* o = TCO + (size_t)b * 16;
+    for (int i = 0; i < 16; ++i) o[i] = T[i];
+}
+
+int launch_tco_init_zup(const float* boxes, const float* pts_table, const int* obj_id, const float* K, const int* im_id,
+                        int B, int P, float* TCO, hipStream_t s) {
+    if (B == 0) return COSY_OK;
+    hipLaunchKernelGGL(tco_init_zup_kernel, dim3(B), dim3(64), 0, s, boxes, pts_table, obj_id, K, im_id, P, TCO);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// scatter_argmin (cosypose_cext.cpp:218-245): segmented argmin, first index wins.
+// Single-launch, deterministic: one wave per segment scans the (short) id list.
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void scatter_argmin_kernel(const float* __restrict__ dists, const int* __restrict__ ids, int M,
+                                                            int* __restrict__ out) {
+    const int seg = blockIdx.x, lane = threadIdx.x;
+    float best = INFINITY; int bi = -1;
+    for (int m = lane; m < M; m += 64) {
+        if (ids[m] != seg) continue;
+        const float d = dists[m];
+        if (bi < 0 || d < best) { best = d; bi = m; }   // strict <: first index wins within a lane
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        const bool take = oi >= 0 && (bi < 0 || ob < best || (ob == best && oi < bi));
+        if (take) { best = ob; bi = oi; }
+    }
+    if (lane == 0) out[seg] = bi;
+}
+
+int launch_scatter_argmin(const float* dists, const int* ids, int M, int n_seg, int* out, hipStream_t s) {
+    if (n_seg == 0) return COSY_OK;
+    hipLaunchKernelGGL(scatter_argmin_kernel, dim3(n_seg), dim3(64), 0, s, dists, ids, M, out);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+
+}  // namespace cosy

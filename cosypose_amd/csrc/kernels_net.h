@@ -1,0 +1,62 @@
+// Launchers of the backbone kernels (kernels_net.hip).  T = float or bf16_t selected by `dtype`.
+#pragma once
+#include "cosy_common.h"
+
+namespace cosy {
+
+// tile configuration of the pointwise-conv GEMM: BN = 16*NI*WN, BM = 64*(4/WN)
+struct PwCfg { int NI, WN; };
+static inline int pw_bn(PwCfg c) { return 16 * c.NI * c.WN; }
+static inline int pw_bm(PwCfg c) { return 64 * (4 / c.WN); }
+PwCfg pw_choose_cfg(int N);
+int pw_kb(int dtype);                     // k elements per fragment block: 32 (bf16) / 16 (f32)
+size_t pw_packed_elems(int K, int N, PwCfg c, int dtype);
+// host-side packing of a (N,K) fp32 weight into the kernel's fragment-block order (dst has elem size of dtype)
+void pw_pack_weights(const float* w, int K, int N, PwCfg c, int dtype, void* dst);
+
+struct PwArgs {
+    const void* A;       // (M,K) activations, NHWC rows
+    const void* Wp;      // packed weights
+    void* out;           // (M,N)
+    const float* scale;  // (N_pad) folded BN scale
+    const float* bias;   // (N_pad) folded BN bias
+    const void* res;     // (M,N) residual or null
+    const float* gate;   // (B,K) SE gate applied to A rows, or null
+    int M, K, N, HW;     // HW = rows per sample (for the gate)
+    int silu;
+};
+int launch_pw_gemm(const PwArgs& a, PwCfg cfg, int dtype, hipStream_t s);
+
+struct DwArgs {
+    const void* in;      // (B,H,W,C)
+    const float* w;      // (k*k, C) fp32 taps
+    const float* scale;  // (C)
+    const float* bias;   // (C)
+    void* out;           // (B,Ho,Wo,C)
+    float* partial;      // (B, n_tiles, C) per-tile sums of the activated output (SE squeeze)
+    int B, H, W, C, Ho, Wo, k, s, pad_lo;
+};
+int dw_num_tiles(int C, int Ho, int Wo, int k);
+int launch_dwconv(const DwArgs& a, int dtype, hipStream_t s);
+
+struct SeArgs {
+    const float* partial;  // (B, n_tiles, C)
+    int n_tiles;
+    const float* w_red;    // (Cse, C)
+    const float* b_red;    // (Cse)
+    const float* w_exp;    // (C, Cse)
+    const float* b_exp;    // (C)
+    float* gate;           // (B, C)
+    int B, C, Cse, HW;
+};
+int launch_se(const SeArgs& a, hipStream_t s);
+
+int launch_stem(const void* x_nhwc8, const float* w /*[3][3][6][40]*/, const float* scale, const float* bias, void* out,
+                int B, int H, int W, int Ho, int Wo, int dtype, hipStream_t s);
+int launch_pool_fc(const void* head /*(B,HW,1536)*/, const float* fc_w /*(9,1536)*/, const float* fc_b, float* feat_or_null,
+                   float* feat_scratch, float* pose, int B, int HW, int dtype, hipStream_t s);
+int launch_nhwc_to_nchw(const void* act /*(B,HW,C)*/, int B, int HW, int C, int dtype, float* out, hipStream_t s);
+int launch_taps(const void* act /*(B,HW,C)*/, int B, int HW, int C, int dtype, float* taps /*(B,9,16)*/, int tap_index,
+                hipStream_t s);
+
+}  // namespace cosy

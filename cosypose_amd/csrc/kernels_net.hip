@@ -1,0 +1,608 @@
+// EfficientNet-B3 backbone kernels for gfx950 (wave64, MFMA).  Activations are NHWC in
+// T = bf16 (throughput) or fp32 (parity); accumulation is always fp32.
+//
+//   pw_gemm   : 1x1 convolutions as GEMM on the matrix cores.  Operands are swapped (weights are the
+//               MFMA "A" operand, activations the "B" operand) so that each lane ends up holding
+//               contiguous output channels of one pixel -> wide NHWC stores; fragments travel
+//               global -> VGPR -> LDS in MFMA-fragment order ("lane-linear" 1 KiB blocks), which makes both
+//               the LDS writes and the ds_read_b128 fragment reads conflict-free without padding.
+//               Epilogue: folded BN scale/bias, optional SiLU, optional residual; prologue: optional
+//               squeeze-excite gate on the activation rows.
+//   dwconv    : depthwise kxk (k 3/5, stride 1/2) with static "same" padding folded into index math,
+//               BN+SiLU epilogue and deterministic per-tile partial sums for the SE squeeze.
+//   se        : squeeze -> reduce FC -> swish -> expand FC -> sigmoid gate, one workgroup per sample.
+//   stem      : dense 3x3 stride-2 conv 6->40 + BN + SiLU.
+//   pool_fc   : global average pool + Linear(1536, 9).
+#include "kernels_net.h"
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+namespace cosy {
+
+template <typename T> struct DT;
+template <> struct DT<float> { static constexpr int EPL = 4, KB = 16; typedef f32x4 raw_t; };
+template <> struct DT<bf16_t> { static constexpr int EPL = 8, KB = 32; typedef bf16x8 raw_t; };
+
+__device__ __forceinline__ void mma(f32x4& c, bf16x8 a, bf16x8 b) { c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void mma(f32x4& c, f32x4 a, f32x4 b) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], c, 0, 0, 0);
+}
+
+template <typename T> __device__ __forceinline__ float sigmoid_t(float x);
+template <> __device__ __forceinline__ float sigmoid_t<float>(float x) { return 1.f / (1.f + expf(-x)); }
+template <> __device__ __forceinline__ float sigmoid_t<bf16_t>(float x) { return __frcp_rn(1.f + __expf(-x)); }
+
+__device__ __forceinline__ void to_f32(const f32x4& r, float* v) { v[0] = r[0]; v[1] = r[1]; v[2] = r[2]; v[3] = r[3]; }
+__device__ __forceinline__ void to_f32(const bf16x8& r, float* v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)r[i];
+}
+__device__ __forceinline__ void from_f32(f32x4& r, const float* v) { r = f32x4{v[0], v[1], v[2], v[3]}; }
+__device__ __forceinline__ void from_f32(bf16x8& r, const float* v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (bf16_t)v[i];
+}
+
+// load / store 8 consecutive channels as fp32
+__device__ __forceinline__ void load8(const float* p, float* v) {
+    f32x4 a = ((const f32x4*)p)[0], b = ((const f32x4*)p)[1];
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float* v) { to_f32(*(const bf16x8*)p, v); }
+__device__ __forceinline__ void store8(float* p, const float* v) {
+    ((f32x4*)p)[0] = f32x4{v[0], v[1], v[2], v[3]};
+    ((f32x4*)p)[1] = f32x4{v[4], v[5], v[6], v[7]};
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float* v) { bf16x8 r; from_f32(r, v); *(bf16x8*)p = r; }
+__device__ __forceinline__ void store4(float* p, const float* v) { *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]}; }
+__device__ __forceinline__ void store4(bf16_t* p, const float* v) {
+    *(bf16x4*)p = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+}
+__device__ __forceinline__ void load4(const float* p, float* v) { f32x4 a = *(const f32x4*)p; v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; }
+__device__ __forceinline__ void load4(const bf16_t* p, float* v) {
+    bf16x4 a = *(const bf16x4*)p; v[0] = (float)a[0]; v[1] = (float)a[1]; v[2] = (float)a[2]; v[3] = (float)a[3];
+}
+
+// ==========================================================================================
+// pointwise conv GEMM
+// ==========================================================================================
+PwCfg pw_choose_cfg(int N) {
+    // BN options: 128 (NI4,WN2) 96 (NI3,WN2) 48 (NI3,WN1) 32 (NI2,WN1).  Cost = padded columns divided by a
+    // rough efficiency of the tile shape (narrow tiles re-read the activation rows more often).
+    const PwCfg opts[4] = {{4, 2}, {3, 2}, {3, 1}, {2, 1}};
+    const double eff[4] = {1.0, 0.9, 0.65, 0.5};
+    PwCfg best = opts[0];
+    double best_cost = -1;
+    for (int i = 0; i < 4; ++i) {
+        const int bn = pw_bn(opts[i]);
+        const double cost = (double)cdiv(N, bn) * bn / eff[i];
+        if (best_cost < 0 || cost < best_cost - 1e-9) { best_cost = cost; best = opts[i]; }
+    }
+    return best;
+}
+int pw_kb(int dtype) { return dtype == COSY_F32 ? 16 : 32; }
+static int pw_nkb_total(int K, int dtype) { int n = cdiv(K, pw_kb(dtype)); return (n + 1) & ~1; }
+size_t pw_packed_elems(int K, int N, PwCfg c, int dtype) {
+    const int epl = dtype == COSY_F32 ? 4 : 8;
+    return (size_t)cdiv(N, pw_bn(c)) * c.NI * c.WN * pw_nkb_total(K, dtype) * 64 * epl;
+}
+static inline uint16_t f32_to_bf16_host(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+void pw_pack_weights(const float* w, int K, int N, PwCfg c, int dtype, void* dst) {
+    const int epl = dtype == COSY_F32 ? 4 : 8, kb = pw_kb(dtype), nkb = pw_nkb_total(K, dtype);
+    const int NW = c.NI * c.WN, BN = pw_bn(c), NT = cdiv(N, BN);
+    size_t idx = 0;
+    for (int nt = 0; nt < NT; ++nt)
+        for (int nb = 0; nb < NW; ++nb)
+            for (int kbi = 0; kbi < nkb; ++kbi)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < epl; ++e, ++idx) {
+                        const int i = lane & 15, kg = lane >> 4, wn = nb / c.NI, ni = nb % c.NI;
+                        const int n = nt * BN + wn * 16 * c.NI + (i >> 2) * 4 * c.NI + ni * 4 + (i & 3);
+                        const int k = kbi * kb + kg * epl + e;
+                        const float v = (n < N && k < K) ? w[(size_t)n * K + k] : 0.f;
+                        if (dtype == COSY_F32) ((float*)dst)[idx] = v; else ((uint16_t*)dst)[idx] = f32_to_bf16_host(v);
+                    }
+}
+
+struct PwKArgs {
+    const void* A; const void* Wp; void* out; const float* scale; const float* bias; const void* res; const float* gate;
+    int M, K, N, HW, silu, MT, NT, nkb_total, nkb_valid;
+};
+
+template <typename T, int NI, int WN>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(PwKArgs a) {
+    using D = DT<T>;
+    using raw_t = typename D::raw_t;
+    constexpr int EPL = D::EPL, KB = D::KB;
+    constexpr int WM = 4 / WN, MI = 4, BM = 64 * WM, BN = 16 * NI * WN;
+    constexpr int NA = BM / 16, NW = NI * WN;  // fragment blocks per k-block
+    constexpr int NLA = 2 * NA / 4;            // A loads per thread per k-tile (2 k-blocks)
+    constexpr int NLW = (2 * NW + 3) / 4;
+    __shared__ __attribute__((aligned(16))) char lds[(NA + NW) * 2 * 1024];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    // XCD-aware tile order: workgroup id%8 selects the XCD; all n-tiles of one m-tile run on one XCD so
+    // the activation rows are fetched into a single L2.
+    const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
+    const int mt = (jj / a.NT) * 8 + xcd, nt = jj % a.NT;
+    if (mt >= a.MT) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const T* __restrict__ A = (const T*)a.A;
+    const T* __restrict__ Wp = (const T*)a.Wp;
+    const int K = a.K, M = a.M, N = a.N;
+
+    // ---- per-thread staging coordinates (wave w stages A row-blocks [w*NA/4, (w+1)*NA/4) x 2 k-blocks)
+    const int row = lane & 15, kg = lane >> 4;
+    const int mthr = m0 + wave * (NA / 4) * 16 + row;
+    const T* Athr = A + (size_t)mthr * K + kg * EPL;
+    int gofs[NLA / 2];
+#pragma unroll
+    for (int i = 0; i < NLA / 2; ++i) {
+        const int m = mthr + i * 16;
+        gofs[i] = (a.gate && m < M) ? (m / a.HW) * K : 0;
+    }
+    raw_t ra[NLA], rw[NLW];
+
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            const int mb = i >> 1, kbi = i & 1;
+            const int m = mthr + mb * 16, k = (kt * 2 + kbi) * KB + kg * EPL;
+            raw_t v;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) v[e] = 0;
+            if (m < M && k < K) {
+                v = *(const raw_t*)(Athr + (size_t)mb * 16 * K + (kt * 2 + kbi) * KB);
+                if (a.gate) {
+                    float f[EPL], g[EPL];
+                    to_f32(v, f);
+                    const float* gp = a.gate + gofs[mb] + k;
+#pragma unroll
+                    for (int e = 0; e < EPL; e += 4) load4(gp + e, g + e);
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) f[e] *= g[e];
+                    from_f32(v, f);
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NLW; ++i) {
+            const int wb = i * 4 + wave;
+            if (wb < 2 * NW) {
+                const int kbi = wb / NW, nb = wb % NW;
+                rw[i] = *(const raw_t*)(Wp + ((size_t)(nt * NW + nb) * a.nkb_total + kt * 2 + kbi) * 64 * EPL + lane * EPL);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            const int mb = wave * (NA / 4) + (i >> 1), kbi = i & 1;
+            *(raw_t*)(lds + (kbi * NA + mb) * 1024 + lane * 16) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NLW; ++i) {
+            const int wb = i * 4 + wave;
+            if (wb < 2 * NW) {
+                const int kbi = wb / NW, nb = wb % NW;
+                *(raw_t*)(lds + (2 * NA + kbi * NW + nb) * 1024 + lane * 16) = rw[i];
+            }
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = (a.nkb_valid + 1) >> 1;
+    load_tile(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const int nv = a.nkb_valid - kt * 2 < 2 ? a.nkb_valid - kt * 2 : 2;
+        for (int kbi = 0; kbi < nv; ++kbi) {
+            raw_t fw[NI], fa[MI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) fw[ni] = *(const raw_t*)(lds + (2 * NA + kbi * NW + wn * NI + ni) * 1024 + lane * 16);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) fa[mi] = *(const raw_t*)(lds + (kbi * NA + wm * MI + mi) * 1024 + lane * 16);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], fw[ni], fa[mi]);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds, for pixel row m, the 4*NI consecutive channels starting at nl
+    const int nl = n0 + wn * 16 * NI + kg * 4 * NI;
+    float sc[NI][4], bi[NI][4];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        load4(a.scale + nl + ni * 4, sc[ni]);
+        load4(a.bias + nl + ni * 4, bi[ni]);
+    }
+    T* __restrict__ out = (T*)a.out;
+    const T* __restrict__ res = (const T*)a.res;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + (wm * MI + mi) * 16 + row;
+        if (m >= M) continue;
+        float y[NI * 4];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[mi][ni][r] * sc[ni][r] + bi[ni][r];
+                if (a.silu) v = v * sigmoid_t<T>(v);
+                y[ni * 4 + r] = v;
+            }
+        const size_t o = (size_t)m * N + nl;
+        if (res) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                if (nl + ni * 4 < N) {
+                    float rv[4];
+                    load4(res + o + ni * 4, rv);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[ni * 4 + r] += rv[r];
+                }
+        }
+        if constexpr (sizeof(T) == 2 && NI % 2 == 0) {
+            // two adjacent 4-channel groups -> one 16-byte store (nl and N are multiples of 8)
+#pragma unroll
+            for (int ni = 0; ni < NI; ni += 2)
+                if (nl + ni * 4 < N) store8(out + o + ni * 4, y + ni * 4);
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                if (nl + ni * 4 < N) store4(out + o + ni * 4, y + ni * 4);
+        }
+    }
+}
+
+template <typename T>
+static int launch_pw_t(const PwArgs& a, PwCfg c, int dtype, hipStream_t s) {
+    PwKArgs k;
+    k.A = a.A; k.Wp = a.Wp; k.out = a.out; k.scale = a.scale; k.bias = a.bias; k.res = a.res; k.gate = a.gate;
+    k.M = a.M; k.K = a.K; k.N = a.N; k.HW = a.HW; k.silu = a.silu;
+    k.MT = cdiv(a.M, pw_bm(c)); k.NT = cdiv(a.N, pw_bn(c));
+    k.nkb_total = pw_nkb_total(a.K, dtype); k.nkb_valid = cdiv(a.K, pw_kb(dtype));
+    const int grid = cdiv(k.MT, 8) * 8 * k.NT;
+    if (c.NI == 4 && c.WN == 2) hipLaunchKernelGGL((pw_gemm_kernel<T, 4, 2>), dim3(grid), dim3(256), 0, s, k);
+    else if (c.NI == 3 && c.WN == 2) hipLaunchKernelGGL((pw_gemm_kernel<T, 3, 2>), dim3(grid), dim3(256), 0, s, k);
+    else if (c.NI == 3 && c.WN == 1) hipLaunchKernelGGL((pw_gemm_kernel<T, 3, 1>), dim3(grid), dim3(256), 0, s, k);
+    else if (c.NI == 2 && c.WN == 1) hipLaunchKernelGGL((pw_gemm_kernel<T, 2, 1>), dim3(grid), dim3(256), 0, s, k);
+    else { set_error("pw_gemm: unsupported tile config NI=%d WN=%d", c.NI, c.WN); return COSY_EINVAL; }
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+
+int launch_pw_gemm(const PwArgs& a, PwCfg cfg, int dtype, hipStream_t s) {
+    if (a.M == 0) return COSY_OK;
+    COSY_REQUIRE(a.K % 8 == 0 && a.N % 8 == 0, "pw_gemm: K=%d and N=%d must be multiples of 8", a.K, a.N);
+    return dtype == COSY_F32 ? launch_pw_t<float>(a, cfg, dtype, s) : launch_pw_t<bf16_t>(a, cfg, dtype, s);
+}
+
+// ==========================================================================================
+// depthwise conv + BN + SiLU + squeeze partial sums
+// ==========================================================================================
+static int dw_cgb(int C) {  // channel groups (of 8) per workgroup: largest divisor of C/8 that is <= 32
+    const int cg = C / 8;
+    int best = 1;
+    for (int d = 1; d <= 32 && d <= cg; ++d)
+        if (cg % d == 0) best = d;
+    return best;
+}
+static constexpr int DW_R = 4;  // output rows per thread
+int dw_num_tiles(int C, int Ho, int Wo, int k) {
+    (void)k;
+    const int pb = 256 / dw_cgb(C);
+    return cdiv((long)Wo * cdiv(Ho, DW_R), pb);
+}
+
+struct DwKArgs {
+    const void* in; const float* w; const float* scale; const float* bias; void* out; float* partial;
+    int H, W, C, Ho, Wo, lo, CGB, PB, n_strips, n_tiles;
+};
+
+template <typename T, int KS, int S>
+__global__ __launch_bounds__(256) void dwconv_kernel(DwKArgs a) {
+    constexpr int R = DW_R;
+    __shared__ float red[256 * 8];
+    const int t = threadIdx.x;
+    const int cgl = t % a.CGB, ps = t / a.CGB;
+    const int c0 = (blockIdx.x * a.CGB + cgl) * 8;
+    const int sid = blockIdx.y * a.PB + ps;
+    const int b = blockIdx.z;
+    const bool active = ps < a.PB && sid < a.n_strips;
+    float sum[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sum[c] = 0.f;
+    if (active) {
+        const int ox = sid % a.Wo, oy0 = (sid / a.Wo) * R;
+        const T* __restrict__ in = (const T*)a.in + (size_t)b * a.H * a.W * a.C + c0;
+        const float* __restrict__ w = a.w + c0;
+        float acc[R][8];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[r][c] = 0.f;
+#pragma unroll
+        for (int iyr = 0; iyr < (R - 1) * S + KS; ++iyr) {
+            const int iy = oy0 * S + iyr - a.lo;
+            if (iy < 0 || iy >= a.H) continue;
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const int ix = ox * S + kx - a.lo;
+                float v[8];
+                if (ix >= 0 && ix < a.W) load8(in + ((size_t)iy * a.W + ix) * a.C, v);
+                else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] = 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int ky = iyr - r * S;
+                    if (ky >= 0 && ky < KS) {
+                        float wv[8];
+                        load8(w + (size_t)(ky * KS + kx) * a.C, wv);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) acc[r][c] += wv[c] * v[c];
+                    }
+                }
+            }
+        }
+        float sc[8], bi[8];
+        load8(a.scale + c0, sc);
+        load8(a.bias + c0, bi);
+        T* __restrict__ out = (T*)a.out + (size_t)b * a.Ho * a.Wo * a.C + c0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int oy = oy0 + r;
+            if (oy >= a.Ho) break;
+            float y[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float v = acc[r][c] * sc[c] + bi[c];
+                v = v * sigmoid_t<T>(v);
+                y[c] = v;
+                sum[c] += v;
+            }
+            store8(out + ((size_t)oy * a.Wo + ox) * a.C, y);
+        }
+    }
+    // deterministic per-workgroup reduction of the squeeze sums: fixed order over the pixel strips
+#pragma unroll
+    for (int c = 0; c < 8; ++c) red[t * 8 + c] = sum[c];
+    __syncthreads();
+    if (t < a.CGB * 8) {
+        const int g = t >> 3, ch = t & 7;
+        float s = 0.f;
+        for (int p = 0; p < a.PB; ++p) s += red[(p * a.CGB + g) * 8 + ch];
+        a.partial[((size_t)b * a.n_tiles + blockIdx.y) * a.C + (blockIdx.x * a.CGB + g) * 8 + ch] = s;
+    }
+}
+
+template <typename T>
+static int launch_dw_t(const DwArgs& a, hipStream_t s) {
+    DwKArgs k;
+    k.in = a.in; k.w = a.w; k.scale = a.scale; k.bias = a.bias; k.out = a.out; k.partial = a.partial;
+    k.H = a.H; k.W = a.W; k.C = a.C; k.Ho = a.Ho; k.Wo = a.Wo; k.lo = a.pad_lo;
+    k.CGB = dw_cgb(a.C); k.PB = 256 / k.CGB;
+    k.n_strips = a.Wo * cdiv(a.Ho, DW_R);
+    k.n_tiles = cdiv(k.n_strips, k.PB);
+    dim3 grid((a.C / 8) / k.CGB, k.n_tiles, a.B);
+    if (a.k == 3 && a.s == 1) hipLaunchKernelGGL((dwconv_kernel<T, 3, 1>), grid, dim3(256), 0, s, k);
+    else if (a.k == 3 && a.s == 2) hipLaunchKernelGGL((dwconv_kernel<T, 3, 2>), grid, dim3(256), 0, s, k);
+    else if (a.k == 5 && a.s == 1) hipLaunchKernelGGL((dwconv_kernel<T, 5, 1>), grid, dim3(256), 0, s, k);
+    else if (a.k == 5 && a.s == 2) hipLaunchKernelGGL((dwconv_kernel<T, 5, 2>), grid, dim3(256), 0, s, k);
+    else { set_error("dwconv: unsupported k=%d s=%d", a.k, a.s); return COSY_EINVAL; }
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+int launch_dwconv(const DwArgs& a, int dtype, hipStream_t s) {
+    if (a.B == 0) return COSY_OK;
+    COSY_REQUIRE(a.C % 8 == 0, "dwconv: C=%d must be a multiple of 8", a.C);
+    return dtype == COSY_F32 ? launch_dw_t<float>(a, s) : launch_dw_t<bf16_t>(a, s);
+}
+
+// ==========================================================================================
+// squeeze-excite gate (efficientnet.py:85-88)
+// ==========================================================================================
+__global__ __launch_bounds__(256) void se_kernel(SeArgs a) {
+    extern __shared__ float sm[];
+    float* pooled = sm;          // C
+    float* redv = sm + a.C;      // Cse
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float inv = 1.f / (float)a.HW;
+    for (int c = tid; c < a.C; c += 256) {
+        float s = 0.f;
+        const float* p = a.partial + (size_t)b * a.n_tiles * a.C + c;
+        for (int t = 0; t < a.n_tiles; ++t) s += p[(size_t)t * a.C];
+        pooled[c] = s * inv;
+    }
+    __syncthreads();
+    for (int j = wave; j < a.Cse; j += 4) {
+        float s = 0.f;
+        const float* wr = a.w_red + (size_t)j * a.C;
+        for (int c = lane; c < a.C; c += 64) s += wr[c] * pooled[c];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) {
+            s += a.b_red[j];
+            redv[j] = s * (1.f / (1.f + expf(-s)));
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < a.C; c += 256) {
+        float s = 0.f;
+        for (int j = 0; j < a.Cse; ++j) s += a.w_exp[(size_t)j * a.C + c] * redv[j];  // w_exp stored (Cse, C)
+        s += a.b_exp[c];
+        a.gate[(size_t)b * a.C + c] = 1.f / (1.f + expf(-s));
+    }
+}
+int launch_se(const SeArgs& a, hipStream_t s) {
+    if (a.B == 0) return COSY_OK;
+    hipLaunchKernelGGL(se_kernel, dim3(a.B), dim3(256), (a.C + a.Cse) * sizeof(float), s, a);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+
+// ==========================================================================================
+// stem: 3x3 stride 2, 6 -> 40, static pad (lo 0, hi 1), BN + SiLU.  One thread per output pixel;
+// weights are wave-uniform (scalar loads), input pixel is one 16/32-byte NHWC8 vector per tap.
+// ==========================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void stem_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+                                                   const float* __restrict__ bias, T* __restrict__ out, int H, int W, int Ho, int Wo) {
+    const int b = blockIdx.y, pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= Ho * Wo) return;
+    const int oy = pix / Wo, ox = pix % Wo;
+    float acc[40];
+#pragma unroll
+    for (int c = 0; c < 40; ++c) acc[c] = 0.f;
+    const T* xb = x + (size_t)b * H * W * 8;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 + ky;
+        if (iy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 + kx;
+            float v[8];
+            if (ix < W) load8(xb + ((size_t)iy * W + ix) * 8, v);
+            else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = 0.f;
+            }
+#pragma unroll
+            for (int ci = 0; ci < 6; ++ci)
+#pragma unroll
+                for (int co = 0; co < 40; ++co) acc[co] += w[((ky * 3 + kx) * 6 + ci) * 40 + co] * v[ci];
+        }
+    }
+    T* o = out + ((size_t)b * Ho * Wo + pix) * 40;
+#pragma unroll
+    for (int g = 0; g < 5; ++g) {
+        float y[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float v = acc[g * 8 + c] * scale[g * 8 + c] + bias[g * 8 + c];
+            y[c] = v * sigmoid_t<T>(v);
+        }
+        store8(o + g * 8, y);
+    }
+}
+int launch_stem(const void* x, const float* w, const float* scale, const float* bias, void* out, int B, int H, int W, int Ho,
+                int Wo, int dtype, hipStream_t s) {
+    if (B == 0) return COSY_OK;
+    dim3 grid(cdiv(Ho * Wo, 256), B);
+    if (dtype == COSY_F32)
+        hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, s, (const float*)x, w, scale, bias, (float*)out, H, W, Ho, Wo);
+    else
+        hipLaunchKernelGGL(stem_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, w, scale, bias, (bf16_t*)out, H, W, Ho, Wo);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+
+// ==========================================================================================
+// global average pool + Linear(1536, 9)   (pose.py:83-86)
+// ==========================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void pool_fc_kernel(const T* __restrict__ head, const float* __restrict__ fw, const float* __restrict__ fb,
+                                                      float* __restrict__ feat, float* __restrict__ pose, int HW) {
+    constexpr int C = 1536;
+    __shared__ float f[C];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* h = head + (size_t)b * HW * C;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int p = 0; p < HW; ++p) s += (float)h[(size_t)p * C + c];
+        s = s / (float)HW;
+        f[c] = s;
+        if (feat) feat[(size_t)b * C + c] = s;
+    }
+    __syncthreads();
+    for (int j = wave; j < 9; j += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += fw[j * C + c] * f[c];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) pose[b * 9 + j] = s + fb[j];
+    }
+}
+int launch_pool_fc(const void* head, const float* fc_w, const float* fc_b, float* feat, float* feat_scratch, float* pose, int B,
+                   int HW, int dtype, hipStream_t s) {
+    (void)feat_scratch;
+    if (B == 0) return COSY_OK;
+    if (dtype == COSY_F32)
+        hipLaunchKernelGGL(pool_fc_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)head, fc_w, fc_b, feat, pose, HW);
+    else
+        hipLaunchKernelGGL(pool_fc_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)head, fc_w, fc_b, feat, pose, HW);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+
+// NHWC (T) -> NCHW fp32 export of an activation (API parity for backbone(x); not on the hot path)
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ act, int HW, int C, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // index in (C,HW)
+    if (i >= (size_t)HW * C) return;
+    const size_t c = i / HW, p = i % HW;
+    out[(size_t)b * HW * C + i] = (float)act[((size_t)b * HW + p) * C + c];
+}
+int launch_nhwc_to_nchw(const void* act, int B, int HW, int C, int dtype, float* out, hipStream_t s) {
+    if (B == 0) return COSY_OK;
+    dim3 grid(cdiv((long)HW * C, 256), B);
+    if (dtype == COSY_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, s, (const float*)act, HW, C, out);
+    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)act, HW, C, out);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+
+// ==========================================================================================
+// test probe: [mean, mean|x|, 14 strided samples] of one NHWC activation, indexed as if NCHW-flattened
+// ==========================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void taps_kernel(const T* __restrict__ act, int HW, int C, float* __restrict__ taps, int tap_index) {
+    __shared__ double s1[256], s2[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const T* a = act + (size_t)b * HW * C;
+    const size_t n = (size_t)HW * C;
+    double x1 = 0, x2 = 0;
+    for (size_t i = tid; i < n; i += 256) { const float v = (float)a[i]; x1 += v; x2 += fabsf(v); }
+    s1[tid] = x1; s2[tid] = x2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { s1[tid] += s1[tid + o]; s2[tid] += s2[tid + o]; }
+        __syncthreads();
+    }
+    float* t = taps + ((size_t)b * 9 + tap_index) * 16;
+    if (tid == 0) { t[0] = (float)(s1[0] / (double)n); t[1] = (float)(s2[0] / (double)n); }
+    if (tid < 14) {
+        const size_t idx = (size_t)(tid * 2 + 1) * n / 29;  // index in (C,H,W) order
+        const size_t c = idx / HW, p = idx % HW;
+        t[2 + tid] = (float)a[p * C + c];
+    }
+}
+int launch_taps(const void* act, int B, int HW, int C, int dtype, float* taps, int tap_index, hipStream_t s) {
+    if (B == 0) return COSY_OK;
+    if (dtype == COSY_F32) hipLaunchKernelGGL(taps_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)act, HW, C, taps, tap_index);
+    else hipLaunchKernelGGL(taps_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)act, HW, C, taps, tap_index);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+
+}  // namespace cosy

@@ -1,0 +1,147 @@
+"""EfficientNet-B3 backbone module: holds the parameters under the reference's state_dict
+keys and runs them through libcosyhip.so.
+
+Drop-in for `EfficientNet.from_name('efficientnet-b3', in_channels=6)`
+(cosypose/models/efficientnet.py:206-210): `load_state_dict` accepts reference checkpoints
+unchanged (`_conv_stem.weight`, `_bn0.*`, `_blocks.{i}._{expand_conv,bn0,depthwise_conv,bn1,
+se_reduce,se_expand,project_conv,bn2}.*`, `_conv_head.weight`, `_bn1.*`), `forward(x)`
+returns the (B,1536,h,w) feature map.  Inference (eval mode) only: training-mode batch-norm
+and drop_connect are out of scope for this round.
+"""
+import ctypes
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import arch
+from ._lib import lib, check, ptr, stream, require_device, COSY_F32, COSY_BF16, CosyHipError
+
+_DTYPES = {'fp32': COSY_F32, 'f32': COSY_F32, 'float32': COSY_F32, 'bf16': COSY_BF16, 'bfloat16': COSY_BF16}
+
+
+class _Block(nn.Module):
+    def __init__(self, k, s, expand, cin, cout):
+        super().__init__()
+        cmid, cse = cin * expand, arch.se_channels(cin)
+        bn = lambda c: nn.BatchNorm2d(c, momentum=0.01, eps=arch.BN_EPS)
+        if expand != 1:
+            self._expand_conv = nn.Conv2d(cin, cmid, 1, bias=False)
+            self._bn0 = bn(cmid)
+        self._depthwise_conv = nn.Conv2d(cmid, cmid, k, stride=s, groups=cmid, bias=False)
+        self._bn1 = bn(cmid)
+        self._se_reduce = nn.Conv2d(cmid, cse, 1)
+        self._se_expand = nn.Conv2d(cse, cmid, 1)
+        self._project_conv = nn.Conv2d(cmid, cout, 1, bias=False)
+        self._bn2 = bn(cout)
+
+
+class EfficientNet(nn.Module):
+    def __init__(self, in_channels=6):
+        super().__init__()
+        if in_channels != arch.IN_C:
+            raise ValueError('the MI355X path implements the 6-channel {observed, rendered} backbone only')
+        self._conv_stem = nn.Conv2d(in_channels, arch.STEM_C, 3, stride=2, bias=False)
+        self._bn0 = nn.BatchNorm2d(arch.STEM_C, momentum=0.01, eps=arch.BN_EPS)
+        self._blocks = nn.ModuleList([_Block(*b) for b in arch.B3_BLOCKS])
+        self._conv_head = nn.Conv2d(arch.B3_BLOCKS[-1][4], arch.HEAD_C, 1, bias=False)
+        self._bn1 = nn.BatchNorm2d(arch.HEAD_C, momentum=0.01, eps=arch.BN_EPS)
+        self.n_features = arch.HEAD_C
+        self.n_inputs = in_channels
+
+    @classmethod
+    def from_name(cls, model_name, override_params=None, in_channels=6):
+        if model_name != 'efficientnet-b3':
+            raise ValueError('only efficientnet-b3 is implemented (the backbone of every released CosyPose model)')
+        return cls(in_channels=in_channels)
+
+    def extract_features(self, inputs):
+        return self.forward(inputs)
+
+    def forward(self, inputs):
+        """(B,6,H,W) fp32 NCHW -> (B,1536,h,w) fp32, via a standalone engine (no pose head)."""
+        eng = getattr(self, '_engine', None)
+        if eng is None:
+            eng = self.__dict__['_engine'] = NetEngine(self, None)
+        return eng.features(inputs)
+
+
+def flat_params(backbone, pose_fc):
+    """Flat fp32 host blob in the order include/cosyhip.h documents."""
+    parts = []
+
+    def bn(m):
+        parts.extend([m.weight, m.bias, m.running_mean, m.running_var])
+    parts.append(backbone._conv_stem.weight); bn(backbone._bn0)
+    for blk, (k, s, e, cin, cout) in zip(backbone._blocks, arch.B3_BLOCKS):
+        if e != 1:
+            parts.append(blk._expand_conv.weight); bn(blk._bn0)
+        parts.append(blk._depthwise_conv.weight); bn(blk._bn1)
+        parts.extend([blk._se_reduce.weight, blk._se_reduce.bias, blk._se_expand.weight, blk._se_expand.bias])
+        parts.append(blk._project_conv.weight); bn(blk._bn2)
+    parts.append(backbone._conv_head.weight); bn(backbone._bn1)
+    if pose_fc is not None:
+        parts.extend([pose_fc.weight, pose_fc.bias])
+    else:
+        parts.extend([torch.zeros(arch.N_POSE, arch.HEAD_C), torch.zeros(arch.N_POSE)])
+    blob = torch.cat([p.detach().reshape(-1).to('cpu', torch.float32) for p in parts]).contiguous()
+    assert blob.numel() == arch.param_count()
+    return blob, parts
+
+
+class NetEngine:
+    """Owns the cosy_net_t for one (backbone, pose_fc) pair; rebuilt lazily when the
+    weights, the crop size, the compute dtype or the required batch capacity change."""
+
+    def __init__(self, backbone, pose_fc):
+        self.backbone, self.pose_fc = backbone, pose_fc
+        self.handle = None
+        self.key = None
+        self.capacity = 0
+
+    def _weights_version(self):
+        ts = list(self.backbone.parameters()) + list(self.backbone.buffers())
+        if self.pose_fc is not None:
+            ts += list(self.pose_fc.parameters())
+        return tuple((t.data_ptr(), t._version) for t in ts)
+
+    def ensure(self, B, H, W, dtype, device):
+        if self.backbone.training:
+            raise CosyHipError('cosypose_amd implements eval-mode inference; call .eval() (training step is a later round)')
+        key = (H, W, _DTYPES[dtype], device.index, self._weights_version())
+        if self.handle is not None and key == self.key and B <= self.capacity:
+            return self.handle
+        self.release()
+        cap = max(B, self.capacity if key[:4] == (self.key or (None,) * 4)[:4] else 0, 16)
+        cap = 1 << (cap - 1).bit_length()
+        blob, _ = flat_params(self.backbone, self.pose_fc)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            check(lib().cosy_effnet_b3_create(blob.data_ptr(), blob.numel(), _DTYPES[dtype], H, W, cap, ctypes.byref(h)))
+        self.handle, self.key, self.capacity = h, key, cap
+        return h
+
+    def release(self):
+        if self.handle is not None:
+            torch.cuda.synchronize()
+            lib().cosy_effnet_b3_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def features(self, x, dtype='fp32'):
+        require_device(x)
+        x = x.detach().float().contiguous()
+        B, C, H, W = x.shape
+        h = self.ensure(B, H, W, dtype, x.device)
+        pose = torch.empty(B, arch.N_POSE, device=x.device)
+        check(lib().cosy_effnet_b3_set_input_nchw(h, ptr(x), B, stream()))
+        check(lib().cosy_effnet_b3_forward(h, B, None, ptr(pose), None, stream()))
+        fh, fw = arch.feature_hw(H, W)
+        out = torch.empty(B, arch.HEAD_C, fh, fw, device=x.device)
+        check(lib().cosy_effnet_b3_features_nchw(h, B, ptr(out), stream()))
+        return out

@@ -1,0 +1,143 @@
+"""PosePredictor: the render-and-compare loop, same surface as the reference's
+cosypose/models/pose.py:18-132, executed by HIP kernels (libcosyhip.so).
+
+Differences that are deliberate and invisible to callers of the reference API:
+  * the observed crop (roi_align) and the renderer's output are written straight into one
+    channels-last 6-channel buffer (no torch.cat, no (B,3,H,W) crop tensor);
+  * `forward(..., im_ids=...)` lets the caller pass the N frames once plus a per-object frame
+    index instead of replicating frames per object (pose_predictor.py:41 `images[im_ids]`);
+  * `compute_dtype` ('fp32' parity mode, 'bf16' throughput mode) selects the backbone's
+    storage type; geometry and the pose update are always fp32.
+There is no CPU / eager fallback: tensors must live on a ROCm device.
+"""
+import torch
+from torch import nn
+
+from . import lib3d, arch
+from ._lib import lib, check, ptr, stream, require_device, CosyHipError
+from .efficientnet import NetEngine
+
+
+class PosePredictor(nn.Module):
+    def __init__(self, backbone, renderer, mesh_db, render_size=(240, 320), pose_dim=9):
+        super().__init__()
+        self.backbone = backbone
+        self.renderer = renderer
+        self.mesh_db = mesh_db
+        self.render_size = render_size
+        self.pose_dim = pose_dim
+
+        n_features = backbone.n_features
+        self.heads = dict()
+        self.pose_fc = nn.Linear(n_features, pose_dim, bias=True)
+        self.heads['pose'] = self.pose_fc
+
+        self.debug = False
+        self.tmp_debug = dict()
+        self.compute_dtype = 'fp32'
+        self.__dict__['_engine'] = NetEngine(backbone, self.pose_fc)
+
+    def enable_debug(self):
+        self.debug = True
+
+    def disable_debug(self):
+        self.debug = False
+
+    # ---- pieces of the loop, reference signatures -------------------------------------------
+    def _geometry(self, K, TCO, labels, im_size, im_ids=None):
+        if self.pose_dim != 9:
+            raise ValueError(f'pose_dim={self.pose_dim} not supported')
+        table = self.mesh_db.point_table(2000)
+        if table.device != TCO.device:
+            raise CosyHipError(f'mesh_db lives on {table.device} but poses on {TCO.device}; call mesh_db.cuda()')
+        obj_ids = labels if torch.is_tensor(labels) else self.mesh_db.object_ids(labels, TCO.device)
+        return lib3d.crop_geometry(table, obj_ids, K, TCO, im_size, self.render_size, im_ids=im_ids, lamb=1.4)
+
+    def crop_inputs(self, images, K, TCO, labels):
+        bsz, nchannels, h, w = images.shape
+        assert K.shape == (bsz, 3, 3)
+        assert TCO.shape == (bsz, 4, 4)
+        assert len(labels) == bsz
+        boxes_rend, boxes_crop, K_crop = self._geometry(K, TCO, labels, (h, w))
+        images_cropped = lib3d.roi_align(images, boxes_crop, self.render_size, sampling_ratio=4)
+        if self.debug:
+            self.tmp_debug.update(boxes_rend=boxes_rend, boxes_crop=boxes_crop)
+        return images_cropped, K_crop.detach(), boxes_rend, boxes_crop
+
+    def update_pose(self, TCO, K_crop, pose_outputs):
+        if self.pose_dim != 9:
+            raise ValueError(f'pose_dim={self.pose_dim} not supported')
+        return lib3d.update_pose(TCO, K_crop, pose_outputs)
+
+    def _net(self, B, device):
+        H, W = self.render_size
+        return self._engine.ensure(B, H, W, self.compute_dtype, device)
+
+    def net_forward(self, x, return_features=False):
+        """x = cat(images_crop, renders) (B,6,H,W) -> {'pose': (B,9)}."""
+        require_device(x)
+        x = x.detach().float().contiguous()
+        B = x.shape[0]
+        assert tuple(x.shape[1:]) == (6,) + tuple(self.render_size), x.shape
+        h = self._net(B, x.device)
+        pose = torch.empty(B, self.pose_dim, device=x.device)
+        feat = torch.empty(B, arch.HEAD_C, device=x.device) if return_features else None
+        check(lib().cosy_effnet_b3_set_input_nchw(h, ptr(x), B, stream()))
+        check(lib().cosy_effnet_b3_forward(h, B, ptr(feat), ptr(pose), None, stream()))
+        outputs = dict(pose=pose)
+        if return_features:
+            outputs['features'] = feat
+        return outputs
+
+    # ---- the loop ----------------------------------------------------------------------------
+    def forward(self, images, K, labels, TCO, n_iterations=1, im_ids=None):
+        require_device(images, K, TCO)
+        if self.pose_dim != 9:
+            raise ValueError(f'pose_dim={self.pose_dim} not supported')
+        bsz = TCO.shape[0]
+        n_im, nchannels, h, w = images.shape
+        assert TCO.shape == (bsz, 4, 4)
+        assert len(labels) == bsz
+        if im_ids is None:
+            assert n_im == bsz and K.shape == (bsz, 3, 3)
+        else:
+            assert K.shape == (n_im, 3, 3) and len(im_ids) == bsz
+            im_ids = torch.as_tensor(im_ids).to(device=TCO.device, dtype=torch.int32).contiguous()
+        images = images.detach().float().contiguous()
+        K = K.detach().float().contiguous()
+        dev = TCO.device
+        obj_ids = self.mesh_db.object_ids(labels, dev)
+        net = self._net(bsz, dev)
+        H, W = self.render_size
+
+        outputs = dict()
+        TCO_input = TCO
+        for n in range(n_iterations):
+            TCO_input = TCO_input.detach().float().contiguous()
+            boxes_rend, boxes_crop, K_crop = self._geometry(K, TCO_input, obj_ids, (h, w), im_ids=im_ids)
+            renders = self.renderer.render(obj_infos=[dict(name=l) for l in labels], TCO=TCO_input,
+                                           K=K_crop, resolution=self.render_size)
+            require_device(renders)
+            renders = renders.detach().float().contiguous()
+            assert renders.shape == (bsz, 3, H, W), renders.shape
+            check(lib().cosy_crop_pack(net, ptr(images), ptr(im_ids), ptr(boxes_crop), ptr(renders), bsz, n_im, h, w, stream()))
+            pose = torch.empty(bsz, self.pose_dim, device=dev)
+            check(lib().cosy_effnet_b3_forward(net, bsz, None, ptr(pose), None, stream()))
+            model_outputs = dict(pose=pose)
+            TCO_output = lib3d.update_pose(TCO_input, K_crop, pose)
+
+            outputs[f'iteration={n+1}'] = {
+                'TCO_input': TCO_input,
+                'TCO_output': TCO_output,
+                'K_crop': K_crop,
+                'model_outputs': model_outputs,
+                'boxes_rend': boxes_rend,
+                'boxes_crop': boxes_crop,
+            }
+            TCO_input = TCO_output
+
+            if self.debug:
+                self.tmp_debug.update(outputs[f'iteration={n+1}'])
+                self.tmp_debug.update(images=images, renders=renders,
+                                      images_crop=lib3d.roi_align(images, boxes_crop, self.render_size, 4, im_ids=im_ids))
+        return outputs

@@ -1,0 +1,142 @@
+"""I/O containers of the drop-in API: same surface as the reference's
+cosypose/utils/tensor_collection.py:7-174 (TensorCollection, PandasTensorCollection,
+concatenate), so detections go in and predictions come out in the shape its callers
+(cosypose/evaluation/pred_runner/bop_predictions.py:108-112) expect.
+
+The one behavioural difference: `gather_distributed` collects ranks with a
+torch.distributed all-gather (RCCL on MI355X) instead of files on a shared disk
+(reference :142-163); see cosypose_amd/distributed.py.
+"""
+import pandas as pd
+import torch
+
+
+class TensorCollection:
+    """Named tensors sharing their first dimension; attribute access and fancy indexing."""
+
+    def __init__(self, **kwargs):
+        self.__dict__['_tensors'] = dict()
+        for name, tensor in kwargs.items():
+            self.register_tensor(name, tensor)
+
+    def register_tensor(self, name, tensor):
+        self._tensors[name] = tensor
+
+    def delete_tensor(self, name):
+        del self._tensors[name]
+
+    @property
+    def tensors(self):
+        return self._tensors
+
+    @property
+    def device(self):
+        return next(iter(self._tensors.values())).device
+
+    def __getattr__(self, name):
+        tensors = self.__dict__.get('_tensors', {})
+        if name in tensors:
+            return tensors[name]
+        if name in self.__dict__:
+            return self.__dict__[name]
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if '_tensors' not in self.__dict__:
+            raise ValueError('Please call __init__')
+        if name in self._tensors:
+            self._tensors[name] = value
+        else:
+            self.__dict__[name] = value
+
+    def __getitem__(self, ids):
+        return TensorCollection(**{k: v[ids] for k, v in self._tensors.items()})
+
+    def __repr__(self):
+        lines = [f'    {k}: {t.shape} {t.dtype} {t.device},' for k, t in self._tensors.items()]
+        return self.__class__.__name__ + '(\n' + '\n'.join(lines) + '\n)'
+
+    def __getstate__(self):
+        return {'tensors': self.tensors}
+
+    def __setstate__(self, state):
+        self.__init__(**state['tensors'])
+
+    def to(self, torch_attr):
+        for k, v in self._tensors.items():
+            self._tensors[k] = v.to(torch_attr)
+        return self
+
+    def cuda(self):
+        return self.to('cuda')
+
+    def cpu(self):
+        return self.to('cpu')
+
+    def float(self):
+        return self.to(torch.float)
+
+    def double(self):
+        return self.to(torch.double)
+
+    def half(self):
+        return self.to(torch.half)
+
+    def clone(self):
+        return TensorCollection(**{k: v.clone() for k, v in self._tensors.items()})
+
+
+class PandasTensorCollection(TensorCollection):
+    """TensorCollection + a pandas DataFrame `infos` with one row per element."""
+
+    def __init__(self, infos, **tensors):
+        super().__init__(**tensors)
+        self.infos = infos.reset_index(drop=True)
+        self.meta = dict()
+
+    def merge_df(self, df, *args, **kwargs):
+        infos = self.infos.merge(df, how='left', *args, **kwargs)
+        assert len(infos) == len(self.infos)
+        assert (infos.index == self.infos.index).all()
+        return PandasTensorCollection(infos=infos, **self.tensors)
+
+    def clone(self):
+        return PandasTensorCollection(self.infos.copy(), **super().clone().tensors)
+
+    def __repr__(self):
+        s = super().__repr__()[:-1]
+        return s + '-' * 40 + '\n    infos:\n' + repr(self.infos) + '\n)'
+
+    def __getitem__(self, ids):
+        infos = self.infos.iloc[ids].reset_index(drop=True)
+        return PandasTensorCollection(infos, **super().__getitem__(ids).tensors)
+
+    def __len__(self):
+        return len(self.infos)
+
+    def gather_distributed(self, tmp_dir=None):
+        """All ranks' collections concatenated in rank order (on every rank).  `tmp_dir` is
+        accepted for signature compatibility and unused: no files, one collective."""
+        from .distributed import gather_collection
+        return gather_collection(self)
+
+    def __getstate__(self):
+        state = super().__getstate__()
+        state['infos'] = self.infos
+        state['meta'] = self.meta
+        return state
+
+    def __setstate__(self, state):
+        self.__init__(state['infos'], **state['tensors'])
+        self.meta = state['meta']
+
+
+def concatenate(datas):
+    """Row-wise concatenation; empty collections are dropped (reference :7-20)."""
+    datas = [d for d in datas if len(d) > 0]
+    if len(datas) == 0:
+        return PandasTensorCollection(infos=pd.DataFrame())
+    assert all(d.__class__ is datas[0].__class__ for d in datas)
+    infos = pd.concat([d.infos for d in datas], axis=0, sort=False).reset_index(drop=True)
+    tensors = {k: torch.cat([getattr(d, k) for d in datas], dim=0) for k in datas[0].tensors.keys()}
+    return PandasTensorCollection(infos=infos, **tensors)

@@ -1,0 +1,123 @@
+/*
+ * cosyhip.h -- C ABI of libcosyhip.so: the MI355X (gfx950) implementation of CosyPose's
+ * render-and-compare pose-refinement hot path.
+ *
+ * Each entry point replaces one reference interface (file:line relative to the reference
+ * checkout of ylabbe/cosypose); the Python shim in cosypose_amd/ binds them with ctypes
+ * (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / C++ types cross this boundary;
+ *   - every pointer is a DEVICE pointer unless the parameter name starts with `host_`;
+ *   - all geometry tensors are fp32 row-major: poses (B,4,4), intrinsics (B,3,3),
+ *     boxes (B,4) = x1,y1,x2,y2 in pixels; frames are fp32 NCHW (N,3,h,w) in [0,1];
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), performs no
+ *     allocation and no synchronisation; the caller owns and sizes every output;
+ *   - return value: COSY_OK (0) or a negative COSY_E* code; cosy_last_error() gives the
+ *     message of the last failure on the calling thread.  Nothing throws across the ABI;
+ *   - the library owns only cosy_net_t (packed weights + activation workspace);
+ *     distinct nets may be used concurrently from distinct threads/streams.
+ */
+#ifndef COSYHIP_H
+#define COSYHIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COSY_VERSION 100 /* 0.1.0 */
+
+enum { COSY_OK = 0, COSY_EINVAL = -1, COSY_ENOMEM = -2, COSY_EHIP = -3, COSY_ESIZE = -4 };
+
+/* storage/compute type of the backbone activations and weights (accumulation is always fp32) */
+enum { COSY_F32 = 0, COSY_BF16 = 1 };
+
+typedef struct cosy_net cosy_net_t;
+typedef void* cosy_stream_t; /* hipStream_t */
+
+int cosy_version(void);
+const char* cosy_last_error(void);
+
+/* ---- backbone: EfficientNet-B3(in_channels=6) + global-avg-pool + Linear(1536,9) ----------
+ * Replaces EfficientNet.extract_features (cosypose/models/efficientnet.py:174-190), MBConvBlock.forward
+ * (:71-98), Conv2dStaticSamePadding (cosypose/models/efficientnet_utils.py:123-146) and
+ * PosePredictor.net_forward (cosypose/models/pose.py:81-87), eval mode.
+ *
+ * host_params: flat fp32 blob of the reference state_dict in this order (BN tensors as
+ * weight,bias,running_mean,running_var; num_batches_tracked omitted):
+ *   backbone._conv_stem.weight[40,6,3,3], backbone._bn0;
+ *   for i in 0..25: [_expand_conv.weight[Cmid,Cin,1,1], _bn0]  (absent when expand==1),
+ *                   _depthwise_conv.weight[Cmid,1,k,k], _bn1,
+ *                   _se_reduce.weight[Cse,Cmid,1,1], _se_reduce.bias, _se_expand.weight[Cmid,Cse,1,1], _se_expand.bias,
+ *                   _project_conv.weight[Cout,Cmid,1,1], _bn2;
+ *   backbone._conv_head.weight[1536,384,1,1], backbone._bn1; pose_fc.weight[9,1536], pose_fc.bias[9].
+ * cosy_effnet_b3_param_count() floats in total (10,798,441). */
+long cosy_effnet_b3_param_count(void);
+int cosy_effnet_b3_out_hw(int H, int W, int* out_h, int* out_w);
+int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, int H, int W, int max_batch,
+                          cosy_net_t** out);
+int cosy_effnet_b3_destroy(cosy_net_t* net);
+size_t cosy_effnet_b3_workspace_bytes(const cosy_net_t* net);
+
+/* Fill the net's 6-channel input from a reference-layout tensor x (B,6,H,W) fp32 NCHW
+ * (what torch.cat((images_crop, renders), 1) produces, pose.py:104). */
+int cosy_effnet_b3_set_input_nchw(cosy_net_t* net, const float* x, int B, cosy_stream_t stream);
+
+/* Fused replacement of deepim_crops_robust's roi_align (cosypose/lib3d/cropping.py:73-74,
+ * torchvision 0.4.2 semantics, sampling_ratio=4) + torch.cat with the renders (pose.py:104):
+ * writes observed crop -> channels 0..2 and renders (B,3,H,W fp32 NCHW) -> channels 3..5 of
+ * the net input.  images (N,3,h,w); im_id (B) int32 index into images or NULL for identity
+ * (the reference gathers images[im_ids] first, cosypose/integrated/pose_predictor.py:41). */
+int cosy_crop_pack(cosy_net_t* net, const float* images, const int* im_id, const float* boxes_crop,
+                   const float* renders, int B, int N, int h, int w, cosy_stream_t stream);
+
+/* Run the backbone on the current input: feat (B,1536) fp32 or NULL, pose9 (B,9) fp32,
+ * taps (B,9,16) fp32 or NULL = per-stage probes [mean, mean|x|, 14 strided samples] of the
+ * stem, the 7 stage outputs and the head activation (test hook; same probe as the oracle). */
+int cosy_effnet_b3_forward(cosy_net_t* net, int B, float* feat, float* pose9, float* taps, cosy_stream_t stream);
+
+/* After cosy_effnet_b3_forward: copy the head activation out as the reference's backbone(x) would return it,
+ * (B,1536,h,w) fp32 NCHW (what EfficientNet.forward yields, efficientnet.py:192-204). */
+int cosy_effnet_b3_features_nchw(cosy_net_t* net, int B, float* out, cosy_stream_t stream);
+
+/* ---- geometry ---------------------------------------------------------------------------
+ * PosePredictor.crop_inputs without the pixel work (cosypose/models/pose.py:45-67):
+ * project_points_robust + boxes_from_uv (cosypose/lib3d/camera_geometry.py:18-42), deepim_boxes
+ * (cosypose/lib3d/cropping.py:7-47, lamb=1.4, not clamped), get_K_crop_resize (camera_geometry.py:45-87).
+ * pts_table (n_obj,P,3) = mesh_db points after sample_points(P, deterministic=True)
+ * (cosypose/lib3d/mesh_ops.py:31-41); obj_id (B) int32 rows of pts_table; K is (N,3,3) indexed
+ * by im_id (B) or (B,3,3) when im_id is NULL. */
+int cosy_crop_geometry(const float* pts_table, const int* obj_id, const float* K, const int* im_id, const float* TCO,
+                       int B, int P, float z_min, int im_h, int im_w, int out_h, int out_w, float lamb,
+                       float* boxes_rend, float* boxes_crop, float* K_crop, cosy_stream_t stream);
+
+/* torchvision.ops.roi_align(images, [im_id|boxes], (out_h,out_w), sampling_ratio) as the reference
+ * calls it (cropping.py:74): out (B,C,out_h,out_w) fp32 NCHW. */
+int cosy_roi_align(const float* images, const int* im_id, const float* boxes, int B, int N, int C, int h, int w,
+                   int out_h, int out_w, int sampling_ratio, float* out, cosy_stream_t stream);
+
+/* PosePredictor.update_pose for pose_dim=9 (pose.py:69-79): compute_rotation_matrix_from_ortho6d
+ * (cosypose/lib3d/rotations.py:6-21) + apply_imagespace_predictions (cosypose/lib3d/cosypose_ops.py:10-31). */
+int cosy_pose_update(const float* TCO_in, const float* K_crop, const float* pose9, int B, float* TCO_out,
+                     cosy_stream_t stream);
+
+/* TCO_init_from_boxes(z_range=(z,z)) (cosypose_ops.py:121-135) and
+ * TCO_init_from_boxes_zup_autodepth (cosypose_ops.py:138-173), as used by
+ * CoarseRefinePosePredictor.make_TCO_init (pose_predictor.py:65-74). */
+int cosy_tco_init_from_boxes(const float* boxes, const float* K, const int* im_id, int B, float z, float* TCO,
+                             cosy_stream_t stream);
+int cosy_tco_init_zup_autodepth(const float* boxes, const float* pts_table, const int* obj_id, const float* K,
+                                const int* im_id, int B, int P, float* TCO, cosy_stream_t stream);
+
+/* ---- index / assignment ops adjacent to the loop (bit-exact) --------------------------------
+ * scatter_argmin (cosypose/csrc/cosypose_cext.cpp:218-245): per segment id in [0,n_seg) the index of the
+ * smallest distance, first index wins on ties; out[s] = -1 for an empty segment. dists (M) fp32,
+ * ids (M) int32 on the device. */
+int cosy_scatter_argmin(const float* dists, const int* ids, int M, int n_seg, int* out, cosy_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COSYHIP_H */
