@@ -23,6 +23,8 @@ _SIGNATURES = {
     'cosy_effnet_b3_workspace_bytes': ([_P], _SZ),
     'cosy_effnet_b3_set_input_nchw': ([_P, _P, _I, _P], _I),
     'cosy_effnet_b3_features_nchw': ([_P, _I, _P, _P], _I),
+    'cosy_effnet_b3_set_profiling': ([_P, _I], _I),
+    'cosy_effnet_b3_profile_read': ([_P, _P, _I, _c.POINTER(_I)], _I),
     'cosy_crop_pack': ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     'cosy_effnet_b3_forward': ([_P, _I, _P, _P, _P, _P], _I),
     'cosy_crop_geometry': ([_P, _P, _P, _P, _P, _I, _I, _F, _I, _I, _I, _I, _F, _P, _P, _P, _P], _I),
@@ -33,6 +35,20 @@ _SIGNATURES = {
     'cosy_scatter_argmin': ([_P, _P, _I, _I, _P, _P], _I),
 }
 EXPORTS = tuple(_SIGNATURES)
+
+
+class ProfRec(ctypes.Structure):
+    _fields_ = [('name', _c.c_char * 48), ('layer', _I), ('n', _I), ('ms_avg', _F), ('ms_min', _F),
+                ('bytes', _c.c_double), ('flops', _c.c_double)]
+
+
+def profile_read(handle):
+    """-> list of dicts, one per launch slot of the backbone schedule (see cosy_prof_rec_t)."""
+    recs = (ProfRec * 200)()
+    n = _I(0)
+    check(lib().cosy_effnet_b3_profile_read(handle, recs, 200, ctypes.byref(n)))
+    return [dict(name=r.name.decode(), layer=r.layer, n=r.n, ms_avg=r.ms_avg, ms_min=r.ms_min, bytes=r.bytes, flops=r.flops)
+            for r in recs[:n.value]]
 
 
 class CosyHipError(RuntimeError):

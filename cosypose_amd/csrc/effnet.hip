@@ -72,7 +72,12 @@ struct cosy_net {
     float *partial, *gate;
     void* wbase; void* abase;
     size_t wbytes, abytes;
+    // profiling ring: PROF_SEGS forwards x (PROF_SLOTS+1) events
+    int prof_on, prof_nslots, prof_seg;
+    hipEvent_t* prof_ev;
+    cosy_prof_rec_t* prof_rec;
 };
+enum { PROF_SEGS = 64, PROF_SLOTS = 160 };
 
 namespace cosy {
 
@@ -200,14 +205,37 @@ static void layout_workspace(cosy_net* n, Bump& b) {
     n->gate = (float*)b.take(B * gate * sizeof(float));
 }
 
+static const char* dt_name(int dtype) { return dtype == COSY_F32 ? "float" : "__bf16"; }
+
 static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps, hipStream_t s) {
     int rc;
     int tap_i = 0;
+    const double esz_d = n->esz;
+    const bool prof = n->prof_on && n->prof_seg < PROF_SEGS && !taps;
+    hipEvent_t* ev = prof ? n->prof_ev + (size_t)n->prof_seg * (PROF_SLOTS + 1) : nullptr;
+    int slot = 0;
+    if (prof) COSY_CHECK_HIP(hipEventRecord(ev[0], s));
+    auto mark = [&](const char* kname, int layer, double bytes, double flops) -> int {
+        if (!prof || slot >= PROF_SLOTS) return COSY_OK;
+        if (n->prof_seg == 0) {
+            cosy_prof_rec_t& r = n->prof_rec[slot];
+            snprintf(r.name, sizeof(r.name), "%s", kname);
+            r.layer = layer; r.bytes = bytes; r.flops = flops;
+        }
+        ++slot;
+        COSY_CHECK_HIP(hipEventRecord(ev[slot], s));
+        return COSY_OK;
+    };
+    auto pw_name = [&](const PwLayer& L, char* buf, size_t nbuf) { snprintf(buf, nbuf, "pw_gemm_kernel<%s, %d, %d>", dt_name(n->dtype), L.cfg.NI, L.cfg.WN); };
+    auto pw_bytes = [&](const PwArgs& a) { return ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N * (a.res ? 2 : 1)) * esz_d + (a.gate ? (double)B * a.K * 4 : 0); };
+    char kn[48];
     auto tap = [&](const void* act, int HW, int C) -> int {
         if (!taps) return COSY_OK;
         return launch_taps(act, B, HW, C, n->dtype, taps, tap_i++, s);
     };
     if ((rc = launch_stem(n->X, n->stem_w, n->stem_scale, n->stem_bias, n->act[0], B, n->H, n->W, n->Hs, n->Ws, n->dtype, s))) return rc;
+    snprintf(kn, sizeof(kn), "stem_kernel<%s>", dt_name(n->dtype));
+    if ((rc = mark(kn, -1, ((double)B * n->H * n->W * 8 + (double)B * n->Hs * n->Ws * STEM_C) * esz_d, 2.0 * B * n->Hs * n->Ws * STEM_C * IN_C * 9))) return rc;
     if ((rc = tap(n->act[0], n->Hs * n->Ws, STEM_C))) return rc;
     int cur = 0, si = 0;
     for (int i = 0; i < 26; ++i) {
@@ -218,21 +246,30 @@ static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps
             a.A = n->act[cur]; a.Wp = b.exp.Wp; a.out = n->E; a.scale = b.exp.scale; a.bias = b.exp.bias;
             a.M = B * b.H * b.W; a.K = b.d.cin; a.N = b.cmid; a.HW = b.H * b.W; a.silu = 1;
             if ((rc = launch_pw_gemm(a, b.exp.cfg, n->dtype, s))) return rc;
+            pw_name(b.exp, kn, sizeof(kn));
+            if ((rc = mark(kn, i, pw_bytes(a), 2.0 * a.M * a.K * a.N))) return rc;
             src = n->E;
         }
         DwArgs d{};
         d.in = src; d.w = b.dw_w; d.scale = b.dw_scale; d.bias = b.dw_bias; d.out = n->D; d.partial = n->partial;
         d.B = B; d.H = b.H; d.W = b.W; d.C = b.cmid; d.Ho = b.Ho; d.Wo = b.Wo; d.k = b.d.k; d.s = b.d.s; d.pad_lo = b.pad_lo;
         if ((rc = launch_dwconv(d, n->dtype, s))) return rc;
+        snprintf(kn, sizeof(kn), "dwconv_kernel<%s, %d, %d>", dt_name(n->dtype), b.d.k, b.d.s);
+        if ((rc = mark(kn, i, ((double)B * b.H * b.W * b.cmid + (double)B * b.Ho * b.Wo * b.cmid) * esz_d + (double)B * b.n_tiles * b.cmid * 4,
+                       2.0 * B * b.Ho * b.Wo * b.cmid * b.d.k * b.d.k))) return rc;
         SeArgs e{};
         e.partial = n->partial; e.n_tiles = b.n_tiles; e.w_red = b.se_wr; e.b_red = b.se_br; e.w_exp = b.se_we; e.b_exp = b.se_be;
         e.gate = n->gate; e.B = B; e.C = b.cmid; e.Cse = b.cse; e.HW = b.Ho * b.Wo;
         if ((rc = launch_se(e, s))) return rc;
+        if ((rc = mark("se_kernel", i, (double)B * b.n_tiles * b.cmid * 4 + (double)B * b.cmid * 4 + 2.0 * b.cse * b.cmid * 4,
+                       4.0 * B * b.cse * b.cmid))) return rc;
         PwArgs a{};
         a.A = n->D; a.Wp = b.proj.Wp; a.out = n->act[cur ^ 1]; a.scale = b.proj.scale; a.bias = b.proj.bias;
         a.res = b.skip ? n->act[cur] : nullptr; a.gate = n->gate;
         a.M = B * b.Ho * b.Wo; a.K = b.cmid; a.N = b.d.cout; a.HW = b.Ho * b.Wo; a.silu = 0;
         if ((rc = launch_pw_gemm(a, b.proj.cfg, n->dtype, s))) return rc;
+        pw_name(b.proj, kn, sizeof(kn));
+        if ((rc = mark(kn, i, pw_bytes(a), 2.0 * a.M * a.K * a.N))) return rc;
         cur ^= 1;
         if (si < 7 && i == STAGE_END[si]) { if ((rc = tap(n->act[cur], b.Ho * b.Wo, b.d.cout))) return rc; ++si; }
     }
@@ -240,8 +277,14 @@ static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps
     a.A = n->act[cur]; a.Wp = n->head.Wp; a.out = n->Hd; a.scale = n->head.scale; a.bias = n->head.bias;
     a.M = B * n->Hf * n->Wf; a.K = HEAD_IN; a.N = HEAD_C; a.HW = n->Hf * n->Wf; a.silu = 1;
     if ((rc = launch_pw_gemm(a, n->head.cfg, n->dtype, s))) return rc;
+    pw_name(n->head, kn, sizeof(kn));
+    if ((rc = mark(kn, 26, pw_bytes(a), 2.0 * a.M * a.K * a.N))) return rc;
     if ((rc = tap(n->Hd, n->Hf * n->Wf, HEAD_C))) return rc;
-    return launch_pool_fc(n->Hd, n->fc_w, n->fc_b, feat, nullptr, pose, B, n->Hf * n->Wf, n->dtype, s);
+    if ((rc = launch_pool_fc(n->Hd, n->fc_w, n->fc_b, feat, nullptr, pose, B, n->Hf * n->Wf, n->dtype, s))) return rc;
+    snprintf(kn, sizeof(kn), "pool_fc_kernel<%s>", dt_name(n->dtype));
+    if ((rc = mark(kn, 26, (double)B * n->Hf * n->Wf * HEAD_C * esz_d, 2.0 * B * HEAD_C * (n->Hf * n->Wf + N_POSE)))) return rc;
+    if (prof) { n->prof_nslots = slot; ++n->prof_seg; }
+    return COSY_OK;
 }
 
 }  // namespace cosy
@@ -302,8 +345,50 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
     return COSY_OK;
 }
 
+int cosy_effnet_b3_set_profiling(cosy_net_t* n, int enable) {
+    COSY_REQUIRE(n, "set_profiling: null net");
+    if (enable && !n->prof_ev) {
+        const size_t ne = (size_t)PROF_SEGS * (PROF_SLOTS + 1);
+        n->prof_ev = (hipEvent_t*)calloc(ne, sizeof(hipEvent_t));
+        n->prof_rec = (cosy_prof_rec_t*)calloc(PROF_SLOTS, sizeof(cosy_prof_rec_t));
+        if (!n->prof_ev || !n->prof_rec) { set_error("set_profiling: host allocation failed"); return COSY_ENOMEM; }
+        for (size_t i = 0; i < ne; ++i) COSY_CHECK_HIP(hipEventCreate(&n->prof_ev[i]));
+    }
+    n->prof_on = enable ? 1 : 0;
+    n->prof_seg = 0;
+    return COSY_OK;
+}
+
+int cosy_effnet_b3_profile_read(cosy_net_t* n, cosy_prof_rec_t* recs, int cap, int* n_out) {
+    COSY_REQUIRE(n && recs && n_out, "profile_read: null argument");
+    COSY_REQUIRE(n->prof_ev, "profile_read: profiling was never enabled");
+    const int ns = n->prof_nslots, segs = n->prof_seg;
+    *n_out = 0;
+    if (segs == 0) return COSY_OK;
+    COSY_REQUIRE(cap >= ns, "profile_read: need room for %d records", ns);
+    for (int i = 0; i < ns; ++i) { recs[i] = n->prof_rec[i]; recs[i].n = 0; recs[i].ms_avg = 0.f; recs[i].ms_min = 1e30f; }
+    for (int g = 0; g < segs; ++g) {
+        hipEvent_t* ev = n->prof_ev + (size_t)g * (PROF_SLOTS + 1);
+        COSY_CHECK_HIP(hipEventSynchronize(ev[ns]));
+        for (int i = 0; i < ns; ++i) {
+            float ms = 0.f;
+            COSY_CHECK_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            recs[i].ms_avg += ms; recs[i].n += 1;
+            if (ms < recs[i].ms_min) recs[i].ms_min = ms;
+        }
+    }
+    for (int i = 0; i < ns; ++i) recs[i].ms_avg /= (float)recs[i].n;
+    *n_out = ns;
+    n->prof_seg = 0;
+    return COSY_OK;
+}
+
 int cosy_effnet_b3_destroy(cosy_net_t* n) {
     if (!n) return COSY_OK;
+    if (n->prof_ev) {
+        for (size_t i = 0; i < (size_t)PROF_SEGS * (PROF_SLOTS + 1); ++i) (void)hipEventDestroy(n->prof_ev[i]);
+        free(n->prof_ev); free(n->prof_rec);
+    }
     (void)hipFree(n->wbase); (void)hipFree(n->abase);
     free(n);
     return COSY_OK;

@@ -82,6 +82,24 @@ int cosy_effnet_b3_forward(cosy_net_t* net, int B, float* feat, float* pose9, fl
  * (B,1536,h,w) fp32 NCHW (what EfficientNet.forward yields, efficientnet.py:192-204). */
 int cosy_effnet_b3_features_nchw(cosy_net_t* net, int B, float* out, cosy_stream_t stream);
 
+/* ---- measurement hook ---------------------------------------------------------------------
+ * With profiling enabled every launch of cosy_effnet_b3_forward is bracketed by HIP events recorded on the
+ * launch stream (no synchronisation, one hipEventRecord per kernel; up to 64 forwards are retained).
+ * cosy_effnet_b3_profile_read blocks until the recorded events have completed and returns one record per
+ * launch slot of the schedule: kernel name (as rocprofv3 prints it, abbreviated), layer index, number of
+ * timed launches, mean/min duration, and the ALGORITHMIC bytes and flops of one launch (tensor sizes
+ * in+out+weights).  Reading resets the accumulation. */
+typedef struct {
+    char name[48];
+    int layer;      /* -1 stem, 0..25 MBConv block, 26 head */
+    int n;          /* launches timed */
+    float ms_avg, ms_min;
+    double bytes;   /* algorithmic HBM bytes of one launch */
+    double flops;   /* algorithmic flops of one launch */
+} cosy_prof_rec_t;
+int cosy_effnet_b3_set_profiling(cosy_net_t* net, int enable);
+int cosy_effnet_b3_profile_read(cosy_net_t* net, cosy_prof_rec_t* recs, int cap, int* n_out);
+
 /* ---- geometry ---------------------------------------------------------------------------
  * PosePredictor.crop_inputs without the pixel work (cosypose/models/pose.py:45-67):
  * project_points_robust + boxes_from_uv (cosypose/lib3d/camera_geometry.py:18-42), deepim_boxes
