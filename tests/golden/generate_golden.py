@@ -245,6 +245,9 @@ def main():
     mesh_points = syn.make_mesh_points(7, n_obj, 2500)
     model, mesh_db = build_ref_model(sd, mesh_points, labels)
     # the ids sample_points(2000, deterministic=True) draws (mesh_ops.py:31-41) for Nmax=2500
+    ref_sd = model.state_dict()
+    out['sd_keys'] = np.array(list(ref_sd.keys()))
+    out['sd_shapes'] = np.array([list(v.shape) + [-1] * (4 - v.dim()) for v in ref_sd.values()])
     out['sample_ids_2500'] = np.random.RandomState(0).choice(2500, size=2000, replace=False)
     g_functions(out)
     g_backbone(out, model, sd)

@@ -1,0 +1,124 @@
+"""CPU tests of the host side: the C ABI exports what include/cosyhip.h declares (no compute
+calls without a GPU), containers, mesh DB, sharding, state-dict layout, factories."""
+import argparse
+import ctypes
+import os
+import re
+import pathlib
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+REPO = pathlib.Path(__file__).resolve().parent.parent
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from cosypose_amd.build import build, LIB
+    build()  # hipcc cross-compiles for gfx950 without a GPU
+    header = (REPO / 'include' / 'cosyhip.h').read_text()
+    code = re.sub(r'/\*.*?\*/', '', header, flags=re.S)          # prototypes only, comments stripped
+    declared = set(re.findall(r'\b(cosy_[a-z0-9_]+)\s*\(', code))
+    assert len(declared) >= 18
+    lib = ctypes.CDLL(LIB)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f'{name} declared in cosyhip.h but not exported'
+    from cosypose_amd import _lib
+    assert set(_lib.EXPORTS) == declared, set(_lib.EXPORTS) ^ declared
+    l = _lib.lib()
+    assert l.cosy_version() == 100
+    assert l.cosy_effnet_b3_param_count() == 10798441
+    oh, ow = ctypes.c_int(), ctypes.c_int()
+    assert l.cosy_effnet_b3_out_hw(240, 320, ctypes.byref(oh), ctypes.byref(ow)) == 0
+    assert (oh.value, ow.value) == (7, 10)          # the static-padding quirk (15x20 -> 7x10)
+    # error path without a GPU: a wrong blob size is rejected before any device work
+    blob = np.zeros(10, np.float32)
+    h = ctypes.c_void_p()
+    rc = l.cosy_effnet_b3_create(blob.ctypes.data, 10, 1, 240, 320, 4, ctypes.byref(h))
+    assert rc == -4 and b'10798441' in l.cosy_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    for f in list((REPO / 'cosypose_amd').rglob('*.py')):
+        code = [l for l in f.read_text().splitlines() if 'import' in l or 'sys.path' in l or 'CDLL' in l]
+        assert not any('oracle' in l for l in code), f
+
+
+def test_cpu_tensors_are_rejected():
+    from cosypose_amd import lib3d
+    from cosypose_amd._lib import CosyHipError
+    with pytest.raises(CosyHipError):
+        lib3d.update_pose(torch.eye(4)[None], torch.eye(3)[None], torch.ones(1, 9))
+
+
+def test_state_dict_layout_and_factories(golden, golden_sd, oracle):
+    from cosypose_amd.pose_models_cfg import create_model_pose, create_model_coarse, create_model_refiner, check_update_config
+    from cosypose_amd.efficientnet import flat_params
+    cfg = check_update_config(argparse.Namespace(backbone_str='efficientnet-b3', n_pose_dims=9))
+    assert cfg.init_method == 'v0'
+    m = create_model_pose(cfg, renderer=None, mesh_db=None)
+    assert m.render_size == (240, 320) and m.pose_dim == 9 and m.backbone.n_features == 1536 and m.backbone.n_inputs == 6
+    assert set(m.heads) == {'pose'} and m.heads['pose'] is m.pose_fc and m.debug is False
+    # reference checkpoints load unchanged: same keys (incl. num_batches_tracked) and shapes
+    ref_keys, ref_shapes = list(golden['sd_keys']), golden['sd_shapes']
+    sd = m.state_dict()
+    assert list(sd.keys()) == ref_keys
+    for k, shp in zip(ref_keys, ref_shapes):
+        assert tuple(sd[k].shape) == tuple(int(v) for v in shp if v >= 0), k
+    full = {k: torch.from_numpy(v) for k, v in golden_sd.items()}
+    full.update({k: torch.tensor(0) for k in ref_keys if k.endswith('num_batches_tracked')})
+    m.load_state_dict(full, strict=True)
+    blob, _ = flat_params(m.backbone, m.pose_fc)
+    assert np.array_equal(blob.numpy(), oracle.flatten_state_dict(golden_sd))
+    for bad in ('flownet', 'resnet34', 'vgg'):
+        with pytest.raises(ValueError):
+            create_model_coarse(argparse.Namespace(backbone_str=bad, n_pose_dims=9), None, None)
+    assert type(create_model_refiner(cfg, None, None)) is type(m)
+
+
+def test_tensor_collections():
+    from cosypose_amd import tensor_collection as tc
+    infos = pd.DataFrame(dict(label=['a', 'b', 'c'], batch_im_id=[0, 0, 1], score=[.9, .8, .7]))
+    c = tc.PandasTensorCollection(infos, poses=torch.arange(48.).reshape(3, 4, 4), bboxes=torch.zeros(3, 4))
+    assert len(c) == 3 and c.poses.shape == (3, 4, 4) and set(c.tensors) == {'poses', 'bboxes'}
+    sub = c[[2, 0]]
+    assert list(sub.infos['label']) == ['c', 'a'] and torch.equal(sub.poses, c.poses[[2, 0]])
+    cat = tc.concatenate([c[[0]], c[[]], c[[1, 2]]])
+    assert list(cat.infos['label']) == ['a', 'b', 'c'] and torch.equal(cat.poses, c.poses)
+    assert len(tc.concatenate([c[[]]])) == 0
+    c.register_tensor('K_crop', torch.ones(3, 3, 3))
+    import pickle
+    c2 = pickle.loads(pickle.dumps(c))
+    assert list(c2.infos['label']) == ['a', 'b', 'c'] and torch.equal(c2.K_crop, c.K_crop)
+    with pytest.raises(AttributeError):
+        c.nope
+    assert c.float().poses.dtype == torch.float32 and c.clone().poses is not c.poses
+
+
+def test_mesh_db_matches_reference_sampling(golden):
+    from cosypose_amd.mesh_db import BatchedMeshes
+    from cosypose_amd import synthetic as syn
+    labels = np.array([f'o{i}' for i in range(4)])
+    pts = torch.from_numpy(syn.make_mesh_points(7, 4, 2500))
+    db = BatchedMeshes({l: dict(label=l, n_sym=1) for l in labels}, labels, pts, torch.eye(4).reshape(1, 1, 4, 4).repeat(4, 1, 1, 1))
+    sel = db.select(['o2', 'o0']).sample_points(2000, deterministic=True)
+    ids = golden['sample_ids_2500']  # what the reference's sample_points(2000, deterministic=True) drew
+    assert torch.equal(sel, pts[[2, 0]][:, ids])
+    assert torch.equal(db.point_table(2000), pts[:, ids])
+    assert db.object_ids(['o3', 'o1']).tolist() == [3, 1]
+    assert db.n_sym_mapping == {l: 1 for l in labels}
+
+
+def test_sharding():
+    from cosypose_amd.distributed import shard_range, balanced_assignment
+    for n in (0, 1, 7, 1024, 2048, 1001):
+        for world in (1, 2, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert [e - s for s, e in spans] == [len(x) for x in np.array_split(np.arange(n), world)]
+    costs = np.array([4] * 10 + [1] * 40, float)
+    parts = balanced_assignment(costs, 8)
+    loads = [costs[p].sum() for p in parts]
+    assert sorted(np.concatenate(parts).tolist()) == list(range(50)) and max(loads) - min(loads) <= 4
