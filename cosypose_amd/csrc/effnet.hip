@@ -69,7 +69,7 @@ struct cosy_net {
     cosy::Block blk[26];
     cosy::PwLayer head;
     void *X, *act[2], *E, *D, *Hd;
-    float *partial, *gate;
+    float *partial, *gate, *featbuf;
     void* wbase; void* abase;
     size_t wbytes, abytes;
     // profiling ring: PROF_SEGS forwards x (PROF_SLOTS+1) events
@@ -203,6 +203,7 @@ static void layout_workspace(cosy_net* n, Bump& b) {
     n->Hd = b.take(B * (size_t)n->Hf * n->Wf * HEAD_C * e);
     n->partial = (float*)b.take(B * part * sizeof(float));
     n->gate = (float*)b.take(B * gate * sizeof(float));
+    n->featbuf = (float*)b.take(B * (size_t)HEAD_C * sizeof(float));
 }
 
 static const char* dt_name(int dtype) { return dtype == COSY_F32 ? "float" : "__bf16"; }
@@ -280,8 +281,8 @@ static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps
     pw_name(n->head, kn, sizeof(kn));
     if ((rc = mark(kn, 26, pw_bytes(a), 2.0 * a.M * a.K * a.N))) return rc;
     if ((rc = tap(n->Hd, n->Hf * n->Wf, HEAD_C))) return rc;
-    if ((rc = launch_pool_fc(n->Hd, n->fc_w, n->fc_b, feat, nullptr, pose, B, n->Hf * n->Wf, n->dtype, s))) return rc;
-    snprintf(kn, sizeof(kn), "pool_fc_kernel<%s>", dt_name(n->dtype));
+    if ((rc = launch_pool_fc(n->Hd, n->fc_w, n->fc_b, feat, n->featbuf, pose, B, n->Hf * n->Wf, n->dtype, s))) return rc;
+    snprintf(kn, sizeof(kn), "pool_kernel<%s>+fc9_kernel", dt_name(n->dtype));
     if ((rc = mark(kn, 26, (double)B * n->Hf * n->Wf * HEAD_C * esz_d, 2.0 * B * HEAD_C * (n->Hf * n->Wf + N_POSE)))) return rc;
     if (prof) { n->prof_nslots = slot; ++n->prof_seg; }
     return COSY_OK;

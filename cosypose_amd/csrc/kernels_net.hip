@@ -32,7 +32,7 @@ __device__ __forceinline__ void mma(f32x4& c, f32x4 a, f32x4 b) {
 
 template <typename T> __device__ __forceinline__ float sigmoid_t(float x);
 template <> __device__ __forceinline__ float sigmoid_t<float>(float x) { return 1.f / (1.f + expf(-x)); }
-template <> __device__ __forceinline__ float sigmoid_t<bf16_t>(float x) { return __frcp_rn(1.f + __expf(-x)); }
+template <> __device__ __forceinline__ float sigmoid_t<bf16_t>(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 __device__ __forceinline__ void to_f32(const f32x4& r, float* v) { v[0] = r[0]; v[1] = r[1]; v[2] = r[2]; v[3] = r[3]; }
 __device__ __forceinline__ void to_f32(const bf16x8& r, float* v) {
@@ -298,117 +298,188 @@ int launch_pw_gemm(const PwArgs& a, PwCfg cfg, int dtype, hipStream_t s) {
 
 // ==========================================================================================
 // depthwise conv + BN + SiLU + squeeze partial sums
+//
+// LDS-staged tiles.  A workgroup owns TH x TW output pixels x CGB channel groups (8 channels = one 16-byte
+// bf16 vector each) of one sample:
+//   1. stage: the (TH*s+k-s) x (TW*s+k-s) x CGB input tile is pulled into LDS with wide, mutually independent
+//      16-byte loads (several per thread in flight -> memory-level parallelism; zero fill implements the static
+//      "same" padding of image_size=300 incl. the 15x20 -> 7x10 quirk), the k*k taps of the channel chunk too;
+//   2. compute: a thread owns (channel group, output column, 4 output rows): for every tap column it walks the
+//      input rows once from LDS (lanes are contiguous in LDS: conflict-free ds_read_b128) and feeds up to k
+//      accumulators (sliding window over rows), then BN + SiLU, one 16-byte NHWC store per output;
+//   3. the activated outputs are reduced per workgroup in a fixed order (deterministic) into
+//      partial[b][spatial tile][C] for the squeeze-excite pooling.
 // ==========================================================================================
-static int dw_cgb(int C) {  // channel groups (of 8) per workgroup: largest divisor of C/8 that is <= 32
-    const int cg = C / 8;
-    int best = 1;
-    for (int d = 1; d <= 32 && d <= cg; ++d)
-        if (cg % d == 0) best = d;
-    return best;
-}
 static constexpr int DW_R = 4;  // output rows per thread
-int dw_num_tiles(int C, int Ho, int Wo, int k) {
-    (void)k;
-    const int pb = 256 / dw_cgb(C);
-    return cdiv((long)Wo * cdiv(Ho, DW_R), pb);
+struct DwPlan { int CGB, TH, TW, THin, TWin, threads, n_chunks, ntx, nty; size_t lds; };
+static DwPlan dw_plan(int C, int Ho, int Wo, int k, int s, int esz) {
+    DwPlan p;
+    p.TW = Wo < 32 ? Wo : 32;
+    p.TH = Ho <= 4 ? 4 : 8;
+    p.THin = (p.TH - 1) * s + k; p.TWin = (p.TW - 1) * s + k;
+    const int cg = C / 8;
+    const size_t lim = esz == 2 ? 40 * 1024 : 60 * 1024;
+    p.CGB = 1;
+    for (int d = 1; d <= 16 && d <= cg; ++d) {
+        if (cg % d) continue;
+        const int units = p.TW * (p.TH / DW_R) * d;
+        const int thr = ((units < 256 ? units : 256) + 63) / 64 * 64;
+        const size_t lds = (size_t)p.THin * p.TWin * d * 8 * esz + (size_t)k * k * d * 32 + (size_t)thr * 32;
+        if (lds <= lim) p.CGB = d;
+    }
+    const int units = p.TW * (p.TH / DW_R) * p.CGB;
+    p.threads = ((units < 256 ? units : 256) + 63) / 64 * 64;
+    p.lds = (size_t)p.THin * p.TWin * p.CGB * 8 * esz + (size_t)k * k * p.CGB * 32 + (size_t)p.threads * 32;
+    p.n_chunks = cg / p.CGB;
+    p.ntx = cdiv(Wo, p.TW); p.nty = cdiv(Ho, p.TH);
+    return p;
 }
+int dw_num_tiles(int C, int Ho, int Wo, int k) { DwPlan p = dw_plan(C, Ho, Wo, k, 1, 2); return p.ntx * p.nty; }
 
 struct DwKArgs {
     const void* in; const float* w; const float* scale; const float* bias; void* out; float* partial;
-    int H, W, C, Ho, Wo, lo, CGB, PB, n_strips, n_tiles;
+    int H, W, C, Ho, Wo, lo, CGB, TH, TW, THin, TWin, ntx, n_tiles, n_chunks, n_jobs;
 };
+
+__device__ __forceinline__ void lds_ld8(const bf16_t* p, float* v) {
+    const uint4 u = *(const uint4*)p;
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ void lds_ld8(const float* p, float* v) { load8(p, v); }
 
 template <typename T, int KS, int S>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwKArgs a) {
     constexpr int R = DW_R;
-    __shared__ float red[256 * 8];
-    const int t = threadIdx.x;
-    const int cgl = t % a.CGB, ps = t / a.CGB;
-    const int c0 = (blockIdx.x * a.CGB + cgl) * 8;
-    const int sid = blockIdx.y * a.PB + ps;
-    const int b = blockIdx.z;
-    const bool active = ps < a.PB && sid < a.n_strips;
+    constexpr int NROW = (R - 1) * S + KS;  // input rows feeding R output rows
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int CGB = a.CGB, TWin = a.TWin, THin = a.THin;
+    T* tile = (T*)smem;                                                   // [THin][TWin][CGB][8]
+    float* wl = (float*)(smem + (size_t)THin * TWin * CGB * 8 * sizeof(T));  // [KS*KS][CGB][8]
+    float* red = wl + KS * KS * CGB * 8;                                  // [threads][8]
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    // XCD-aware decode: all channel chunks of one (sample, spatial tile) job run on the same XCD (id % 8), so the
+    // 128-byte lines they share are fetched into / written back from ONE L2 (the per-XCD L2s are not coherent).
+    const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
+    const int job = (jj / a.n_chunks) * 8 + xcd, chunk = jj % a.n_chunks;
+    if (job >= a.n_jobs) return;
+    const int tile_id = job % a.n_tiles, b = job / a.n_tiles;
+    const int tx = tile_id % a.ntx, ty = tile_id / a.ntx;
+    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+    const int iy0 = oy0 * S - a.lo, ix0 = ox0 * S - a.lo;
+    const int c0 = chunk * CGB * 8;
+    {   // ---- stage the input tile (zero padded) and the taps
+        const T* __restrict__ in = (const T*)a.in + (size_t)b * a.H * a.W * a.C + c0;
+        const int nvec = THin * TWin * CGB;
+        for (int v = tid; v < nvec; v += nthr) {
+            const int cg = v % CGB, p = v / CGB, xx = p % TWin, yy = p / TWin;
+            const int iy = iy0 + yy, ix = ix0 + xx;
+            typename DT<T>::raw_t r0, r1;
+            constexpr int EPL = DT<T>::EPL;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { r0[e] = 0; r1[e] = 0; }
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+                const T* src = in + ((size_t)iy * a.W + ix) * a.C + cg * 8;
+                r0 = *(const typename DT<T>::raw_t*)src;
+                if constexpr (sizeof(T) == 4) r1 = *(const typename DT<T>::raw_t*)(src + 4);
+            }
+            *(typename DT<T>::raw_t*)(tile + (size_t)v * 8) = r0;
+            if constexpr (sizeof(T) == 4) *(typename DT<T>::raw_t*)(tile + (size_t)v * 8 + 4) = r1;
+        }
+        const int nw = KS * KS * CGB * 2;  // float4 pieces
+        for (int i = tid; i < nw; i += nthr) {
+            const int h = i & 1, cg = (i >> 1) % CGB, tap = (i >> 1) / CGB;
+            *(f32x4*)(wl + (tap * CGB + cg) * 8 + h * 4) = *(const f32x4*)(a.w + (size_t)tap * a.C + c0 + cg * 8 + h * 4);
+        }
+    }
+    __syncthreads();
+    // ---- compute
+    const int nyq = a.TH / R;
+    const int units = a.TW * nyq * CGB;
+    const int stride = (nthr / CGB) * CGB;  // keeps a thread's channel group fixed across its units
     float sum[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) sum[c] = 0.f;
-    if (active) {
-        const int ox = sid % a.Wo, oy0 = (sid / a.Wo) * R;
-        const T* __restrict__ in = (const T*)a.in + (size_t)b * a.H * a.W * a.C + c0;
-        const float* __restrict__ w = a.w + c0;
-        float acc[R][8];
+    if (tid < stride) {
+        const int cg = tid % CGB;
+        float sc[8], bi[8];
+        load8(a.scale + c0 + cg * 8, sc);
+        load8(a.bias + c0 + cg * 8, bi);
+        T* __restrict__ out = (T*)a.out + (size_t)b * a.Ho * a.Wo * a.C + c0 + cg * 8;
+#pragma unroll 1
+        for (int u = tid; u < units; u += stride) {
+            const int q = u / CGB, x = q % a.TW, yq = q / a.TW;
+            const int ox = ox0 + x, oyb = oy0 + yq * R;
+            if (ox >= a.Wo || oyb >= a.Ho) continue;
+            float acc[R][8];
 #pragma unroll
-        for (int r = 0; r < R; ++r)
+            for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) acc[r][c] = 0.f;
+                for (int c = 0; c < 8; ++c) acc[r][c] = 0.f;
+#pragma unroll 1
+            for (int kx = 0; kx < KS; ++kx) {   // rolled on purpose: bounds live registers to one tap column
+                float wc[KS][8];
 #pragma unroll
-        for (int iyr = 0; iyr < (R - 1) * S + KS; ++iyr) {
-            const int iy = oy0 * S + iyr - a.lo;
-            if (iy < 0 || iy >= a.H) continue;
+                for (int ky = 0; ky < KS; ++ky) load8(wl + ((ky * KS + kx) * CGB + cg) * 8, wc[ky]);
+                const T* col = tile + ((size_t)(yq * R * S) * TWin + x * S + kx) * CGB * 8 + cg * 8;
 #pragma unroll
-            for (int kx = 0; kx < KS; ++kx) {
-                const int ix = ox * S + kx - a.lo;
-                float v[8];
-                if (ix >= 0 && ix < a.W) load8(in + ((size_t)iy * a.W + ix) * a.C, v);
-                else {
+                for (int rr = 0; rr < NROW; ++rr) {
+                    float v[8];
+                    lds_ld8(col + (size_t)rr * TWin * CGB * 8, v);
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) v[c] = 0.f;
-                }
+                    for (int r = 0; r < R; ++r) {
+                        const int ky = rr - r * S;
+                        if (ky >= 0 && ky < KS) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int ky = iyr - r * S;
-                    if (ky >= 0 && ky < KS) {
-                        float wv[8];
-                        load8(w + (size_t)(ky * KS + kx) * a.C, wv);
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) acc[r][c] += wv[c] * v[c];
+                            for (int c = 0; c < 8; ++c) acc[r][c] += wc[ky][c] * v[c];
+                        }
                     }
                 }
             }
-        }
-        float sc[8], bi[8];
-        load8(a.scale + c0, sc);
-        load8(a.bias + c0, bi);
-        T* __restrict__ out = (T*)a.out + (size_t)b * a.Ho * a.Wo * a.C + c0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int oy = oy0 + r;
-            if (oy >= a.Ho) break;
-            float y[8];
+            for (int r = 0; r < R; ++r) {
+                const int oy = oyb + r;
+                if (oy < a.Ho) {
+                    float y[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                float v = acc[r][c] * sc[c] + bi[c];
-                v = v * sigmoid_t<T>(v);
-                y[c] = v;
-                sum[c] += v;
+                    for (int c = 0; c < 8; ++c) {
+                        float v = acc[r][c] * sc[c] + bi[c];
+                        v = v * sigmoid_t<T>(v);
+                        y[c] = v;
+                        sum[c] += v;
+                    }
+                    store8(out + ((size_t)oy * a.Wo + ox) * a.C, y);
+                }
             }
-            store8(out + ((size_t)oy * a.Wo + ox) * a.C, y);
         }
     }
-    // deterministic per-workgroup reduction of the squeeze sums: fixed order over the pixel strips
+    // ---- deterministic reduction of the squeeze sums over the threads that share a channel group
 #pragma unroll
-    for (int c = 0; c < 8; ++c) red[t * 8 + c] = sum[c];
+    for (int c = 0; c < 8; ++c) red[tid * 8 + c] = sum[c];
     __syncthreads();
-    if (t < a.CGB * 8) {
-        const int g = t >> 3, ch = t & 7;
+    if (tid < CGB * 8) {
+        const int g = tid >> 3, ch = tid & 7;
         float s = 0.f;
-        for (int p = 0; p < a.PB; ++p) s += red[(p * a.CGB + g) * 8 + ch];
-        a.partial[((size_t)b * a.n_tiles + blockIdx.y) * a.C + (blockIdx.x * a.CGB + g) * 8 + ch] = s;
+        for (int t = g; t < stride; t += CGB) s += red[t * 8 + ch];
+        a.partial[((size_t)b * a.n_tiles + tile_id) * a.C + c0 + g * 8 + ch] = s;
     }
 }
 
 template <typename T>
 static int launch_dw_t(const DwArgs& a, hipStream_t s) {
+    const DwPlan p = dw_plan(a.C, a.Ho, a.Wo, a.k, a.s, sizeof(T));
     DwKArgs k;
     k.in = a.in; k.w = a.w; k.scale = a.scale; k.bias = a.bias; k.out = a.out; k.partial = a.partial;
     k.H = a.H; k.W = a.W; k.C = a.C; k.Ho = a.Ho; k.Wo = a.Wo; k.lo = a.pad_lo;
-    k.CGB = dw_cgb(a.C); k.PB = 256 / k.CGB;
-    k.n_strips = a.Wo * cdiv(a.Ho, DW_R);
-    k.n_tiles = cdiv(k.n_strips, k.PB);
-    dim3 grid((a.C / 8) / k.CGB, k.n_tiles, a.B);
-    if (a.k == 3 && a.s == 1) hipLaunchKernelGGL((dwconv_kernel<T, 3, 1>), grid, dim3(256), 0, s, k);
-    else if (a.k == 3 && a.s == 2) hipLaunchKernelGGL((dwconv_kernel<T, 3, 2>), grid, dim3(256), 0, s, k);
-    else if (a.k == 5 && a.s == 1) hipLaunchKernelGGL((dwconv_kernel<T, 5, 1>), grid, dim3(256), 0, s, k);
-    else if (a.k == 5 && a.s == 2) hipLaunchKernelGGL((dwconv_kernel<T, 5, 2>), grid, dim3(256), 0, s, k);
+    k.CGB = p.CGB; k.TH = p.TH; k.TW = p.TW; k.THin = p.THin; k.TWin = p.TWin; k.ntx = p.ntx; k.n_tiles = p.ntx * p.nty;
+    k.n_chunks = p.n_chunks; k.n_jobs = k.n_tiles * a.B;
+    dim3 grid((unsigned)cdiv(k.n_jobs, 8) * 8 * p.n_chunks), block(p.threads);
+    if (a.k == 3 && a.s == 1) hipLaunchKernelGGL((dwconv_kernel<T, 3, 1>), grid, block, p.lds, s, k);
+    else if (a.k == 3 && a.s == 2) hipLaunchKernelGGL((dwconv_kernel<T, 3, 2>), grid, block, p.lds, s, k);
+    else if (a.k == 5 && a.s == 1) hipLaunchKernelGGL((dwconv_kernel<T, 5, 1>), grid, block, p.lds, s, k);
+    else if (a.k == 5 && a.s == 2) hipLaunchKernelGGL((dwconv_kernel<T, 5, 2>), grid, block, p.lds, s, k);
     else { set_error("dwconv: unsupported k=%d s=%d", a.k, a.s); return COSY_EINVAL; }
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
@@ -420,25 +491,52 @@ int launch_dwconv(const DwArgs& a, int dtype, hipStream_t s) {
 }
 
 // ==========================================================================================
-// squeeze-excite gate (efficientnet.py:85-88)
+// squeeze-excite gate (efficientnet.py:85-88): pooled = sum(partials)/HW -> FC(C->Cse)+b -> swish ->
+// FC(Cse->C)+b -> sigmoid.  One 512-thread workgroup per sample; the pooling is spread over
+// (channel, tile-group) threads and finished by a fixed-order LDS reduction (deterministic).
 // ==========================================================================================
-__global__ __launch_bounds__(256) void se_kernel(SeArgs a) {
+__global__ __launch_bounds__(512) void se_kernel(SeArgs a) {
     extern __shared__ float sm[];
-    float* pooled = sm;          // C
-    float* redv = sm + a.C;      // Cse
+    const int C = a.C;
+    float* pooled = sm;              // C
+    float* redv = sm + C;            // Cse
+    float* scratch = sm + C + a.Cse; // 512
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float inv = 1.f / (float)a.HW;
-    for (int c = tid; c < a.C; c += 256) {
+    const float* part = a.partial + (size_t)b * a.n_tiles * C;
+    if (C >= 512 || a.n_tiles == 1) {
+        for (int c = tid; c < C; c += 512) {
+            float s0 = 0.f, s1 = 0.f;
+            int t = 0;
+            for (; t + 1 < a.n_tiles; t += 2) { s0 += part[(size_t)t * C + c]; s1 += part[(size_t)(t + 1) * C + c]; }
+            if (t < a.n_tiles) s0 += part[(size_t)t * C + c];
+            pooled[c] = (s0 + s1) * inv;
+        }
+    } else {
+        const int G = 512 / C;  // tile groups
+        const int c = tid % C, g = tid / C;
         float s = 0.f;
-        const float* p = a.partial + (size_t)b * a.n_tiles * a.C + c;
-        for (int t = 0; t < a.n_tiles; ++t) s += p[(size_t)t * a.C];
-        pooled[c] = s * inv;
+        if (g < G)
+            for (int t = g; t < a.n_tiles; t += G) s += part[(size_t)t * C + c];
+        scratch[tid] = s;
+        __syncthreads();
+        if (tid < C) {
+            float r = 0.f;
+            for (int gg = 0; gg < G; ++gg) r += scratch[gg * C + tid];
+            pooled[tid] = r * inv;
+        }
     }
     __syncthreads();
-    for (int j = wave; j < a.Cse; j += 4) {
-        float s = 0.f;
-        const float* wr = a.w_red + (size_t)j * a.C;
-        for (int c = lane; c < a.C; c += 64) s += wr[c] * pooled[c];
+    for (int j = wave; j < a.Cse; j += 8) {
+        const float* wr = a.w_red + (size_t)j * C;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int c = lane;
+        for (; c + 192 < C; c += 256) {
+            s0 += wr[c] * pooled[c]; s1 += wr[c + 64] * pooled[c + 64];
+            s2 += wr[c + 128] * pooled[c + 128]; s3 += wr[c + 192] * pooled[c + 192];
+        }
+        for (; c < C; c += 64) s0 += wr[c] * pooled[c];
+        float s = (s0 + s1) + (s2 + s3);
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if (lane == 0) {
             s += a.b_red[j];
@@ -446,16 +544,21 @@ __global__ __launch_bounds__(256) void se_kernel(SeArgs a) {
         }
     }
     __syncthreads();
-    for (int c = tid; c < a.C; c += 256) {
-        float s = 0.f;
-        for (int j = 0; j < a.Cse; ++j) s += a.w_exp[(size_t)j * a.C + c] * redv[j];  // w_exp stored (Cse, C)
-        s += a.b_exp[c];
-        a.gate[(size_t)b * a.C + c] = 1.f / (1.f + expf(-s));
+    for (int c = tid; c < C; c += 512) {
+        float s0 = 0.f, s1 = 0.f;
+        int j = 0;
+        for (; j + 1 < a.Cse; j += 2) {  // w_exp stored (Cse, C)
+            s0 += a.w_exp[(size_t)j * C + c] * redv[j];
+            s1 += a.w_exp[(size_t)(j + 1) * C + c] * redv[j + 1];
+        }
+        if (j < a.Cse) s0 += a.w_exp[(size_t)j * C + c] * redv[j];
+        const float s = s0 + s1 + a.b_exp[c];
+        a.gate[(size_t)b * C + c] = 1.f / (1.f + expf(-s));
     }
 }
 int launch_se(const SeArgs& a, hipStream_t s) {
     if (a.B == 0) return COSY_OK;
-    hipLaunchKernelGGL(se_kernel, dim3(a.B), dim3(256), (a.C + a.Cse) * sizeof(float), s, a);
+    hipLaunchKernelGGL(se_kernel, dim3(a.B), dim3(512), (a.C + a.Cse + 512) * sizeof(float), s, a);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }
@@ -518,38 +621,40 @@ int launch_stem(const void* x, const float* w, const float* scale, const float* 
 }
 
 // ==========================================================================================
-// global average pool + Linear(1536, 9)   (pose.py:83-86)
+// global average pool + Linear(1536, 9)   (pose.py:83-86): pool over (sample, 256-channel chunk)
+// workgroups, then one small workgroup per sample for the 9 dot products.
 // ==========================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void pool_fc_kernel(const T* __restrict__ head, const float* __restrict__ fw, const float* __restrict__ fb,
-                                                      float* __restrict__ feat, float* __restrict__ pose, int HW) {
+__global__ __launch_bounds__(256) void pool_kernel(const T* __restrict__ head, float* __restrict__ feat, int HW) {
     constexpr int C = 1536;
-    __shared__ float f[C];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const T* h = head + (size_t)b * HW * C;
-    for (int c = tid; c < C; c += 256) {
-        float s = 0.f;
-        for (int p = 0; p < HW; ++p) s += (float)h[(size_t)p * C + c];
-        s = s / (float)HW;
-        f[c] = s;
-        if (feat) feat[(size_t)b * C + c] = s;
-    }
-    __syncthreads();
-    for (int j = wave; j < 9; j += 4) {
-        float s = 0.f;
-        for (int c = lane; c < C; c += 64) s += fw[j * C + c] * f[c];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (lane == 0) pose[b * 9 + j] = s + fb[j];
-    }
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    const T* h = head + (size_t)b * HW * C + c;
+    float s0 = 0.f, s1 = 0.f;
+    int p = 0;
+    for (; p + 1 < HW; p += 2) { s0 += (float)h[(size_t)p * C]; s1 += (float)h[(size_t)(p + 1) * C]; }
+    if (p < HW) s0 += (float)h[(size_t)p * C];
+    feat[(size_t)b * C + c] = (s0 + s1) / (float)HW;
+}
+__global__ __launch_bounds__(576) void fc9_kernel(const float* __restrict__ feat, const float* __restrict__ fw,
+                                                  const float* __restrict__ fb, float* __restrict__ pose) {
+    constexpr int C = 1536;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, j = threadIdx.x >> 6;  // 9 waves, one output each
+    const float* f = feat + (size_t)b * C;
+    float s0 = 0.f, s1 = 0.f;
+    for (int c = lane; c < C; c += 128) { s0 += fw[j * C + c] * f[c]; s1 += fw[j * C + c + 64] * f[c + 64]; }
+    float s = s0 + s1;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) pose[b * 9 + j] = s + fb[j];
 }
 int launch_pool_fc(const void* head, const float* fc_w, const float* fc_b, float* feat, float* feat_scratch, float* pose, int B,
                    int HW, int dtype, hipStream_t s) {
-    (void)feat_scratch;
     if (B == 0) return COSY_OK;
-    if (dtype == COSY_F32)
-        hipLaunchKernelGGL(pool_fc_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)head, fc_w, fc_b, feat, pose, HW);
-    else
-        hipLaunchKernelGGL(pool_fc_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)head, fc_w, fc_b, feat, pose, HW);
+    float* f = feat ? feat : feat_scratch;
+    COSY_REQUIRE(f, "pool_fc: no feature buffer");
+    dim3 grid(1536 / 256, B);
+    if (dtype == COSY_F32) hipLaunchKernelGGL(pool_kernel<float>, grid, dim3(256), 0, s, (const float*)head, f, HW);
+    else hipLaunchKernelGGL(pool_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)head, f, HW);
+    hipLaunchKernelGGL(fc9_kernel, dim3(B), dim3(576), 0, s, f, fc_w, fc_b, pose);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }

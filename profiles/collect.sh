@@ -1,0 +1,24 @@
+#!/bin/bash
+# Profile `bench.py` on the GPU box (run through gpurun from the repo root):
+#   profiles/collect.sh <tag> [bench args...]
+# 1. rocprofv3 --kernel-trace --stats  (per-kernel time)            -> gpurun_out/prof_<tag>/stats
+# 2. PMC passes, each in its own run with counters only (never combined with sys/hip tracing)
+#    -> gpurun_out/prof_<tag>/pmc_*
+# Summaries for the judge are produced by profiles/summarize.py and copied into profiles/.
+set -u
+TAG=${1:-run}; shift || true
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-profile $*"
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o t -- python bench.py $ARGS > $OUT/bench_stats.json 2> $OUT/stats.err
+pass() { # name counters...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" -f csv -d $OUT/pmc_$name -o t -- python bench.py $ARGS > /dev/null 2> $OUT/pmc_$name.err || echo "pmc pass $name failed"
+}
+pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr TA_TOTAL_WAVEFRONTS_sum
+python profiles/summarize.py $OUT > $OUT/summary.txt 2>&1
+tail -60 $OUT/summary.txt

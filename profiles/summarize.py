@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Summarise a profiles/collect.sh output directory: per-kernel time (rocprofv3 --kernel-trace) and
+per-kernel mean PMC counters per launch.  HBM traffic follows MI355X_MICROARCH.md: on gfx950 FETCH_SIZE
+(KiB) reports half of a wide coalesced read stream -> read bytes ~= 2 * FETCH_SIZE * 1024 (upper bound for
+narrow accesses); WRITE_SIZE (KiB) is taken as is (uncalibrated)."""
+import csv
+import glob
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    """rocprofv3's demangler garbles the __bf16 template arguments; keep the base kernel name and, for the
+    mangled form, the template digits (e.g. pw_gemm_kernel[bf16,3,2])."""
+    m = re.match(r'_ZN4cosy\d+([a-z0-9_]+?)I(.*?)EEv', name)
+    if m:
+        args = re.sub(r'Li(\d+)E', r',\1', m.group(2)).replace('DF16b', 'bf16')
+        return f'{m.group(1)}[{args}]'
+    name = re.sub(r'^void ', '', name)
+    name = re.sub(r'\(.*$', '', name)
+    return name.replace('cosy::', '')
+
+
+def main(root):
+    times = defaultdict(list)
+    for f in glob.glob(f'{root}/stats/**/*kernel_trace.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            times[(short(r['Kernel_Name']), str(int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z'])))].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    ctr = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(f'{root}/pmc_*/**/*counter_collection.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            ctr[(short(r['Kernel_Name']), r.get('Grid_Size', ''))][r['Counter_Name']].append(float(r['Counter_Value']))
+    total = sum(sum(v) for v in times.values())
+    bykern = defaultdict(lambda: [0.0, 0])
+    for (k, g), v in times.items():
+        bykern[k][0] += sum(v); bykern[k][1] += len(v)
+    print(f'== per-kernel time (rocprofv3 --kernel-trace), total {total / 1e3:.2f} ms')
+    for k, (t, n) in sorted(bykern.items(), key=lambda kv: -kv[1][0])[:25]:
+        print(f'{100 * t / total:5.1f}%  n={n:5d}  avg {t / n:9.1f} us  {k}')
+    print('\n== per (kernel, grid): avg us | counters per launch (mean)')
+    names = sorted({c for v in ctr.values() for c in v})
+    for key, v in sorted(times.items(), key=lambda kv: -sum(kv[1]))[:60]:
+        c = ctr.get(key, {})
+        m = {n: sum(c[n]) / len(c[n]) for n in c}
+        extra = []
+        if 'FETCH_SIZE' in m:
+            extra.append(f"rd~{2 * m['FETCH_SIZE'] * 1024 / 1e6:.1f}MB")
+        if 'WRITE_SIZE' in m:
+            extra.append(f"wr~{m['WRITE_SIZE'] * 1024 / 1e6:.1f}MB")
+        if 'TCC_HIT_sum' in m and m['TCC_HIT_sum'] + m.get('TCC_MISS_sum', 0) > 0:
+            extra.append(f"L2hit={m['TCC_HIT_sum'] / (m['TCC_HIT_sum'] + m['TCC_MISS_sum']):.2f}")
+        if 'SQ_WAVE_CYCLES' in m and m['SQ_WAVE_CYCLES'] > 0:
+            wc = m['SQ_WAVE_CYCLES']
+            extra.append(f"wait={m.get('SQ_WAIT_ANY', 0) / wc:.2f} waitinst={m.get('SQ_WAIT_INST_ANY', 0) / wc:.2f} "
+                         f"valu={m.get('SQ_ACTIVE_INST_VALU', 0) / wc:.2f} vmem={m.get('SQ_ACTIVE_INST_VMEM', 0) / wc:.2f}")
+        if 'SQ_BUSY_CYCLES' in m and 'GRBM_GUI_ACTIVE' in m and m['GRBM_GUI_ACTIVE'] > 0:
+            extra.append(f"gui={m['GRBM_GUI_ACTIVE']:.0f}")
+        if 'TA_BUSY_avr' in m:
+            extra.append(f"TAbusy={m['TA_BUSY_avr']:.0f}")
+        if 'TCP_TOTAL_CACHE_ACCESSES_sum' in m:
+            extra.append(f"L1acc={m['TCP_TOTAL_CACHE_ACCESSES_sum'] / 1e6:.2f}M L1->L2rd={m.get('TCP_TCC_READ_REQ_sum', 0) / 1e6:.2f}M "
+                         f"wr={m.get('TCP_TCC_WRITE_REQ_sum', 0) / 1e6:.2f}M pend={m.get('TCP_PENDING_STALL_CYCLES_sum', 0) / 1e6:.1f}M")
+        print(f'{sum(v) / len(v):9.1f} us n={len(v):3d} {key[0]} grid={key[1]} | ' + ' '.join(extra))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/prof_run')
