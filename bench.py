@@ -182,9 +182,14 @@ def main():
             k['ms'] += r['ms_avg'] * r['n']; k['bytes'] += r['bytes'] * r['n']; k['flops'] += r['flops'] * r['n']; k['n'] += r['n']
         total_ms = sum(k['ms'] for k in kinds.values())
         if args.layers:
-            for r in recs:
-                print(f"{r['layer']:3d} {r['name']:34s} n={r['n']:3d} {r['ms_avg'] * 1e3:9.1f} us  {r['bytes'] / r['ms_avg'] / 1e6:8.1f} GB/s "
-                      f"{r['flops'] / r['ms_avg'] / 1e9:8.1f} TFLOP/s", file=sys.stderr)
+            per = {}
+            for r in recs:   # a chunked segment launches the same layer several times per forward: aggregate
+                k = per.setdefault((r['layer'], r['name']), dict(ms=0.0, bytes=0.0, flops=0.0, n=0))
+                k['ms'] += r['ms_avg'] * r['n']; k['bytes'] += r['bytes'] * r['n']; k['flops'] += r['flops'] * r['n']; k['n'] += r['n']
+            nfw = args.steps * (n_coarse + n_refine)
+            for (layer, name), k in per.items():
+                print(f"{layer:3d} {name:34s} n={k['n']:4d} {k['ms'] / nfw * 1e3:9.1f} us/fwd  {k['bytes'] / k['ms'] / 1e6:8.1f} GB/s "
+                      f"{k['flops'] / k['ms'] / 1e9:8.1f} TFLOP/s", file=sys.stderr)
             for name, k in sorted(kinds.items(), key=lambda kv: -kv[1]['ms']):
                 print(f"{name:34s} {100 * k['ms'] / total_ms:5.1f}%  avg {k['ms'] / k['n'] * 1e3:8.1f} us  {k['bytes'] / k['ms'] / 1e6:8.1f} GB/s "
                       f"{k['flops'] / k['ms'] / 1e9:8.1f} TFLOP/s", file=sys.stderr)

@@ -44,9 +44,9 @@ class ProfRec(ctypes.Structure):
 
 def profile_read(handle):
     """-> list of dicts, one per launch slot of the backbone schedule (see cosy_prof_rec_t)."""
-    recs = (ProfRec * 200)()
+    recs = (ProfRec * 1100)()
     n = _I(0)
-    check(lib().cosy_effnet_b3_profile_read(handle, recs, 200, ctypes.byref(n)))
+    check(lib().cosy_effnet_b3_profile_read(handle, recs, 1100, ctypes.byref(n)))
     return [dict(name=r.name.decode(), layer=r.layer, n=r.n, ms_avg=r.ms_avg, ms_min=r.ms_min, bytes=r.bytes, flops=r.flops)
             for r in recs[:n.value]]
 

@@ -68,8 +68,10 @@ struct cosy_net {
     float *stem_w, *stem_scale, *stem_bias, *fc_w, *fc_b;
     cosy::Block blk[26];
     cosy::PwLayer head;
-    void *X, *act[2], *E, *D, *Hd;
+    void *X, *act[2], *E, *D, *Hd, *actc[2], *Ec, *Dc;
+    int chunk;
     float *partial, *gate, *featbuf;
+    void* zeros;
     void* wbase; void* abase;
     size_t wbytes, abytes;
     // profiling ring: PROF_SEGS forwards x (PROF_SLOTS+1) events
@@ -77,7 +79,7 @@ struct cosy_net {
     hipEvent_t* prof_ev;
     cosy_prof_rec_t* prof_rec;
 };
-enum { PROF_SEGS = 64, PROF_SLOTS = 160 };
+enum { PROF_SEGS = 24, PROF_SLOTS = 1024 };
 
 namespace cosy {
 
@@ -184,34 +186,48 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
     return (long)(p - p0);
 }
 
+enum { EARLY_BLOCKS = 9 };  // stem + blocks 0..8 (feature maps >= 32x32 at 256^2) form the "early" segment
+
+// Early segment runs in sample chunks through small buffers that are REUSED for every chunk, so the large
+// high-resolution intermediates stay resident in the 256 MiB Infinity Cache / L2 between producer and consumer
+// kernels instead of round-tripping through HBM; the late segment (small maps, big GEMMs) runs on the full batch.
 static void layout_workspace(cosy_net* n, Bump& b) {
     const size_t B = n->maxB, e = n->esz;
-    size_t act = (size_t)n->Hs * n->Ws * STEM_C, ex = 0, dw = 0, part = 0, gate = 0;
+    const size_t Bc = (size_t)std::min(n->chunk, n->maxB);
+    size_t act_e = (size_t)n->Hs * n->Ws * STEM_C, ex_e = 0, dw_e = 0, act_l = 0, ex_l = 0, dw_l = 0, part = 0, gate = 0;
     for (int i = 0; i < 26; ++i) {
         const Block& k = n->blk[i];
+        const bool early = i < EARLY_BLOCKS;
+        size_t& act = early ? act_e : act_l; size_t& ex = early ? ex_e : ex_l; size_t& dw = early ? dw_e : dw_l;
         act = std::max(act, (size_t)k.Ho * k.Wo * k.d.cout);
+        if (i == EARLY_BLOCKS - 1) act_l = std::max(act_l, (size_t)k.Ho * k.Wo * k.d.cout);  // hand-over tensor
         if (k.d.e != 1) ex = std::max(ex, (size_t)k.H * k.W * k.cmid);
         dw = std::max(dw, (size_t)k.Ho * k.Wo * k.cmid);
-        part = std::max(part, (size_t)k.n_tiles * k.cmid);
+        part = std::max(part, (size_t)k.n_tiles * k.cmid * (early ? Bc : B));
         gate = std::max(gate, (size_t)k.cmid);
     }
     n->X = b.take(B * n->H * n->W * 8 * e);
-    n->act[0] = b.take(B * act * e);
-    n->act[1] = b.take(B * act * e);
-    n->E = b.take(B * ex * e);
-    n->D = b.take(B * dw * e);
+    n->actc[0] = b.take(Bc * act_e * e);
+    n->actc[1] = b.take(Bc * act_e * e);
+    n->Ec = b.take(Bc * ex_e * e);
+    n->Dc = b.take(Bc * dw_e * e);
+    n->act[0] = b.take(B * act_l * e);
+    n->act[1] = b.take(B * act_l * e);
+    n->E = b.take(B * ex_l * e);
+    n->D = b.take(B * dw_l * e);
     n->Hd = b.take(B * (size_t)n->Hf * n->Wf * HEAD_C * e);
-    n->partial = (float*)b.take(B * part * sizeof(float));
+    n->partial = (float*)b.take(part * sizeof(float));
     n->gate = (float*)b.take(B * gate * sizeof(float));
     n->featbuf = (float*)b.take(B * (size_t)HEAD_C * sizeof(float));
+    n->zeros = b.take(256);   // stays zero: the workspace is memset at creation and nothing writes here
 }
 
 static const char* dt_name(int dtype) { return dtype == COSY_F32 ? "float" : "__bf16"; }
 
 static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps, hipStream_t s) {
     int rc;
-    int tap_i = 0;
     const double esz_d = n->esz;
+    const size_t e = n->esz;
     const bool prof = n->prof_on && n->prof_seg < PROF_SEGS && !taps;
     hipEvent_t* ev = prof ? n->prof_ev + (size_t)n->prof_seg * (PROF_SLOTS + 1) : nullptr;
     int slot = 0;
@@ -227,60 +243,86 @@ static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps
         COSY_CHECK_HIP(hipEventRecord(ev[slot], s));
         return COSY_OK;
     };
-    auto pw_name = [&](const PwLayer& L, char* buf, size_t nbuf) { snprintf(buf, nbuf, "pw_gemm_kernel<%s, %d, %d>", dt_name(n->dtype), L.cfg.NI, L.cfg.WN); };
-    auto pw_bytes = [&](const PwArgs& a) { return ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N * (a.res ? 2 : 1)) * esz_d + (a.gate ? (double)B * a.K * 4 : 0); };
     char kn[48];
-    auto tap = [&](const void* act, int HW, int C) -> int {
+    auto pw_name = [&](const PwLayer& L) { snprintf(kn, sizeof(kn), "pw_gemm_kernel<%s, %d, %d>", dt_name(n->dtype), L.cfg.NI, L.cfg.WN); };
+    auto pw_bytes = [&](const PwArgs& a, int Bc) { return ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N * (a.res ? 2 : 1)) * esz_d + (a.gate ? (double)Bc * a.K * 4 : 0); };
+    auto tap = [&](const void* act, int Bc, int b0, int HW, int C, int idx) -> int {
         if (!taps) return COSY_OK;
-        return launch_taps(act, B, HW, C, n->dtype, taps, tap_i++, s);
+        return launch_taps(act, Bc, HW, C, n->dtype, taps + (size_t)b0 * 9 * 16, idx, s);
     };
-    if ((rc = launch_stem(n->X, n->stem_w, n->stem_scale, n->stem_bias, n->act[0], B, n->H, n->W, n->Hs, n->Ws, n->dtype, s))) return rc;
-    snprintf(kn, sizeof(kn), "stem_kernel<%s>", dt_name(n->dtype));
-    if ((rc = mark(kn, -1, ((double)B * n->H * n->W * 8 + (double)B * n->Hs * n->Ws * STEM_C) * esz_d, 2.0 * B * n->Hs * n->Ws * STEM_C * IN_C * 9))) return rc;
-    if ((rc = tap(n->act[0], n->Hs * n->Ws, STEM_C))) return rc;
-    int cur = 0, si = 0;
-    for (int i = 0; i < 26; ++i) {
+    // one MBConv block on Bc samples: [expand 1x1] -> depthwise (+squeeze partials) -> SE gate -> project 1x1 (+residual)
+    auto run_block = [&](int i, const void* in, void* out, int Bc, void* Ebuf, void* Dbuf) -> int {
         const Block& b = n->blk[i];
-        const void* src = n->act[cur];
+        const void* src = in;
         if (b.d.e != 1) {
             PwArgs a{};
-            a.A = n->act[cur]; a.Wp = b.exp.Wp; a.out = n->E; a.scale = b.exp.scale; a.bias = b.exp.bias;
-            a.M = B * b.H * b.W; a.K = b.d.cin; a.N = b.cmid; a.HW = b.H * b.W; a.silu = 1;
+            a.A = in; a.Wp = b.exp.Wp; a.out = Ebuf; a.scale = b.exp.scale; a.bias = b.exp.bias;
+            a.M = Bc * b.H * b.W; a.K = b.d.cin; a.N = b.cmid; a.HW = b.H * b.W; a.silu = 1;
             if ((rc = launch_pw_gemm(a, b.exp.cfg, n->dtype, s))) return rc;
-            pw_name(b.exp, kn, sizeof(kn));
-            if ((rc = mark(kn, i, pw_bytes(a), 2.0 * a.M * a.K * a.N))) return rc;
-            src = n->E;
+            pw_name(b.exp);
+            if ((rc = mark(kn, i, pw_bytes(a, Bc), 2.0 * a.M * a.K * a.N))) return rc;
+            src = Ebuf;
         }
         DwArgs d{};
-        d.in = src; d.w = b.dw_w; d.scale = b.dw_scale; d.bias = b.dw_bias; d.out = n->D; d.partial = n->partial;
-        d.B = B; d.H = b.H; d.W = b.W; d.C = b.cmid; d.Ho = b.Ho; d.Wo = b.Wo; d.k = b.d.k; d.s = b.d.s; d.pad_lo = b.pad_lo;
+        d.in = src; d.w = b.dw_w; d.scale = b.dw_scale; d.bias = b.dw_bias; d.out = Dbuf; d.partial = n->partial;
+        d.B = Bc; d.H = b.H; d.W = b.W; d.C = b.cmid; d.Ho = b.Ho; d.Wo = b.Wo; d.k = b.d.k; d.s = b.d.s; d.pad_lo = b.pad_lo; d.zeros = n->zeros;
         if ((rc = launch_dwconv(d, n->dtype, s))) return rc;
         snprintf(kn, sizeof(kn), "dwconv_kernel<%s, %d, %d>", dt_name(n->dtype), b.d.k, b.d.s);
-        if ((rc = mark(kn, i, ((double)B * b.H * b.W * b.cmid + (double)B * b.Ho * b.Wo * b.cmid) * esz_d + (double)B * b.n_tiles * b.cmid * 4,
-                       2.0 * B * b.Ho * b.Wo * b.cmid * b.d.k * b.d.k))) return rc;
-        SeArgs e{};
-        e.partial = n->partial; e.n_tiles = b.n_tiles; e.w_red = b.se_wr; e.b_red = b.se_br; e.w_exp = b.se_we; e.b_exp = b.se_be;
-        e.gate = n->gate; e.B = B; e.C = b.cmid; e.Cse = b.cse; e.HW = b.Ho * b.Wo;
-        if ((rc = launch_se(e, s))) return rc;
-        if ((rc = mark("se_kernel", i, (double)B * b.n_tiles * b.cmid * 4 + (double)B * b.cmid * 4 + 2.0 * b.cse * b.cmid * 4,
-                       4.0 * B * b.cse * b.cmid))) return rc;
+        if ((rc = mark(kn, i, ((double)Bc * b.H * b.W * b.cmid + (double)Bc * b.Ho * b.Wo * b.cmid) * esz_d + (double)Bc * b.n_tiles * b.cmid * 4,
+                       2.0 * Bc * b.Ho * b.Wo * b.cmid * b.d.k * b.d.k))) return rc;
+        SeArgs se{};
+        se.partial = n->partial; se.n_tiles = b.n_tiles; se.w_red = b.se_wr; se.b_red = b.se_br; se.w_exp = b.se_we; se.b_exp = b.se_be;
+        se.gate = n->gate; se.B = Bc; se.C = b.cmid; se.Cse = b.cse; se.HW = b.Ho * b.Wo;
+        if ((rc = launch_se(se, s))) return rc;
+        if ((rc = mark("se_kernel", i, (double)Bc * b.n_tiles * b.cmid * 4 + (double)Bc * b.cmid * 4 + 2.0 * b.cse * b.cmid * 4,
+                       4.0 * Bc * b.cse * b.cmid))) return rc;
         PwArgs a{};
-        a.A = n->D; a.Wp = b.proj.Wp; a.out = n->act[cur ^ 1]; a.scale = b.proj.scale; a.bias = b.proj.bias;
-        a.res = b.skip ? n->act[cur] : nullptr; a.gate = n->gate;
-        a.M = B * b.Ho * b.Wo; a.K = b.cmid; a.N = b.d.cout; a.HW = b.Ho * b.Wo; a.silu = 0;
+        a.A = Dbuf; a.Wp = b.proj.Wp; a.out = out; a.scale = b.proj.scale; a.bias = b.proj.bias;
+        a.res = b.skip ? in : nullptr; a.gate = n->gate;
+        a.M = Bc * b.Ho * b.Wo; a.K = b.cmid; a.N = b.d.cout; a.HW = b.Ho * b.Wo; a.silu = 0;
         if ((rc = launch_pw_gemm(a, b.proj.cfg, n->dtype, s))) return rc;
-        pw_name(b.proj, kn, sizeof(kn));
-        if ((rc = mark(kn, i, pw_bytes(a), 2.0 * a.M * a.K * a.N))) return rc;
+        pw_name(b.proj);
+        return mark(kn, i, pw_bytes(a, Bc), 2.0 * a.M * a.K * a.N);
+    };
+    auto stage_tap_index = [&](int i) -> int { for (int q = 0; q < 7; ++q) if (STAGE_END[q] == i) return q + 1; return -1; };
+
+    // ---- early segment, chunked
+    const Block& last_e = n->blk[EARLY_BLOCKS - 1];
+    const size_t handover = (size_t)last_e.Ho * last_e.Wo * last_e.d.cout * e;
+    const int chunk = std::min(n->chunk, n->maxB);
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int Bc = std::min(chunk, B - b0);
+        const char* x = (const char*)n->X + (size_t)b0 * n->H * n->W * 8 * e;
+        if ((rc = launch_stem(x, n->stem_w, n->stem_scale, n->stem_bias, n->actc[0], Bc, n->H, n->W, n->Hs, n->Ws, n->dtype, s))) return rc;
+        snprintf(kn, sizeof(kn), "stem_kernel<%s>", dt_name(n->dtype));
+        if ((rc = mark(kn, -1, ((double)Bc * n->H * n->W * 8 + (double)Bc * n->Hs * n->Ws * STEM_C) * esz_d, 2.0 * Bc * n->Hs * n->Ws * STEM_C * IN_C * 9))) return rc;
+        if ((rc = tap(n->actc[0], Bc, b0, n->Hs * n->Ws, STEM_C, 0))) return rc;
+        int cur = 0;
+        for (int i = 0; i < EARLY_BLOCKS; ++i) {
+            const Block& b = n->blk[i];
+            void* out = (i == EARLY_BLOCKS - 1) ? (void*)((char*)n->act[0] + (size_t)b0 * handover) : n->actc[cur ^ 1];
+            if ((rc = run_block(i, n->actc[cur], out, Bc, n->Ec, n->Dc))) return rc;
+            cur ^= 1;
+            const int ti = stage_tap_index(i);
+            if (ti >= 0 && (rc = tap(out, Bc, b0, b.Ho * b.Wo, b.d.cout, ti))) return rc;
+        }
+    }
+    // ---- late segment, full batch
+    int cur = 0;
+    for (int i = EARLY_BLOCKS; i < 26; ++i) {
+        const Block& b = n->blk[i];
+        if ((rc = run_block(i, n->act[cur], n->act[cur ^ 1], B, n->E, n->D))) return rc;
         cur ^= 1;
-        if (si < 7 && i == STAGE_END[si]) { if ((rc = tap(n->act[cur], b.Ho * b.Wo, b.d.cout))) return rc; ++si; }
+        const int ti = stage_tap_index(i);
+        if (ti >= 0 && (rc = tap(n->act[cur], B, 0, b.Ho * b.Wo, b.d.cout, ti))) return rc;
     }
     PwArgs a{};
     a.A = n->act[cur]; a.Wp = n->head.Wp; a.out = n->Hd; a.scale = n->head.scale; a.bias = n->head.bias;
     a.M = B * n->Hf * n->Wf; a.K = HEAD_IN; a.N = HEAD_C; a.HW = n->Hf * n->Wf; a.silu = 1;
     if ((rc = launch_pw_gemm(a, n->head.cfg, n->dtype, s))) return rc;
-    pw_name(n->head, kn, sizeof(kn));
-    if ((rc = mark(kn, 26, pw_bytes(a), 2.0 * a.M * a.K * a.N))) return rc;
-    if ((rc = tap(n->Hd, n->Hf * n->Wf, HEAD_C))) return rc;
+    pw_name(n->head);
+    if ((rc = mark(kn, 26, pw_bytes(a, B), 2.0 * a.M * a.K * a.N))) return rc;
+    if ((rc = tap(n->Hd, B, 0, n->Hf * n->Wf, HEAD_C, 8))) return rc;
     if ((rc = launch_pool_fc(n->Hd, n->fc_w, n->fc_b, feat, n->featbuf, pose, B, n->Hf * n->Wf, n->dtype, s))) return rc;
     snprintf(kn, sizeof(kn), "pool_kernel<%s>+fc9_kernel", dt_name(n->dtype));
     if ((rc = mark(kn, 26, (double)B * n->Hf * n->Wf * HEAD_C * esz_d, 2.0 * B * HEAD_C * (n->Hf * n->Wf + N_POSE)))) return rc;
@@ -318,6 +360,11 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
     if (!n) { set_error("create: host allocation failed"); return COSY_ENOMEM; }
     n->dtype = dtype; n->H = H; n->W = W; n->maxB = max_batch; n->esz = dtype == COSY_F32 ? 4 : 2;
     n->Hs = out_dim(H, 3, 2); n->Ws = out_dim(W, 3, 2);
+    {   // early-segment chunk (samples); COSY_EARLY_CHUNK overrides, 0 = whole batch
+        const char* ev = getenv("COSY_EARLY_CHUNK");
+        int c = ev ? atoi(ev) : 0;   // measured: chunking is slower (kernels are issue-bound, not HBM-bound)
+        n->chunk = c <= 0 ? max_batch : c;
+    }
     hipError_t herr = hipSuccess;
     Bump wb;
     const long used = build_weights(n, host_params, wb, false, &herr);

@@ -35,6 +35,7 @@ struct DwArgs {
     void* out;           // (B,Ho,Wo,C)
     float* partial;      // (B, n_tiles, C) per-tile sums of the activated output (SE squeeze)
     int B, H, W, C, Ho, Wo, k, s, pad_lo;
+    const void* zeros;   // >= 16 zero bytes (global), source of the padding for the LDS-DMA staging
 };
 int dw_num_tiles(int C, int Ho, int Wo, int k);
 int launch_dwconv(const DwArgs& a, int dtype, hipStream_t s);

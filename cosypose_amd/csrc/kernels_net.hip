@@ -339,6 +339,7 @@ int dw_num_tiles(int C, int Ho, int Wo, int k) { DwPlan p = dw_plan(C, Ho, Wo, k
 struct DwKArgs {
     const void* in; const float* w; const float* scale; const float* bias; void* out; float* partial;
     int H, W, C, Ho, Wo, lo, CGB, TH, TW, THin, TWin, ntx, n_tiles, n_chunks, n_jobs;
+    const void* zeros;  // >= 16 zero bytes in global memory
 };
 
 __device__ __forceinline__ void lds_ld8(const bf16_t* p, float* v) {
@@ -370,23 +371,38 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwKArgs a) {
     const int oy0 = ty * a.TH, ox0 = tx * a.TW;
     const int iy0 = oy0 * S - a.lo, ix0 = ox0 * S - a.lo;
     const int c0 = chunk * CGB * 8;
-    {   // ---- stage the input tile (zero padded) and the taps
+    {   // ---- stage the input tile (zero padded) with asynchronous global->LDS DMA (global_load_lds, 16 B per
+        // lane): every 16-byte unit of the tile is in flight at once, no staging VGPRs, no ds_write.  The tile rows
+        // are lane-linear in LDS (unit index = (x, channel) with channels fastest), which is exactly the DMA's
+        // destination rule (wave-uniform base + lane*16); out-of-image lanes fetch from a 16-byte zero page
+        // (= the static "same" padding).  Wave w stages tile rows w, w+nwaves, ...
+        constexpr int UPV = 8 * sizeof(T) / 16;      // 16-byte units per 8-channel vector (1 bf16, 2 fp32)
+        constexpr int JN = 5 * UPV;                  // max units per lane per tile row (TWin*CGB <= 320)
         const T* __restrict__ in = (const T*)a.in + (size_t)b * a.H * a.W * a.C + c0;
-        const int nvec = THin * TWin * CGB;
-        for (int v = tid; v < nvec; v += nthr) {
-            const int cg = v % CGB, p = v / CGB, xx = p % TWin, yy = p / TWin;
-            const int iy = iy0 + yy, ix = ix0 + xx;
-            typename DT<T>::raw_t r0, r1;
-            constexpr int EPL = DT<T>::EPL;
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthr >> 6;
+        const int rowunits = TWin * CGB * UPV, upp = CGB * UPV;  // units per row / per pixel
+        int goff[JN]; bool ok[JN];
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) { r0[e] = 0; r1[e] = 0; }
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-                const T* src = in + ((size_t)iy * a.W + ix) * a.C + cg * 8;
-                r0 = *(const typename DT<T>::raw_t*)src;
-                if constexpr (sizeof(T) == 4) r1 = *(const typename DT<T>::raw_t*)(src + 4);
+        for (int j = 0; j < JN; ++j) {
+            const int idx = lane + 64 * j;
+            const int xx = idx / upp, q = idx - xx * upp, ix = ix0 + xx;
+            ok[j] = ix >= 0 && ix < a.W;
+            goff[j] = ix * a.C + q * (16 / (int)sizeof(T));
+        }
+        for (int yy = wave; yy < THin; yy += nwaves) {
+            const int iy = iy0 + yy;
+            const bool yok = iy >= 0 && iy < a.H;
+            const T* rowp = in + (size_t)iy * a.W * a.C;
+            char* dst = smem + (size_t)yy * rowunits * 16;
+#pragma unroll
+            for (int j = 0; j < JN; ++j) {
+                if (64 * j < rowunits) {
+                    const void* src = (yok && ok[j]) ? (const void*)(rowp + goff[j]) : (const void*)a.zeros;
+                    if (lane + 64 * j < rowunits)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                         (__attribute__((address_space(3))) void*)(dst + 64 * j * 16), 16, 0, 0);
+                }
             }
-            *(typename DT<T>::raw_t*)(tile + (size_t)v * 8) = r0;
-            if constexpr (sizeof(T) == 4) *(typename DT<T>::raw_t*)(tile + (size_t)v * 8 + 4) = r1;
         }
         const int nw = KS * KS * CGB * 2;  // float4 pieces
         for (int i = tid; i < nw; i += nthr) {
@@ -394,6 +410,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwKArgs a) {
             *(f32x4*)(wl + (tap * CGB + cg) * 8 + h * 4) = *(const f32x4*)(a.w + (size_t)tap * a.C + c0 + cg * 8 + h * 4);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA has landed; the barrier publishes it
     __syncthreads();
     // ---- compute
     const int nyq = a.TH / R;
@@ -474,7 +491,7 @@ static int launch_dw_t(const DwArgs& a, hipStream_t s) {
     k.in = a.in; k.w = a.w; k.scale = a.scale; k.bias = a.bias; k.out = a.out; k.partial = a.partial;
     k.H = a.H; k.W = a.W; k.C = a.C; k.Ho = a.Ho; k.Wo = a.Wo; k.lo = a.pad_lo;
     k.CGB = p.CGB; k.TH = p.TH; k.TW = p.TW; k.THin = p.THin; k.TWin = p.TWin; k.ntx = p.ntx; k.n_tiles = p.ntx * p.nty;
-    k.n_chunks = p.n_chunks; k.n_jobs = k.n_tiles * a.B;
+    k.n_chunks = p.n_chunks; k.n_jobs = k.n_tiles * a.B; k.zeros = a.zeros;
     dim3 grid((unsigned)cdiv(k.n_jobs, 8) * 8 * p.n_chunks), block(p.threads);
     if (a.k == 3 && a.s == 1) hipLaunchKernelGGL((dwconv_kernel<T, 3, 1>), grid, block, p.lds, s, k);
     else if (a.k == 3 && a.s == 2) hipLaunchKernelGGL((dwconv_kernel<T, 3, 2>), grid, block, p.lds, s, k);

@@ -84,7 +84,7 @@ int cosy_effnet_b3_features_nchw(cosy_net_t* net, int B, float* out, cosy_stream
 
 /* ---- measurement hook ---------------------------------------------------------------------
  * With profiling enabled every launch of cosy_effnet_b3_forward is bracketed by HIP events recorded on the
- * launch stream (no synchronisation, one hipEventRecord per kernel; up to 64 forwards are retained).
+ * launch stream (no synchronisation, one hipEventRecord per kernel; up to 24 forwards are retained).
  * cosy_effnet_b3_profile_read blocks until the recorded events have completed and returns one record per
  * launch slot of the schedule: kernel name (as rocprofv3 prints it, abbreviated), layer index, number of
  * timed launches, mean/min duration, and the ALGORITHMIC bytes and flops of one launch (tensor sizes
