@@ -25,6 +25,7 @@ _SIGNATURES = {
     'cosy_effnet_b3_features_nchw': ([_P, _I, _P, _P], _I),
     'cosy_effnet_b3_set_profiling': ([_P, _I], _I),
     'cosy_effnet_b3_profile_read': ([_P, _P, _I, _c.POINTER(_I)], _I),
+    'cosy_frames_to_nhwc4': ([_P, _P, _I, _I, _I, _P], _I),
     'cosy_crop_pack': ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     'cosy_effnet_b3_forward': ([_P, _I, _P, _P, _P, _P], _I),
     'cosy_crop_geometry': ([_P, _P, _P, _P, _P, _I, _I, _F, _I, _I, _I, _I, _F, _P, _P, _P, _P], _I),

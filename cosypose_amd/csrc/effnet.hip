@@ -56,8 +56,9 @@ static long param_count() {
 
 struct PwLayer { int K = 0, N = 0; PwCfg cfg{4, 2}; void* Wp = nullptr; float* scale = nullptr; float* bias = nullptr; };
 struct Block {
-    BlkDef d; int cmid, cse, H, W, Ho, Wo, pad_lo, n_tiles; bool skip;
+    BlkDef d; int cmid, cse, H, W, Ho, Wo, pad_lo, n_tiles; bool skip, fused;
     PwLayer exp, proj;
+    void* exp_wp_fused;   // expand weights packed in 48-channel tiles for mbconv_front_kernel
     float *dw_w, *dw_scale, *dw_bias, *se_wr, *se_br, *se_we, *se_be;
 };
 
@@ -69,7 +70,7 @@ struct cosy_net {
     cosy::Block blk[26];
     cosy::PwLayer head;
     void *X, *act[2], *E, *D, *Hd, *actc[2], *Ec, *Dc;
-    int chunk;
+    int chunk, fuse;
     float *partial, *gate, *featbuf;
     void* zeros;
     void* wbase; void* abase;
@@ -141,8 +142,23 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         int hi; static_pad(b.d.k, b.d.s, &b.pad_lo, &hi);
         b.skip = (b.d.s == 1 && b.d.cin == b.d.cout);  // id_skip, efficientnet.py:94
         b.n_tiles = dw_num_tiles(b.cmid, b.Ho, b.Wo, b.d.k);
+        // blocks 2..5 (>= 64x64 maps at 256^2, Cin <= 32): expand + depthwise fused, expanded tensor stays in LDS
+        b.fused = n->fuse && b.d.e != 1 && i >= 2 && i <= 5 && fuse_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype);
+        b.exp_wp_fused = nullptr;
         if (b.d.e != 1) {
             mk_pw(b.exp, p, b.d.cin, b.cmid, p + (size_t)b.cmid * b.d.cin);
+            if (b.fused) {
+                const PwCfg c48{3, 1};
+                const size_t ne = pw_packed_elems(b.d.cin, b.cmid, c48, n->dtype);
+                b.exp_wp_fused = bump.take(ne * n->esz);
+                if (fill) {
+                    std::vector<char> tmp(ne * n->esz);
+                    pw_pack_weights(p, b.d.cin, b.cmid, c48, n->dtype, tmp.data());
+                    hipError_t e2 = hipMemcpy(b.exp_wp_fused, tmp.data(), tmp.size(), hipMemcpyHostToDevice);
+                    if (e2 != hipSuccess) *herr = e2;
+                }
+                b.n_tiles = fuse_num_tiles(b.d.cin, b.Ho, b.Wo, b.d.k, b.d.s, n->dtype);
+            }
             p += (size_t)b.cmid * b.d.cin + 4 * b.cmid;
         }
         {   // depthwise (Cmid,1,k,k) -> [tap][Cmid]
@@ -254,6 +270,16 @@ static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps
     auto run_block = [&](int i, const void* in, void* out, int Bc, void* Ebuf, void* Dbuf) -> int {
         const Block& b = n->blk[i];
         const void* src = in;
+        if (b.fused) {
+            FuseArgs f{};
+            f.X = in; f.Wp = b.exp_wp_fused; f.s0 = b.exp.scale; f.b0 = b.exp.bias; f.dww = b.dw_w; f.s1 = b.dw_scale; f.b1 = b.dw_bias;
+            f.D = Dbuf; f.partial = n->partial; f.zeros = n->zeros;
+            f.B = Bc; f.H = b.H; f.W = b.W; f.Cin = b.d.cin; f.Cmid = b.cmid; f.Ho = b.Ho; f.Wo = b.Wo; f.k = b.d.k; f.s = b.d.s; f.pad_lo = b.pad_lo;
+            if ((rc = launch_mbconv_front(f, n->dtype, s))) return rc;
+            snprintf(kn, sizeof(kn), "mbconv_front_kernel<%s, %d, %d>", dt_name(n->dtype), b.d.k, b.d.s);
+            if ((rc = mark(kn, i, ((double)Bc * b.H * b.W * b.d.cin + (double)Bc * b.Ho * b.Wo * b.cmid + (double)b.d.cin * b.cmid) * esz_d,
+                           2.0 * Bc * b.H * b.W * b.d.cin * b.cmid + 2.0 * Bc * b.Ho * b.Wo * b.cmid * b.d.k * b.d.k))) return rc;
+        } else {
         if (b.d.e != 1) {
             PwArgs a{};
             a.A = in; a.Wp = b.exp.Wp; a.out = Ebuf; a.scale = b.exp.scale; a.bias = b.exp.bias;
@@ -270,6 +296,7 @@ static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps
         snprintf(kn, sizeof(kn), "dwconv_kernel<%s, %d, %d>", dt_name(n->dtype), b.d.k, b.d.s);
         if ((rc = mark(kn, i, ((double)Bc * b.H * b.W * b.cmid + (double)Bc * b.Ho * b.Wo * b.cmid) * esz_d + (double)Bc * b.n_tiles * b.cmid * 4,
                        2.0 * Bc * b.Ho * b.Wo * b.cmid * b.d.k * b.d.k))) return rc;
+        }
         SeArgs se{};
         se.partial = n->partial; se.n_tiles = b.n_tiles; se.w_red = b.se_wr; se.b_red = b.se_br; se.w_exp = b.se_we; se.b_exp = b.se_be;
         se.gate = n->gate; se.B = Bc; se.C = b.cmid; se.Cse = b.cse; se.HW = b.Ho * b.Wo;
@@ -364,6 +391,8 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
         const char* ev = getenv("COSY_EARLY_CHUNK");
         int c = ev ? atoi(ev) : 0;   // measured: chunking is slower (kernels are issue-bound, not HBM-bound)
         n->chunk = c <= 0 ? max_batch : c;
+        const char* fv = getenv("COSY_FUSE");
+        n->fuse = fv ? atoi(fv) : 1;
     }
     hipError_t herr = hipSuccess;
     Bump wb;
@@ -448,6 +477,11 @@ int cosy_effnet_b3_set_input_nchw(cosy_net_t* n, const float* x, int B, cosy_str
     COSY_REQUIRE(n && x, "set_input: null argument");
     COSY_REQUIRE(B >= 0 && B <= n->maxB, "set_input: batch %d exceeds max_batch %d", B, n->maxB);
     return launch_pack_nchw(n->X, n->dtype, x, B, n->H, n->W, (hipStream_t)stream);
+}
+
+int cosy_frames_to_nhwc4(const float* images, float* out, int N, int h, int w, cosy_stream_t stream) {
+    COSY_REQUIRE(images && out, "frames_to_nhwc4: null argument");
+    return launch_frames_to_nhwc4(images, out, N, h, w, (hipStream_t)stream);
 }
 
 int cosy_crop_pack(cosy_net_t* n, const float* images, const int* im_id, const float* boxes_crop, const float* renders, int B,

@@ -40,6 +40,22 @@ struct DwArgs {
 int dw_num_tiles(int C, int Ho, int Wo, int k);
 int launch_dwconv(const DwArgs& a, int dtype, hipStream_t s);
 
+// fused expand(1x1, MFMA) + depthwise front half of an MBConv block (the expanded tensor stays in LDS)
+struct FuseArgs {
+    const void* X;       // (B,H,W,Cin) block input
+    const void* Wp;      // expand weights packed with PwCfg{3,1} (48-channel tiles)
+    const float* s0; const float* b0;   // folded BN0 (Cmid)
+    const float* dww;    // (k*k, Cmid) fp32 depthwise taps
+    const float* s1; const float* b1;   // folded BN1 (Cmid)
+    void* D;             // (B,Ho,Wo,Cmid)
+    float* partial;      // (B, n_tiles, Cmid)
+    const void* zeros;
+    int B, H, W, Cin, Cmid, Ho, Wo, k, s, pad_lo;
+};
+bool fuse_supported(int Cin, int Cmid, int k, int s, int dtype);
+int fuse_num_tiles(int Cin, int Ho, int Wo, int k, int s, int dtype);
+int launch_mbconv_front(const FuseArgs& a, int dtype, hipStream_t s);
+
 struct SeArgs {
     const float* partial;  // (B, n_tiles, C)
     int n_tiles;

@@ -106,6 +106,9 @@ class PosePredictor(nn.Module):
         images = images.detach().float().contiguous()
         K = K.detach().float().contiguous()
         dev = TCO.device
+        # frames -> interleaved (N,h,w,4) once per call: the crop kernel then fetches a pixel's RGB with one 16-byte load
+        frames4 = torch.empty(n_im, h, w, 4, device=dev, dtype=torch.float32)
+        check(lib().cosy_frames_to_nhwc4(ptr(images), ptr(frames4), n_im, h, w, stream()))
         obj_ids = self.mesh_db.object_ids(labels, dev)
         net = self._net(bsz, dev)
         H, W = self.render_size
@@ -120,7 +123,7 @@ class PosePredictor(nn.Module):
             require_device(renders)
             renders = renders.detach().float().contiguous()
             assert renders.shape == (bsz, 3, H, W), renders.shape
-            check(lib().cosy_crop_pack(net, ptr(images), ptr(im_ids), ptr(boxes_crop), ptr(renders), bsz, n_im, h, w, stream()))
+            check(lib().cosy_crop_pack(net, ptr(frames4), ptr(im_ids), ptr(boxes_crop), ptr(renders), bsz, n_im, h, w, stream()))
             pose = torch.empty(bsz, self.pose_dim, device=dev)
             check(lib().cosy_effnet_b3_forward(net, bsz, None, ptr(pose), None, stream()))
             model_outputs = dict(pose=pose)

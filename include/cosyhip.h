@@ -65,12 +65,17 @@ size_t cosy_effnet_b3_workspace_bytes(const cosy_net_t* net);
  * (what torch.cat((images_crop, renders), 1) produces, pose.py:104). */
 int cosy_effnet_b3_set_input_nchw(cosy_net_t* net, const float* x, int B, cosy_stream_t stream);
 
+/* Frames (N,3,h,w) fp32 planar -> (N,h,w,4) fp32 interleaved (RGB + pad), the layout cosy_crop_pack samples from.
+ * Done once per PosePredictor.forward call (the frames do not change across iterations); out holds N*h*w*4 floats. */
+int cosy_frames_to_nhwc4(const float* images, float* out, int N, int h, int w, cosy_stream_t stream);
+
 /* Fused replacement of deepim_crops_robust's roi_align (cosypose/lib3d/cropping.py:73-74,
  * torchvision 0.4.2 semantics, sampling_ratio=4) + torch.cat with the renders (pose.py:104):
  * writes observed crop -> channels 0..2 and renders (B,3,H,W fp32 NCHW) -> channels 3..5 of
- * the net input.  images (N,3,h,w); im_id (B) int32 index into images or NULL for identity
- * (the reference gathers images[im_ids] first, cosypose/integrated/pose_predictor.py:41). */
-int cosy_crop_pack(cosy_net_t* net, const float* images, const int* im_id, const float* boxes_crop,
+ * the net input.  frames_nhwc4 (N,h,w,4) from cosy_frames_to_nhwc4; im_id (B) int32 index into the frames
+ * or NULL for identity (the reference gathers images[im_ids] first, cosypose/integrated/pose_predictor.py:41).
+ * The 16 bilinear samples of a pixel are evaluated in separable form (same sum, fp32 rounding differs ~1e-7). */
+int cosy_crop_pack(cosy_net_t* net, const float* frames_nhwc4, const int* im_id, const float* boxes_crop,
                    const float* renders, int B, int N, int h, int w, cosy_stream_t stream);
 
 /* Run the backbone on the current input: feat (B,1536) fp32 or NULL, pose9 (B,9) fp32,
