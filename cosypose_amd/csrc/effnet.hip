@@ -283,7 +283,7 @@ static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps
         if (b.d.e != 1) {
             PwArgs a{};
             a.A = in; a.Wp = b.exp.Wp; a.out = Ebuf; a.scale = b.exp.scale; a.bias = b.exp.bias;
-            a.M = Bc * b.H * b.W; a.K = b.d.cin; a.N = b.cmid; a.HW = b.H * b.W; a.silu = 1;
+            a.M = Bc * b.H * b.W; a.K = b.d.cin; a.N = b.cmid; a.HW = b.H * b.W; a.silu = 1; a.zeros = n->zeros;
             if ((rc = launch_pw_gemm(a, b.exp.cfg, n->dtype, s))) return rc;
             pw_name(b.exp);
             if ((rc = mark(kn, i, pw_bytes(a, Bc), 2.0 * a.M * a.K * a.N))) return rc;
@@ -306,7 +306,7 @@ static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps
         PwArgs a{};
         a.A = Dbuf; a.Wp = b.proj.Wp; a.out = out; a.scale = b.proj.scale; a.bias = b.proj.bias;
         a.res = b.skip ? in : nullptr; a.gate = n->gate;
-        a.M = Bc * b.Ho * b.Wo; a.K = b.cmid; a.N = b.d.cout; a.HW = b.Ho * b.Wo; a.silu = 0;
+        a.M = Bc * b.Ho * b.Wo; a.K = b.cmid; a.N = b.d.cout; a.HW = b.Ho * b.Wo; a.silu = 0; a.zeros = n->zeros;
         if ((rc = launch_pw_gemm(a, b.proj.cfg, n->dtype, s))) return rc;
         pw_name(b.proj);
         return mark(kn, i, pw_bytes(a, Bc), 2.0 * a.M * a.K * a.N);
@@ -345,7 +345,7 @@ static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps
     }
     PwArgs a{};
     a.A = n->act[cur]; a.Wp = n->head.Wp; a.out = n->Hd; a.scale = n->head.scale; a.bias = n->head.bias;
-    a.M = B * n->Hf * n->Wf; a.K = HEAD_IN; a.N = HEAD_C; a.HW = n->Hf * n->Wf; a.silu = 1;
+    a.M = B * n->Hf * n->Wf; a.K = HEAD_IN; a.N = HEAD_C; a.HW = n->Hf * n->Wf; a.silu = 1; a.zeros = n->zeros;
     if ((rc = launch_pw_gemm(a, n->head.cfg, n->dtype, s))) return rc;
     pw_name(n->head);
     if ((rc = mark(kn, 26, pw_bytes(a, B), 2.0 * a.M * a.K * a.N))) return rc;

@@ -24,6 +24,7 @@ struct PwArgs {
     const float* gate;   // (B,K) SE gate applied to A rows, or null
     int M, K, N, HW;     // HW = rows per sample (for the gate)
     int silu;
+    const void* zeros;   // >= 16 zero bytes (global): source of padded rows/k for the LDS-DMA pipeline; null -> classic kernel
 };
 int launch_pw_gemm(const PwArgs& a, PwCfg cfg, int dtype, hipStream_t s);
 

@@ -15,6 +15,7 @@
 //   pool_fc   : global average pool + Linear(1536, 9).
 #include "kernels_net.h"
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -114,6 +115,7 @@ void pw_pack_weights(const float* w, int K, int N, PwCfg c, int dtype, void* dst
 struct PwKArgs {
     const void* A; const void* Wp; void* out; const float* scale; const float* bias; const void* res; const float* gate;
     int M, K, N, HW, silu, MT, NT, nkb_total, nkb_valid;
+    const void* zeros;
 };
 
 template <typename T, int NI, int WN>
@@ -273,6 +275,185 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwKArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Pipelined variant: both operands arrive by asynchronous global->LDS DMA (global_load_lds, 16 B/lane, one
+// instruction per 1 KiB fragment block: the blocks are lane-linear, which is exactly the DMA's destination rule)
+// into an NS-stage ring of 32-deep k-blocks.  Per k-block: counted s_waitcnt vmcnt (never 0 in steady state, the
+// next NS-2 k-blocks stay in flight across the barrier), ONE raw s_barrier, issue the DMA for k-block kb+NS-1, MFMA.
+// No staging VGPRs, no ds_write, no ordinary global loads inside the loop (they would make the compiler drain the
+// DMA queue).  Every wave issues the same number L of DMA instructions per k-block (surplus ones land in a dummy
+// block) so that the vmcnt immediates are compile-time constants.
+// SE gate (project convs): out = sum_k D[m,k] g[b,k] W[n,k]; the gate is folded into the WEIGHT fragments
+// (W[n,k]*g[b,k]) at fragment-read time from a gate row staged in LDS; valid when the 64 pixel rows of a wave belong
+// to one sample (HW % 64 == 0); otherwise the launcher falls back to pw_gemm_kernel (gate on the activation rows).
+// ------------------------------------------------------------------------------------------
+template <typename T, int NI, int WN, int NS, bool GATE>
+__global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwKArgs a) {
+    using D = DT<T>;
+    using raw_t = typename D::raw_t;
+    constexpr int EPL = D::EPL, KB = D::KB;
+    constexpr int WM = 4 / WN, MI = 4, BM = 64 * WM, BN = 16 * NI * WN;
+    constexpr int NA = BM / 16, NW = NI * WN, NB = NA + NW;
+    constexpr int L = (NB + 3) / 4;   // DMA instructions per wave per k-block
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* dummy = lds + NS * NB * 1024;
+    float* gl = (float*)(dummy + 1024);   // GATE: [2][Kpad] gate rows of the (<= 2) samples under this m-tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
+    const int mt = (jj / a.NT) * 8 + xcd, nt = jj % a.NT;
+    if (mt >= a.MT) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const T* __restrict__ A = (const T*)a.A;
+    const T* __restrict__ Wp = (const T*)a.Wp;
+    const int K = a.K, M = a.M, N = a.N;
+    const int row = lane & 15, kg = lane >> 4;
+    const int Kpad = a.nkb_total * KB;
+
+    int gsel = 0;
+    if constexpr (GATE) {
+        const int b_first = m0 / a.HW;
+        for (int i = tid; i < 2 * Kpad; i += 256) {
+            const int sidx = i / Kpad, k = i - sidx * Kpad;
+            const long mrow = (long)(b_first + sidx) * a.HW;
+            gl[i] = (k < K && mrow < M) ? a.gate[(size_t)(b_first + sidx) * K + k] : 0.f;
+        }
+        gsel = (m0 + wm * 64) / a.HW - b_first;
+        __syncthreads();
+    }
+
+    auto issue = [&](int kb) {
+        char* st = lds + (kb % NS) * NB * 1024;
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const int blk = i * 4 + wave;
+            const void* src = a.zeros;
+            char* dst = dummy;
+            if (kb < a.nkb_valid && blk < NB) {
+                dst = st + blk * 1024;
+                if (blk < NA) {
+                    const int m = m0 + blk * 16 + row, k = kb * KB + kg * EPL;
+                    if (m < M && k < K) src = A + (size_t)m * K + k;
+                } else {
+                    src = Wp + ((size_t)(nt * NW + (blk - NA)) * a.nkb_total + kb) * 64 * EPL + lane * EPL;
+                }
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0) issue(s0);
+    for (int kb = 0; kb < a.nkb_valid; ++kb) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * L) : "memory");  // k-block kb has landed (this wave's part)
+        __builtin_amdgcn_s_barrier();                                          // ... and everybody's; stage (kb-1)%NS is free
+        asm volatile("" ::: "memory");
+        issue(kb + NS - 1);
+        const char* st = lds + (kb % NS) * NB * 1024;
+        raw_t fw[NI], fa[MI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) fw[ni] = *(const raw_t*)(st + (NA + wn * NI + ni) * 1024 + lane * 16);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) fa[mi] = *(const raw_t*)(st + (wm * MI + mi) * 1024 + lane * 16);
+        if constexpr (GATE) {
+            float g[EPL];
+            const float* gp = gl + gsel * Kpad + kb * KB + kg * EPL;
+#pragma unroll
+            for (int e = 0; e < EPL; e += 4) load4(gp + e, g + e);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                float f[EPL];
+                to_f32(fw[ni], f);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) f[e] *= g[e];
+                from_f32(fw[ni], f);
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], fw[ni], fa[mi]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue (same as pw_gemm_kernel)
+    const int nl = n0 + wn * 16 * NI + kg * 4 * NI;
+    float sc[NI][4], bi[NI][4];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        load4(a.scale + nl + ni * 4, sc[ni]);
+        load4(a.bias + nl + ni * 4, bi[ni]);
+    }
+    T* __restrict__ out = (T*)a.out;
+    const T* __restrict__ res = (const T*)a.res;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + (wm * MI + mi) * 16 + row;
+        if (m >= M) continue;
+        float y[NI * 4];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[mi][ni][r] * sc[ni][r] + bi[ni][r];
+                if (a.silu) v = v * sigmoid_t<T>(v);
+                y[ni * 4 + r] = v;
+            }
+        const size_t o = (size_t)m * N + nl;
+        if (res) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                if (nl + ni * 4 < N) {
+                    float rv[4];
+                    load4(res + o + ni * 4, rv);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[ni * 4 + r] += rv[r];
+                }
+        }
+        if constexpr (sizeof(T) == 2 && NI % 2 == 0) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ni += 2)
+                if (nl + ni * 4 < N) store8(out + o + ni * 4, y + ni * 4);
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                if (nl + ni * 4 < N) store4(out + o + ni * 4, y + ni * 4);
+        }
+    }
+}
+
+template <typename T, int NI, int WN, bool GATE>
+static int launch_pw_dma_cfg(const PwKArgs& k, int grid, hipStream_t s) {
+    constexpr int NS = 3, WM = 4 / WN, NB = 64 * WM / 16 + NI * WN;
+    const size_t lds = (size_t)NS * NB * 1024 + 1024 + (GATE ? (size_t)2 * k.nkb_total * DT<T>::KB * 4 : 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        COSY_CHECK_HIP(hipFuncSetAttribute((const void*)pw_gemm_dma_kernel<T, NI, WN, NS, GATE>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((pw_gemm_dma_kernel<T, NI, WN, NS, GATE>), dim3(grid), dim3(256), lds, s, k);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+template <typename T, bool GATE>
+static int launch_pw_dma(const PwKArgs& k, PwCfg c, int grid, hipStream_t s) {
+    if (c.NI == 4 && c.WN == 2) return launch_pw_dma_cfg<T, 4, 2, GATE>(k, grid, s);
+    if (c.NI == 3 && c.WN == 2) return launch_pw_dma_cfg<T, 3, 2, GATE>(k, grid, s);
+    if (c.NI == 3 && c.WN == 1) return launch_pw_dma_cfg<T, 3, 1, GATE>(k, grid, s);
+    if (c.NI == 2 && c.WN == 1) return launch_pw_dma_cfg<T, 2, 1, GATE>(k, grid, s);
+    set_error("pw_gemm_dma: unsupported tile config NI=%d WN=%d", c.NI, c.WN);
+    return COSY_EINVAL;
+}
+
 template <typename T>
 static int launch_pw_t(const PwArgs& a, PwCfg c, int dtype, hipStream_t s) {
     PwKArgs k;
@@ -281,6 +462,12 @@ static int launch_pw_t(const PwArgs& a, PwCfg c, int dtype, hipStream_t s) {
     k.MT = cdiv(a.M, pw_bm(c)); k.NT = cdiv(a.N, pw_bn(c));
     k.nkb_total = pw_nkb_total(a.K, dtype); k.nkb_valid = cdiv(a.K, pw_kb(dtype));
     const int grid = cdiv(k.MT, 8) * 8 * k.NT;
+    k.zeros = a.zeros;
+    static const int use_dma = getenv("COSY_PW_DMA") ? atoi(getenv("COSY_PW_DMA")) : 1;
+    if (use_dma && a.zeros) {
+        if (!a.gate) return launch_pw_dma<T, false>(k, c, grid, s);
+        if (a.HW % 64 == 0) return launch_pw_dma<T, true>(k, c, grid, s);
+    }
     if (c.NI == 4 && c.WN == 2) hipLaunchKernelGGL((pw_gemm_kernel<T, 4, 2>), dim3(grid), dim3(256), 0, s, k);
     else if (c.NI == 3 && c.WN == 2) hipLaunchKernelGGL((pw_gemm_kernel<T, 3, 2>), dim3(grid), dim3(256), 0, s, k);
     else if (c.NI == 3 && c.WN == 1) hipLaunchKernelGGL((pw_gemm_kernel<T, 3, 1>), dim3(grid), dim3(256), 0, s, k);
