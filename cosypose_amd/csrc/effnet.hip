@@ -66,7 +66,8 @@ struct Block {
 
 struct cosy_net {
     int dtype, H, W, maxB, esz, Hs, Ws, Hf, Wf;
-    float *stem_w, *stem_scale, *stem_bias, *fc_w, *fc_b;
+    void* stem_w;
+    float *stem_scale, *stem_bias, *fc_w, *fc_b;
     cosy::Block blk[26];
     cosy::PwLayer head;
     void *X, *act[2], *E, *D, *Hd, *actc[2], *Ec, *Dc;
@@ -122,17 +123,21 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         } else { sc.assign(npad, 0.f); bi.assign(npad, 0.f); }
         L.scale = up_f32(sc); L.bias = up_f32(bi);
     };
-    // stem: (40,6,3,3) -> [ky][kx][ci][co]
+    // stem: (40,6,3,3) -> MFMA fragment blocks (implicit GEMM, K = 9 taps x 8 channels)
     {
-        std::vector<float> w(9 * IN_C * STEM_C), sc, bi;
-        if (fill)
-            for (int co = 0; co < STEM_C; ++co)
-                for (int ci = 0; ci < IN_C; ++ci)
-                    for (int t = 0; t < 9; ++t) w[(t * IN_C + ci) * STEM_C + co] = p[(co * IN_C + ci) * 9 + t];
+        const size_t ne = stem_packed_elems(n->dtype);
+        n->stem_w = bump.take(ne * n->esz);
+        std::vector<float> sc, bi;
+        if (fill) {
+            std::vector<char> tmp(ne * n->esz);
+            stem_pack_weights(p, n->dtype, tmp.data());
+            hipError_t e2 = hipMemcpy(n->stem_w, tmp.data(), tmp.size(), hipMemcpyHostToDevice);
+            if (e2 != hipSuccess) *herr = e2;
+        }
         p += STEM_C * IN_C * 9;
         if (fill) fold_bn(p, STEM_C, STEM_C, sc, bi); else { sc.assign(STEM_C, 0.f); bi.assign(STEM_C, 0.f); }
         p += 4 * STEM_C;
-        n->stem_w = up_f32(w); n->stem_scale = up_f32(sc); n->stem_bias = up_f32(bi);
+        n->stem_scale = up_f32(sc); n->stem_bias = up_f32(bi);
     }
     int h = n->Hs, w_ = n->Ws;
     for (int i = 0; i < 26; ++i) {

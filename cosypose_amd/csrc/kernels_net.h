@@ -69,7 +69,9 @@ struct SeArgs {
 };
 int launch_se(const SeArgs& a, hipStream_t s);
 
-int launch_stem(const void* x_nhwc8, const float* w /*[3][3][6][40]*/, const float* scale, const float* bias, void* out,
+size_t stem_packed_elems(int dtype);
+void stem_pack_weights(const float* w_oihw /*(40,6,3,3)*/, int dtype, void* dst);
+int launch_stem(const void* x_nhwc8, const void* w_packed, const float* scale, const float* bias, void* out,
                 int B, int H, int W, int Ho, int Wo, int dtype, hipStream_t s);
 int launch_pool_fc(const void* head /*(B,HW,1536)*/, const float* fc_w /*(9,1536)*/, const float* fc_b, float* feat_or_null,
                    float* feat_scratch, float* pose, int B, int HW, int dtype, hipStream_t s);

@@ -1001,58 +1001,108 @@ int launch_se(const SeArgs& a, hipStream_t s) {
 }
 
 // ==========================================================================================
-// stem: 3x3 stride 2, 6 -> 40, static pad (lo 0, hi 1), BN + SiLU.  One thread per output pixel;
-// weights are wave-uniform (scalar loads), input pixel is one 16/32-byte NHWC8 vector per tap.
+// stem: 3x3 stride 2, 6 -> 40, static pad (lo 0, hi 1), BN + SiLU -- as an implicit GEMM on the matrix cores.
+// K = 9 taps x 8 (NHWC8-padded) input channels = 72 -> 3 k-blocks of 32 (taps 9..11 are zero); the B-operand
+// fragment of lane (pixel j, k-group kg) in k-block kb is exactly ONE 16-byte NHWC8 input pixel (tap 4*kb+kg), loaded
+// straight from global memory: no LDS, no im2col.  Weights (40 -> 48 rows) are the A operand, so a lane ends up
+// with 12 consecutive output channels of its pixel (80-byte NHWC rows are written completely by the 4 k-groups).
+// For fp32 the same scheme runs with 16-deep k-blocks (2 taps each) on v_mfma_f32_16x16x4_f32.
 // ==========================================================================================
+static constexpr int STEM_G = 4;   // 16-pixel groups per wave
+size_t stem_packed_elems(int dtype) { return (size_t)3 * (dtype == COSY_F32 ? 6 : 3) * 64 * (dtype == COSY_F32 ? 4 : 8); }
+// w: reference layout (40, 6, 3, 3) -> fragment blocks [ni 0..2][kb][lane][EPL], rows permuted so lane (i>>2 = kg') holds
+// channels kg'*12 + ni*4 + (i&3)
+void stem_pack_weights(const float* w, int dtype, void* dst) {
+    const int epl = dtype == COSY_F32 ? 4 : 8, kb_n = dtype == COSY_F32 ? 6 : 3, kdepth = dtype == COSY_F32 ? 16 : 32;
+    size_t idx = 0;
+    for (int ni = 0; ni < 3; ++ni)
+        for (int kb = 0; kb < kb_n; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < epl; ++e, ++idx) {
+                    const int i = lane & 15, kg = lane >> 4;
+                    const int n = (i >> 2) * 12 + ni * 4 + (i & 3);
+                    const int k = kb * kdepth + kg * epl + e;      // k = tap*8 + ci
+                    const int tap = k / 8, ci = k % 8;
+                    const float v = (n < 40 && tap < 9 && ci < 6) ? w[((size_t)n * 6 + ci) * 9 + tap] : 0.f;
+                    if (dtype == COSY_F32) ((float*)dst)[idx] = v; else ((uint16_t*)dst)[idx] = f32_to_bf16_host(v);
+                }
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void stem_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
-                                                   const float* __restrict__ bias, T* __restrict__ out, int H, int W, int Ho, int Wo) {
-    const int b = blockIdx.y, pix = blockIdx.x * 256 + threadIdx.x;
-    if (pix >= Ho * Wo) return;
-    const int oy = pix / Wo, ox = pix % Wo;
-    float acc[40];
+__global__ __launch_bounds__(256) void stem_kernel(const T* __restrict__ x, const T* __restrict__ wp, const float* __restrict__ scale,
+                                                   const float* __restrict__ bias, T* __restrict__ out, int H, int W, int Ho, int Wo,
+                                                   long n_groups) {
+    using raw_t = typename DT<T>::raw_t;
+    constexpr int EPL = DT<T>::EPL;
+    constexpr int KBN = sizeof(T) == 2 ? 3 : 6;          // k-blocks
+    constexpr int TPB = sizeof(T) == 2 ? 4 : 2;          // taps per k-block
+    constexpr int LPT = 16 / (int)sizeof(T) == 8 ? 1 : 2;  // 16-byte loads per tap (NHWC8 pixel = 16 B bf16 / 32 B fp32)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kg = lane >> 4;
+    raw_t wf[3][KBN];
 #pragma unroll
-    for (int c = 0; c < 40; ++c) acc[c] = 0.f;
-    const T* xb = x + (size_t)b * H * W * 8;
+    for (int ni = 0; ni < 3; ++ni)
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy * 2 + ky;
-        if (iy >= H) continue;
+        for (int kb = 0; kb < KBN; ++kb) wf[ni][kb] = *(const raw_t*)(wp + ((size_t)(ni * KBN + kb) * 64 + lane) * EPL);
+    const int n0 = kg * 12;
+    float sc[12], bi[12];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox * 2 + kx;
-            float v[8];
-            if (ix < W) load8(xb + ((size_t)iy * W + ix) * 8, v);
-            else {
+    for (int q = 0; q < 12; ++q) { sc[q] = n0 + q < 40 ? scale[n0 + q] : 0.f; bi[q] = n0 + q < 40 ? bias[n0 + q] : 0.f; }
+    const long g0 = ((long)blockIdx.x * 4 + wave) * STEM_G;
+#pragma unroll 1
+    for (int gi = 0; gi < STEM_G; ++gi) {
+        const long g = g0 + gi;
+        if (g >= n_groups) break;
+        const long pix = g * 16 + j;                 // linear output pixel over (b, oy, ox); Ho*Wo is a multiple of 16
+        const int ox = (int)(pix % Wo);
+        const long t2 = pix / Wo;
+        const int oy = (int)(t2 % Ho), b = (int)(t2 / Ho);
+        const T* xb = x + (size_t)b * H * W * 8;
+        f32x4 acc[3];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = 0.f;
+        for (int ni = 0; ni < 3; ++ni) acc[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KBN; ++kb) {
+            // this lane's k-range inside the block: kg*EPL .. +EPL  ->  tap and channel offset
+            const int kk = kg * EPL;                      // 0..31 (bf16) / 0..15 (fp32)
+            const int tap = kb * TPB + kk / 8, ci0 = kk % 8;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int iy = oy * 2 + ky, ix = ox * 2 + kx;
+            raw_t xf;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) xf[e] = 0;
+            if (tap < 9 && iy < H && ix < W) xf = *(const raw_t*)(xb + ((size_t)iy * W + ix) * 8 + ci0);
+#pragma unroll
+            for (int ni = 0; ni < 3; ++ni) mma(acc[ni], wf[ni][kb], xf);
+        }
+        (void)LPT;
+        float y[12];
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[ni][r] * sc[ni * 4 + r] + bi[ni * 4 + r];
+                y[ni * 4 + r] = v * sigmoid_t<T>(v);
             }
-#pragma unroll
-            for (int ci = 0; ci < 6; ++ci)
-#pragma unroll
-                for (int co = 0; co < 40; ++co) acc[co] += w[((ky * 3 + kx) * 6 + ci) * 40 + co] * v[ci];
+        T* o = out + (size_t)pix * 40 + n0;
+        if (kg < 3) {
+            if constexpr (sizeof(T) == 2) { store8(o, y); store4(o + 8, y + 8); }
+            else { store4(o, y); store4(o + 4, y + 4); store4(o + 8, y + 8); }
+        } else {
+            store4(o, y);                                 // channels 36..39
         }
-    }
-    T* o = out + ((size_t)b * Ho * Wo + pix) * 40;
-#pragma unroll
-    for (int g = 0; g < 5; ++g) {
-        float y[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            float v = acc[g * 8 + c] * scale[g * 8 + c] + bias[g * 8 + c];
-            y[c] = v * sigmoid_t<T>(v);
-        }
-        store8(o + g * 8, y);
     }
 }
-int launch_stem(const void* x, const float* w, const float* scale, const float* bias, void* out, int B, int H, int W, int Ho,
+int launch_stem(const void* x, const void* wp, const float* scale, const float* bias, void* out, int B, int H, int W, int Ho,
                 int Wo, int dtype, hipStream_t s) {
     if (B == 0) return COSY_OK;
-    dim3 grid(cdiv(Ho * Wo, 256), B);
+    COSY_REQUIRE((Ho * Wo) % 16 == 0, "stem: Ho*Wo=%d must be a multiple of 16", Ho * Wo);
+    const long n_groups = (long)B * Ho * Wo / 16;
+    dim3 grid((unsigned)cdiv(n_groups, 4 * STEM_G));
     if (dtype == COSY_F32)
-        hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, s, (const float*)x, w, scale, bias, (float*)out, H, W, Ho, Wo);
+        hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)wp, scale, bias, (float*)out, H, W, Ho, Wo, n_groups);
     else
-        hipLaunchKernelGGL(stem_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, w, scale, bias, (bf16_t*)out, H, W, Ho, Wo);
+        hipLaunchKernelGGL(stem_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)wp, scale, bias, (bf16_t*)out, H, W, Ho, Wo, n_groups);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }
