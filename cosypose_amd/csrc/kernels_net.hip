@@ -932,70 +932,95 @@ int launch_mbconv_front(const FuseArgs& a, int dtype, hipStream_t s) {
 // FC(Cse->C)+b -> sigmoid.  One 512-thread workgroup per sample; the pooling is spread over
 // (channel, tile-group) threads and finished by a fixed-order LDS reduction (deterministic).
 // ==========================================================================================
+// One 512-thread workgroup per sample (measured: batching 4 samples per workgroup to share the weight reads is
+// slower -- the kernel is bound by the length of its dependent chains, not by L2 bandwidth).
 __global__ __launch_bounds__(512) void se_kernel(SeArgs a) {
-    extern __shared__ float sm[];
-    const int C = a.C;
-    float* pooled = sm;              // C
-    float* redv = sm + C;            // Cse
-    float* scratch = sm + C + a.Cse; // 512
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int C = a.C, C4 = C >> 2;       // C is a multiple of 8: everything moves as float4
+    float* pooled = sm;                   // C
+    float* redv = sm + C;                 // Cse (padded to 4)
+    float* scratch = redv + ((a.Cse + 3) & ~3);  // 512 * 4
+    const int b = blockIdx.x, tid = threadIdx.x;
     const float inv = 1.f / (float)a.HW;
-    const float* part = a.partial + (size_t)b * a.n_tiles * C;
-    if (C >= 512 || a.n_tiles == 1) {
-        for (int c = tid; c < C; c += 512) {
-            float s0 = 0.f, s1 = 0.f;
+    const f32x4* part = (const f32x4*)(a.partial + (size_t)b * a.n_tiles * C);
+    // ---- pooling: sum the per-tile partial sums (fixed order -> deterministic)
+    if (C4 >= 512 || a.n_tiles == 1) {
+        for (int c = tid; c < C4; c += 512) {
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
             int t = 0;
-            for (; t + 1 < a.n_tiles; t += 2) { s0 += part[(size_t)t * C + c]; s1 += part[(size_t)(t + 1) * C + c]; }
-            if (t < a.n_tiles) s0 += part[(size_t)t * C + c];
-            pooled[c] = (s0 + s1) * inv;
+            for (; t + 1 < a.n_tiles; t += 2) { s0 += part[(size_t)t * C4 + c]; s1 += part[(size_t)(t + 1) * C4 + c]; }
+            if (t < a.n_tiles) s0 += part[(size_t)t * C4 + c];
+            ((f32x4*)pooled)[c] = (s0 + s1) * inv;
         }
     } else {
-        const int G = 512 / C;  // tile groups
-        const int c = tid % C, g = tid / C;
-        float s = 0.f;
+        const int G = 512 / C4;  // tile groups
+        const int c = tid % C4, g = tid / C4;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
         if (g < G)
-            for (int t = g; t < a.n_tiles; t += G) s += part[(size_t)t * C + c];
-        scratch[tid] = s;
+            for (int t = g; t < a.n_tiles; t += 8 * G) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = t + u * G < a.n_tiles ? part[(size_t)(t + u * G) * C4 + c] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+        ((f32x4*)scratch)[tid] = s;
         __syncthreads();
-        if (tid < C) {
-            float r = 0.f;
-            for (int gg = 0; gg < G; ++gg) r += scratch[gg * C + tid];
-            pooled[tid] = r * inv;
+        if (tid < C4) {
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+            for (int gg = 0; gg < G; ++gg) r += ((const f32x4*)scratch)[gg * C4 + tid];
+            ((f32x4*)pooled)[tid] = r * inv;
         }
     }
     __syncthreads();
-    for (int j = wave; j < a.Cse; j += 8) {
-        const float* wr = a.w_red + (size_t)j * C;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int c = lane;
-        for (; c + 192 < C; c += 256) {
-            s0 += wr[c] * pooled[c]; s1 += wr[c + 64] * pooled[c + 64];
-            s2 += wr[c + 128] * pooled[c + 128]; s3 += wr[c + 192] * pooled[c + 192];
+    // ---- reduce FC + swish: thread (j = t/8, part = t%8) accumulates the float4 chunks part, part+8, ... of row j:
+    // every load is independent (deep memory pipeline), 8 lanes then combine with 3 shuffles.
+    for (int j0 = 0; j0 < a.Cse; j0 += 64) {
+        const int j = j0 + (tid >> 3), prt = tid & 7;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (j < a.Cse) {
+            const f32x4* wr = (const f32x4*)(a.w_red + (size_t)j * C);
+            for (int c = prt; c < C4; c += 64) {       // 8 independent 16-byte loads in flight, then the FMAs
+                f32x4 w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] = c + 8 * u < C4 ? wr[c + 8 * u] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (c + 8 * u < C4) acc += w[u] * ((const f32x4*)pooled)[c + 8 * u];
+            }
         }
-        for (; c < C; c += 64) s0 += wr[c] * pooled[c];
-        float s = (s0 + s1) + (s2 + s3);
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (lane == 0) {
+        float s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        if (prt == 0 && j < a.Cse) {
             s += a.b_red[j];
             redv[j] = s * (1.f / (1.f + expf(-s)));
         }
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 512) {
-        float s0 = 0.f, s1 = 0.f;
-        int j = 0;
-        for (; j + 1 < a.Cse; j += 2) {  // w_exp stored (Cse, C)
-            s0 += a.w_exp[(size_t)j * C + c] * redv[j];
-            s1 += a.w_exp[(size_t)(j + 1) * C + c] * redv[j + 1];
+    // ---- expand FC + sigmoid: a thread owns 4 consecutive channels (w_exp stored (Cse, C))
+    for (int c = tid; c < C4; c += 512) {
+        const f32x4* we = (const f32x4*)a.w_exp + c;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        for (int j = 0; j < a.Cse; j += 8) {           // 8 independent loads per batch
+            f32x4 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = j + u < a.Cse ? we[(size_t)(j + u) * C4] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                if (j + u < a.Cse) s0 += w[u] * redv[j + u];
+                if (j + u + 1 < a.Cse) s1 += w[u + 1] * redv[j + u + 1];
+            }
         }
-        if (j < a.Cse) s0 += a.w_exp[(size_t)j * C + c] * redv[j];
-        const float s = s0 + s1 + a.b_exp[c];
-        a.gate[(size_t)b * C + c] = 1.f / (1.f + expf(-s));
+        const f32x4 be = ((const f32x4*)a.b_exp)[c];
+        f32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = 1.f / (1.f + expf(-(s0[e] + s1[e] + be[e])));
+        ((f32x4*)(a.gate + (size_t)b * C))[c] = g;
     }
 }
 int launch_se(const SeArgs& a, hipStream_t s) {
     if (a.B == 0) return COSY_OK;
-    hipLaunchKernelGGL(se_kernel, dim3(a.B), dim3(512), (a.C + a.Cse + 512) * sizeof(float), s, a);
+    hipLaunchKernelGGL(se_kernel, dim3(a.B), dim3(512), (a.C + ((a.Cse + 3) & ~3) + 2048) * sizeof(float), s, a);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }
