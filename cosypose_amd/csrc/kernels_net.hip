@@ -430,9 +430,9 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwKArgs a) {
     }
 }
 
-template <typename T, int NI, int WN, bool GATE>
-static int launch_pw_dma_cfg(const PwKArgs& k, int grid, hipStream_t s) {
-    constexpr int NS = 3, WM = 4 / WN, NB = 64 * WM / 16 + NI * WN;
+template <typename T, int NI, int WN, bool GATE, int NS>
+static int launch_pw_dma_ns(const PwKArgs& k, int grid, hipStream_t s) {
+    constexpr int WM = 4 / WN, NB = 64 * WM / 16 + NI * WN;
     const size_t lds = (size_t)NS * NB * 1024 + 1024 + (GATE ? (size_t)2 * k.nkb_total * DT<T>::KB * 4 : 0);
     static bool attr_set = false;
     if (!attr_set) {
@@ -443,6 +443,13 @@ static int launch_pw_dma_cfg(const PwKArgs& k, int grid, hipStream_t s) {
     hipLaunchKernelGGL((pw_gemm_dma_kernel<T, NI, WN, NS, GATE>), dim3(grid), dim3(256), lds, s, k);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
+}
+template <typename T, int NI, int WN, bool GATE>
+static int launch_pw_dma_cfg(const PwKArgs& k, int grid, hipStream_t s) {
+    // short k-loops (<= 2 k-blocks: the streaming 1x1 convs of the high-resolution blocks) need no deep ring:
+    // 2 stages keep the LDS footprint small so that more workgroups are resident per CU
+    if (k.nkb_valid <= 2) return launch_pw_dma_ns<T, NI, WN, GATE, 2>(k, grid, s);
+    return launch_pw_dma_ns<T, NI, WN, GATE, 3>(k, grid, s);
 }
 template <typename T, bool GATE>
 static int launch_pw_dma(const PwKArgs& k, PwCfg c, int grid, hipStream_t s) {
