@@ -714,19 +714,22 @@ int launch_dwconv(const DwArgs& a, int dtype, hipStream_t s) {
 //   3. depthwise from Et exactly as dwconv_kernel (sliding window over rows), BN+SiLU, NHWC store, squeeze sums.
 // Cost: the expansion is recomputed on the halo (x1.2-1.4), on MFMA units that are otherwise idle here.
 // ==========================================================================================
-struct FusePlan { int TH, TW, THin, TWin, MB, kbn, threads, ntx, nty; size_t lds; };
+struct FusePlan { int TH, TW, THin, TWin, MB, kbn, threads, ntx, nty, et_f32; size_t lds; };
+static int fuse_et_f32() { static const int v = getenv("COSY_FUSE_ET32") ? atoi(getenv("COSY_FUSE_ET32")) : 1; return v; }
 static FusePlan fuse_plan(int Cin, int Ho, int Wo, int k, int s, int esz) {
     FusePlan p;
     const int R = s == 1 ? 4 : 2;
+    p.et_f32 = esz == 4 ? 1 : fuse_et_f32();       // element type of the LDS tile that holds the expanded activations
+    const int ees = p.et_f32 ? 4 : 2;
     if (s == 1) { p.TH = esz == 2 ? 8 : 4; p.TW = 16; }
     else { p.TH = 4; p.TW = 8; }
     if (p.TW > Wo) p.TW = Wo;
     p.THin = (p.TH - 1) * s + k; p.TWin = (p.TW - 1) * s + k;
     p.MB = (p.THin * p.TWin + 15) / 16;
     p.kbn = cdiv(Cin, esz == 2 ? 32 : 16);
-    const int cpt = 16 / esz, units = (48 / cpt) * p.TW * (p.TH / R);
+    const int cpt = 16 / ees, units = (48 / cpt) * p.TW * (p.TH / R);
     p.threads = ((units < 384 ? units : 384) + 63) / 64 * 64;
-    p.lds = (size_t)p.MB * p.kbn * 1024 + (size_t)p.MB * 16 * (48 * esz + 16) + (size_t)k * k * 48 * 4 + (size_t)p.threads * 8 * 4;
+    p.lds = (size_t)p.MB * p.kbn * 1024 + (size_t)p.MB * 16 * (48 * ees + 16) + (size_t)k * k * 48 * 4 + (size_t)p.threads * 8 * 4;
     p.ntx = cdiv(Wo, p.TW); p.nty = cdiv(Ho, p.TH);
     return p;
 }
@@ -742,22 +745,24 @@ bool fuse_supported(int Cin, int Cmid, int k, int s, int dtype) {
 struct FuseKArgs {
     const void* X; const void* Wp; const float* s0; const float* b0; const float* dww; const float* s1; const float* b1;
     void* D; float* partial; const void* zeros;
-    int H, W, Cin, Cmid, Ho, Wo, lo, TH, TW, THin, TWin, MB, kbn, ntx, n_tiles, nkb_total;
+    int H, W, Cin, Cmid, Ho, Wo, lo, TH, TW, THin, TWin, MB, ntx, n_tiles, nkb_total;
+    unsigned rcp_tw;   // ceil(2^16 / TWin): p / TWin == (p * rcp_tw) >> 16 for the tile's pixel range (checked on the host)
 };
 
-template <typename T, int KS, int S, int R>
+// T = storage type of X/D (and of the MFMA operands), ET = element type of the LDS tile of expanded activations
+template <typename T, typename ET, int KS, int S, int R, int KBN>
 __global__ __launch_bounds__(384) void mbconv_front_kernel(FuseKArgs a) {
     using raw_t = typename DT<T>::raw_t;
     constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
     constexpr int NI = 3, CC = 48;
-    constexpr int PITCH = CC * (int)sizeof(T) + 16;  // bytes per Et pixel row
-    constexpr int CPT = 16 / (int)sizeof(T);         // channels per depthwise thread (one 16-byte Et read)
-    constexpr int NG = CC / CPT;                     // channel groups per chunk
+    constexpr int PITCH = CC * (int)sizeof(ET) + 16;  // bytes per Et pixel row (+16: conflict-free 16-byte writes)
+    constexpr int CPT = 16 / (int)sizeof(ET);         // channels per depthwise thread (one 16-byte Et read)
+    constexpr int NG = CC / CPT;                      // channel groups per chunk
     constexpr int NROW = (R - 1) * S + KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int TWin = a.TWin, Pin = a.THin * a.TWin, MB = a.MB, kbn = a.kbn;
+    const int TWin = a.TWin, Pin = a.THin * a.TWin, MB = a.MB;
     char* Xt = smem;
-    char* Et = Xt + (size_t)MB * kbn * 1024;
+    char* Et = Xt + (size_t)MB * KBN * 1024;
     float* wl = (float*)(Et + (size_t)MB * 16 * PITCH);
     float* red = wl + KS * KS * CC;
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
@@ -771,10 +776,10 @@ __global__ __launch_bounds__(384) void mbconv_front_kernel(FuseKArgs a) {
     // ---- 1. DMA the input tile into LDS in fragment order
     {
         const T* __restrict__ X = (const T*)a.X + (size_t)b * a.H * a.W * a.Cin;
-        for (int blk = wave; blk < MB * kbn; blk += nwaves) {
-            const int mb = blk / kbn, kb = blk - mb * kbn;
+        for (int blk = wave; blk < MB * KBN; blk += nwaves) {
+            const int mb = blk / KBN, kb = blk - mb * KBN;
             const int p = mb * 16 + prow, k = kb * KB + kg * EPL;
-            const int yy = p / TWin, xx = p - yy * TWin, iy = iy0 + yy, ix = ix0 + xx;
+            const int yy = (int)(((unsigned)p * a.rcp_tw) >> 16), xx = p - yy * TWin, iy = iy0 + yy, ix = ix0 + xx;
             const bool ok = p < Pin && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && k < a.Cin;
             const void* src = ok ? (const void*)(X + ((size_t)iy * a.W + ix) * a.Cin + k) : a.zeros;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -797,12 +802,12 @@ __global__ __launch_bounds__(384) void mbconv_front_kernel(FuseKArgs a) {
         }
         // ---- 2. expansion on the matrix cores -> Et
         {
-            raw_t wf[NI][2];
+            raw_t wf[NI][KBN];
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-                    if (kb < kbn) wf[ni][kb] = *(const raw_t*)((const T*)a.Wp + ((size_t)(ch * NI + ni) * a.nkb_total + kb) * 64 * EPL + lane * EPL);
+                for (int kb = 0; kb < KBN; ++kb)
+                    wf[ni][kb] = *(const raw_t*)((const T*)a.Wp + ((size_t)(ch * NI + ni) * a.nkb_total + kb) * 64 * EPL + lane * EPL);
             const int n0 = ch * CC + kg * 4 * NI;   // this lane's 12 consecutive expanded channels
             float sc[NI * 4], bi[NI * 4];
 #pragma unroll
@@ -812,14 +817,13 @@ __global__ __launch_bounds__(384) void mbconv_front_kernel(FuseKArgs a) {
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-                    if (kb < kbn) {
-                        const raw_t xf = *(const raw_t*)(Xt + (size_t)(mb * kbn + kb) * 1024 + lane * 16);
+                for (int kb = 0; kb < KBN; ++kb) {
+                    const raw_t xf = *(const raw_t*)(Xt + (size_t)(mb * KBN + kb) * 1024 + lane * 16);
 #pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) mma(acc[ni], wf[ni][kb], xf);
-                    }
+                    for (int ni = 0; ni < NI; ++ni) mma(acc[ni], wf[ni][kb], xf);
+                }
                 const int p = mb * 16 + prow;
-                const int yy = p / TWin, xx = p - yy * TWin, iy = iy0 + yy, ix = ix0 + xx;
+                const int yy = (int)(((unsigned)p * a.rcp_tw) >> 16), xx = p - yy * TWin, iy = iy0 + yy, ix = ix0 + xx;
                 const bool inside = p < Pin && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
                 float y[NI * 4];
 #pragma unroll
@@ -830,8 +834,8 @@ __global__ __launch_bounds__(384) void mbconv_front_kernel(FuseKArgs a) {
                         v = v * sigmoid_t<T>(v);
                         y[ni * 4 + r] = inside ? v : 0.f;
                     }
-                T* dst = (T*)(Et + (size_t)p * PITCH) + kg * 4 * NI;
-                if constexpr (sizeof(T) == 2) { store8(dst, y); store4(dst + 8, y + 8); }
+                ET* dst = (ET*)(Et + (size_t)p * PITCH) + kg * 4 * NI;
+                if constexpr (sizeof(ET) == 2) { store8(dst, y); store4(dst + 8, y + 8); }
                 else { store4(dst, y); store4(dst + 4, y + 4); store4(dst + 8, y + 8); }
             }
         }
@@ -867,7 +871,7 @@ __global__ __launch_bounds__(384) void mbconv_front_kernel(FuseKArgs a) {
 #pragma unroll
                     for (int rr = 0; rr < NROW; ++rr) {
                         float v[CPT];
-                        if constexpr (sizeof(T) == 2) lds_ld8((const bf16_t*)(col + (size_t)rr * TWin * PITCH), v);
+                        if constexpr (sizeof(ET) == 2) lds_ld8((const bf16_t*)(col + (size_t)rr * TWin * PITCH), v);
                         else load4((const float*)(col + (size_t)rr * TWin * PITCH), v);
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
@@ -892,7 +896,7 @@ __global__ __launch_bounds__(384) void mbconv_front_kernel(FuseKArgs a) {
                             sum[c] += v;
                         }
                         T* o = out + ((size_t)oy * a.Wo + ox) * a.Cmid;
-                        if constexpr (sizeof(T) == 2) store8(o, y); else store4(o, y);
+                        if constexpr (CPT == 8) store8(o, y); else store4(o, y);
                     }
                 }
             }
@@ -911,22 +915,30 @@ __global__ __launch_bounds__(384) void mbconv_front_kernel(FuseKArgs a) {
     }
 }
 
+template <typename T, typename ET, int KBN>
+static int launch_fuse_k(const FuseArgs& a, const FusePlan& p, const FuseKArgs& k, hipStream_t s) {
+    dim3 grid((unsigned)(k.n_tiles * a.B)), block(p.threads);
+    if (a.k == 3 && a.s == 1) hipLaunchKernelGGL((mbconv_front_kernel<T, ET, 3, 1, 4, KBN>), grid, block, p.lds, s, k);
+    else if (a.k == 3 && a.s == 2) hipLaunchKernelGGL((mbconv_front_kernel<T, ET, 3, 2, 2, KBN>), grid, block, p.lds, s, k);
+    else if (a.k == 5 && a.s == 1) hipLaunchKernelGGL((mbconv_front_kernel<T, ET, 5, 1, 4, KBN>), grid, block, p.lds, s, k);
+    else if (a.k == 5 && a.s == 2) hipLaunchKernelGGL((mbconv_front_kernel<T, ET, 5, 2, 2, KBN>), grid, block, p.lds, s, k);
+    else { set_error("mbconv_front: unsupported k=%d s=%d", a.k, a.s); return COSY_EINVAL; }
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
 template <typename T>
 static int launch_fuse_t(const FuseArgs& a, hipStream_t s) {
     const FusePlan p = fuse_plan(a.Cin, a.Ho, a.Wo, a.k, a.s, sizeof(T));
     FuseKArgs k;
     k.X = a.X; k.Wp = a.Wp; k.s0 = a.s0; k.b0 = a.b0; k.dww = a.dww; k.s1 = a.s1; k.b1 = a.b1; k.D = a.D; k.partial = a.partial;
     k.zeros = a.zeros; k.H = a.H; k.W = a.W; k.Cin = a.Cin; k.Cmid = a.Cmid; k.Ho = a.Ho; k.Wo = a.Wo; k.lo = a.pad_lo;
-    k.TH = p.TH; k.TW = p.TW; k.THin = p.THin; k.TWin = p.TWin; k.MB = p.MB; k.kbn = p.kbn; k.ntx = p.ntx; k.n_tiles = p.ntx * p.nty;
+    k.TH = p.TH; k.TW = p.TW; k.THin = p.THin; k.TWin = p.TWin; k.MB = p.MB; k.ntx = p.ntx; k.n_tiles = p.ntx * p.nty;
     k.nkb_total = pw_nkb_total(a.Cin, sizeof(T) == 4 ? COSY_F32 : COSY_BF16);
-    dim3 grid((unsigned)(k.n_tiles * a.B)), block(p.threads);
-    if (a.k == 3 && a.s == 1) hipLaunchKernelGGL((mbconv_front_kernel<T, 3, 1, 4>), grid, block, p.lds, s, k);
-    else if (a.k == 3 && a.s == 2) hipLaunchKernelGGL((mbconv_front_kernel<T, 3, 2, 2>), grid, block, p.lds, s, k);
-    else if (a.k == 5 && a.s == 1) hipLaunchKernelGGL((mbconv_front_kernel<T, 5, 1, 4>), grid, block, p.lds, s, k);
-    else if (a.k == 5 && a.s == 2) hipLaunchKernelGGL((mbconv_front_kernel<T, 5, 2, 2>), grid, block, p.lds, s, k);
-    else { set_error("mbconv_front: unsupported k=%d s=%d", a.k, a.s); return COSY_EINVAL; }
-    COSY_CHECK_HIP(hipGetLastError());
-    return COSY_OK;
+    k.rcp_tw = (65536u + p.TWin - 1) / p.TWin;
+    for (int q = 0; q < p.MB * 16; ++q)
+        if ((int)(((unsigned)q * k.rcp_tw) >> 16) != q / p.TWin) { set_error("mbconv_front: reciprocal division inexact"); return COSY_EINVAL; }
+    if (p.kbn == 1) return p.et_f32 ? launch_fuse_k<T, float, 1>(a, p, k, s) : launch_fuse_k<T, T, 1>(a, p, k, s);
+    return p.et_f32 ? launch_fuse_k<T, float, 2>(a, p, k, s) : launch_fuse_k<T, T, 2>(a, p, k, s);
 }
 int launch_mbconv_front(const FuseArgs& a, int dtype, hipStream_t s) {
     if (a.B == 0) return COSY_OK;
