@@ -25,8 +25,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
-MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}
-ALGO_MB_PER_POSE_ITER = {('bf16', 256): 10.7, ('fp32', 256): 21.3, ('bf16', 240): 12.4, ('fp32', 240): 24.9}
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0, 'fp32': 157.3}
+ALGO_MB_PER_POSE_ITER = {('bf16', 256): 10.7, ('fp16', 256): 10.7, ('fp32', 256): 21.3, ('bf16', 240): 12.4, ('fp16', 240): 12.4, ('fp32', 240): 24.9}
 
 
 class SyntheticRenderer:
@@ -93,7 +93,7 @@ def main():
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--crop', default='256x256', help='HxW of the crops: 256x256 (metric) or 240x320 (reference native)')
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
     ap.add_argument('--detections', type=int, default=256, help='detections per GPU per step')
     ap.add_argument('--bsz-objects', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -211,7 +211,13 @@ def main():
             ach = k['flops'] / k['ms'] / 1e9
             roofline = dict(bound='mfma', achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS[args.dtype], unit='TFLOP/s',
                             frac=round(ach / MFMA_PEAK_TFLOPS[args.dtype], 4))
-        roofline.update(traffic=None, kernel=name, launches_timed=k['n'], avg_launch_us=round(k['ms'] / k['n'] * 1e3, 2),
+        traffic = None   # HBM bytes per launch from the committed PMC passes of the same command (profiles/collect.sh)
+        tfile = os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')
+        if os.path.exists(tfile) and args.crop == '256x256' and args.dtype == 'bf16' and D == 256:
+            t = json.load(open(tfile)).get(name)
+            if t:
+                traffic = round(t['read_bytes'] + t['write_bytes'])
+        roofline.update(traffic=traffic, kernel=name, launches_timed=k['n'], avg_launch_us=round(k['ms'] / k['n'] * 1e3, 2),
                         algorithmic_bytes_per_launch=round(k['bytes'] / k['n']), algorithmic_flops_per_launch=round(k['flops'] / k['n']),
                         share_of_backbone_time=round(k['ms'] / total_ms, 4),
                         backbone_ms_per_forward=round(total_ms / (prof_steps * (n_coarse + n_refine)), 3))

@@ -7,7 +7,7 @@ import os
 
 from .build import LIB
 
-COSY_F32, COSY_BF16 = 0, 1
+COSY_F32, COSY_BF16, COSY_F16 = 0, 1, 2
 _lib = None
 
 _c = ctypes
@@ -39,7 +39,7 @@ EXPORTS = tuple(_SIGNATURES)
 
 
 class ProfRec(ctypes.Structure):
-    _fields_ = [('name', _c.c_char * 48), ('layer', _I), ('n', _I), ('ms_avg', _F), ('ms_min', _F),
+    _fields_ = [('name', _c.c_char * 64), ('layer', _I), ('n', _I), ('ms_avg', _F), ('ms_min', _F),
                 ('bytes', _c.c_double), ('flops', _c.c_double)]
 
 

@@ -29,11 +29,29 @@ void set_error(const char* fmt, ...);
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+static inline int dtype_size(int dtype) { return dtype == COSY_F32 ? 4 : 2; }
+// statement form: COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(kernel<T>, ...));
+#define COSY_DISPATCH_STMT(dtype, ...)                                        \
+    do {                                                                      \
+        if ((dtype) == COSY_F32) { using T = float; __VA_ARGS__; }            \
+        else if ((dtype) == COSY_BF16) { using T = cosy::bf16_t; __VA_ARGS__; } \
+        else { using T = cosy::f16_t; __VA_ARGS__; }                          \
+    } while (0)
+// run `expr` with T bound to the storage type selected by `dtype`
+#define COSY_DISPATCH_T(dtype, expr)                                    \
+    ((dtype) == COSY_F32 ? [&] { using T = float; return (expr); }()    \
+     : (dtype) == COSY_BF16 ? [&] { using T = cosy::bf16_t; return (expr); }() \
+                            : [&] { using T = cosy::f16_t; return (expr); }())
 
 // ---- kernels_geom.hip ----
 int launch_crop_geometry(const float* pts_table, const int* obj_id, const float* K, const int* im_id, const float* TCO,

@@ -243,7 +243,7 @@ static void layout_workspace(cosy_net* n, Bump& b) {
     n->zeros = b.take(256);   // stays zero: the workspace is memset at creation and nothing writes here
 }
 
-static const char* dt_name(int dtype) { return dtype == COSY_F32 ? "float" : "__bf16"; }
+static const char* dt_name(int dtype) { return dtype == COSY_F32 ? "float" : dtype == COSY_BF16 ? "__bf16" : "_Float16"; }
 
 static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps, hipStream_t s) {
     int rc;
@@ -264,8 +264,8 @@ static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps
         COSY_CHECK_HIP(hipEventRecord(ev[slot], s));
         return COSY_OK;
     };
-    char kn[48];
-    auto pw_name = [&](const PwLayer& L) { snprintf(kn, sizeof(kn), "pw_gemm_kernel<%s, %d, %d>", dt_name(n->dtype), L.cfg.NI, L.cfg.WN); };
+    char kn[64];
+    auto pw_name = [&](const PwLayer& L, const PwArgs& a) { pw_kernel_name(a, L.cfg, n->dtype, kn, sizeof(kn)); };
     auto pw_bytes = [&](const PwArgs& a, int Bc) { return ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N * (a.res ? 2 : 1)) * esz_d + (a.gate ? (double)Bc * a.K * 4 : 0); };
     auto tap = [&](const void* act, int Bc, int b0, int HW, int C, int idx) -> int {
         if (!taps) return COSY_OK;
@@ -281,7 +281,7 @@ static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps
             f.D = Dbuf; f.partial = n->partial; f.zeros = n->zeros;
             f.B = Bc; f.H = b.H; f.W = b.W; f.Cin = b.d.cin; f.Cmid = b.cmid; f.Ho = b.Ho; f.Wo = b.Wo; f.k = b.d.k; f.s = b.d.s; f.pad_lo = b.pad_lo;
             if ((rc = launch_mbconv_front(f, n->dtype, s))) return rc;
-            snprintf(kn, sizeof(kn), "mbconv_front_kernel<%s, %d, %d>", dt_name(n->dtype), b.d.k, b.d.s);
+            fuse_kernel_name(b.d.cin, b.d.k, b.d.s, n->dtype, kn, sizeof(kn));
             if ((rc = mark(kn, i, ((double)Bc * b.H * b.W * b.d.cin + (double)Bc * b.Ho * b.Wo * b.cmid + (double)b.d.cin * b.cmid) * esz_d,
                            2.0 * Bc * b.H * b.W * b.d.cin * b.cmid + 2.0 * Bc * b.Ho * b.Wo * b.cmid * b.d.k * b.d.k))) return rc;
         } else {
@@ -290,7 +290,7 @@ static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps
             a.A = in; a.Wp = b.exp.Wp; a.out = Ebuf; a.scale = b.exp.scale; a.bias = b.exp.bias;
             a.M = Bc * b.H * b.W; a.K = b.d.cin; a.N = b.cmid; a.HW = b.H * b.W; a.silu = 1; a.zeros = n->zeros;
             if ((rc = launch_pw_gemm(a, b.exp.cfg, n->dtype, s))) return rc;
-            pw_name(b.exp);
+            pw_name(b.exp, a);
             if ((rc = mark(kn, i, pw_bytes(a, Bc), 2.0 * a.M * a.K * a.N))) return rc;
             src = Ebuf;
         }
@@ -313,7 +313,7 @@ static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps
         a.res = b.skip ? in : nullptr; a.gate = n->gate;
         a.M = Bc * b.Ho * b.Wo; a.K = b.cmid; a.N = b.d.cout; a.HW = b.Ho * b.Wo; a.silu = 0; a.zeros = n->zeros;
         if ((rc = launch_pw_gemm(a, b.proj.cfg, n->dtype, s))) return rc;
-        pw_name(b.proj);
+        pw_name(b.proj, a);
         return mark(kn, i, pw_bytes(a, Bc), 2.0 * a.M * a.K * a.N);
     };
     auto stage_tap_index = [&](int i) -> int { for (int q = 0; q < 7; ++q) if (STAGE_END[q] == i) return q + 1; return -1; };
@@ -352,7 +352,7 @@ static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps
     a.A = n->act[cur]; a.Wp = n->head.Wp; a.out = n->Hd; a.scale = n->head.scale; a.bias = n->head.bias;
     a.M = B * n->Hf * n->Wf; a.K = HEAD_IN; a.N = HEAD_C; a.HW = n->Hf * n->Wf; a.silu = 1; a.zeros = n->zeros;
     if ((rc = launch_pw_gemm(a, n->head.cfg, n->dtype, s))) return rc;
-    pw_name(n->head);
+    pw_name(n->head, a);
     if ((rc = mark(kn, 26, pw_bytes(a, B), 2.0 * a.M * a.K * a.N))) return rc;
     if ((rc = tap(n->Hd, B, 0, n->Hf * n->Wf, HEAD_C, 8))) return rc;
     if ((rc = launch_pool_fc(n->Hd, n->fc_w, n->fc_b, feat, n->featbuf, pose, B, n->Hf * n->Wf, n->dtype, s))) return rc;
@@ -382,7 +382,7 @@ int cosy_effnet_b3_out_hw(int H, int W, int* oh, int* ow) {
 
 int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, int H, int W, int max_batch, cosy_net_t** out) {
     COSY_REQUIRE(host_params && out, "create: null argument");
-    COSY_REQUIRE(dtype == COSY_F32 || dtype == COSY_BF16, "create: dtype %d not supported (0=f32, 1=bf16)", dtype);
+    COSY_REQUIRE(dtype == COSY_F32 || dtype == COSY_BF16 || dtype == COSY_F16, "create: dtype %d not supported (0=f32, 1=bf16, 2=f16)", dtype);
     COSY_REQUIRE(H >= 32 && W >= 32 && max_batch >= 1, "create: bad shape H=%d W=%d max_batch=%d", H, W, max_batch);
     if ((long)n_floats != param_count()) {
         set_error("create: parameter blob has %zu floats, expected %ld", n_floats, param_count());

@@ -179,6 +179,11 @@ int launch_roi_align(const float* images, const int* im_id, const float* boxes, 
 template <typename T>
 __device__ __forceinline__ void store_px8(T* dst, const float* v);
 template <>
+__device__ __forceinline__ void store_px8<f16_t>(f16_t* dst, const float* v) {
+    f16x8 o = {(f16_t)v[0], (f16_t)v[1], (f16_t)v[2], (f16_t)v[3], (f16_t)v[4], (f16_t)v[5], (f16_t)0.f, (f16_t)0.f};
+    *(f16x8*)dst = o;
+}
+template <>
 __device__ __forceinline__ void store_px8<float>(float* dst, const float* v) {
     ((f32x4*)dst)[0] = f32x4{v[0], v[1], v[2], v[3]};
     ((f32x4*)dst)[1] = f32x4{v[4], v[5], 0.f, 0.f};
@@ -297,10 +302,7 @@ int launch_crop_pack(void* x, int dtype, const float* frames4, const int* im_id,
     (void)N;
     if (B == 0) return COSY_OK;
     dim3 grid(cdiv(H * W, 256), B);
-    if (dtype == COSY_F32)
-        hipLaunchKernelGGL(crop_pack_kernel<float>, grid, dim3(256), 0, s, (float*)x, frames4, im_id, boxes, renders, h, w, H, W);
-    else
-        hipLaunchKernelGGL(crop_pack_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)x, frames4, im_id, boxes, renders, h, w, H, W);
+    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(crop_pack_kernel<T>, grid, dim3(256), 0, s, (T*)x, frames4, im_id, boxes, renders, h, w, H, W));
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }
@@ -318,10 +320,7 @@ __global__ __launch_bounds__(256) void pack_nchw_kernel(T* __restrict__ x, const
 int launch_pack_nchw(void* x, int dtype, const float* x_nchw6, int B, int H, int W, hipStream_t s) {
     if (B == 0) return COSY_OK;
     dim3 grid(cdiv(H * W, 256), B);
-    if (dtype == COSY_F32)
-        hipLaunchKernelGGL(pack_nchw_kernel<float>, grid, dim3(256), 0, s, (float*)x, x_nchw6, H * W);
-    else
-        hipLaunchKernelGGL(pack_nchw_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)x, x_nchw6, H * W);
+    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(pack_nchw_kernel<T>, grid, dim3(256), 0, s, (T*)x, x_nchw6, H * W));
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }

@@ -27,6 +27,8 @@ struct PwArgs {
     const void* zeros;   // >= 16 zero bytes (global): source of padded rows/k for the LDS-DMA pipeline; null -> classic kernel
 };
 int launch_pw_gemm(const PwArgs& a, PwCfg cfg, int dtype, hipStream_t s);
+void pw_kernel_name(const PwArgs& a, PwCfg c, int dtype, char* buf, size_t n);
+void fuse_kernel_name(int Cin, int k, int s, int dtype, char* buf, size_t n);
 
 struct DwArgs {
     const void* in;      // (B,H,W,C)

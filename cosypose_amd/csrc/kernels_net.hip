@@ -24,8 +24,10 @@ namespace cosy {
 template <typename T> struct DT;
 template <> struct DT<float> { static constexpr int EPL = 4, KB = 16; typedef f32x4 raw_t; };
 template <> struct DT<bf16_t> { static constexpr int EPL = 8, KB = 32; typedef bf16x8 raw_t; };
+template <> struct DT<f16_t> { static constexpr int EPL = 8, KB = 32; typedef f16x8 raw_t; };
 
 __device__ __forceinline__ void mma(f32x4& c, bf16x8 a, bf16x8 b) { c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void mma(f32x4& c, f16x8 a, f16x8 b) { c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ void mma(f32x4& c, f32x4 a, f32x4 b) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], c, 0, 0, 0);
@@ -34,6 +36,7 @@ __device__ __forceinline__ void mma(f32x4& c, f32x4 a, f32x4 b) {
 template <typename T> __device__ __forceinline__ float sigmoid_t(float x);
 template <> __device__ __forceinline__ float sigmoid_t<float>(float x) { return 1.f / (1.f + expf(-x)); }
 template <> __device__ __forceinline__ float sigmoid_t<bf16_t>(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+template <> __device__ __forceinline__ float sigmoid_t<f16_t>(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 __device__ __forceinline__ void to_f32(const f32x4& r, float* v) { v[0] = r[0]; v[1] = r[1]; v[2] = r[2]; v[3] = r[3]; }
 __device__ __forceinline__ void to_f32(const bf16x8& r, float* v) {
@@ -46,6 +49,24 @@ __device__ __forceinline__ void from_f32(bf16x8& r, const float* v) {
     for (int i = 0; i < 8; ++i) r[i] = (bf16_t)v[i];
 }
 
+__device__ __forceinline__ void to_f32(const f16x8& r, float* v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)r[i];
+}
+// fp16 saturates instead of overflowing to inf (activations beyond +-65504 would otherwise poison the squeeze sums)
+__device__ __forceinline__ f16_t to_f16_sat(float x) { return (f16_t)__builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f); }
+__device__ __forceinline__ void from_f32(f16x8& r, const float* v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = to_f16_sat(v[i]);
+}
+__device__ __forceinline__ void load8(const f16_t* p, float* v) { to_f32(*(const f16x8*)p, v); }
+__device__ __forceinline__ void store8(f16_t* p, const float* v) { f16x8 r; from_f32(r, v); *(f16x8*)p = r; }
+__device__ __forceinline__ void store4(f16_t* p, const float* v) {
+    *(f16x4*)p = f16x4{to_f16_sat(v[0]), to_f16_sat(v[1]), to_f16_sat(v[2]), to_f16_sat(v[3])};
+}
+__device__ __forceinline__ void load4(const f16_t* p, float* v) {
+    f16x4 a = *(const f16x4*)p; v[0] = (float)a[0]; v[1] = (float)a[1]; v[2] = (float)a[2]; v[3] = (float)a[3];
+}
 // load / store 8 consecutive channels as fp32
 __device__ __forceinline__ void load8(const float* p, float* v) {
     f32x4 a = ((const f32x4*)p)[0], b = ((const f32x4*)p)[1];
@@ -84,6 +105,7 @@ PwCfg pw_choose_cfg(int N) {
     return best;
 }
 int pw_kb(int dtype) { return dtype == COSY_F32 ? 16 : 32; }
+static inline uint16_t f32_to_f16_host(float f) { _Float16 h = (_Float16)(f > 65504.f ? 65504.f : (f < -65504.f ? -65504.f : f)); uint16_t u; memcpy(&u, &h, 2); return u; }
 static int pw_nkb_total(int K, int dtype) { int n = cdiv(K, pw_kb(dtype)); return (n + 1) & ~1; }
 size_t pw_packed_elems(int K, int N, PwCfg c, int dtype) {
     const int epl = dtype == COSY_F32 ? 4 : 8;
@@ -108,10 +130,12 @@ void pw_pack_weights(const float* w, int K, int N, PwCfg c, int dtype, void* dst
                         const int n = nt * BN + wn * 16 * c.NI + (i >> 2) * 4 * c.NI + ni * 4 + (i & 3);
                         const int k = kbi * kb + kg * epl + e;
                         const float v = (n < N && k < K) ? w[(size_t)n * K + k] : 0.f;
-                        if (dtype == COSY_F32) ((float*)dst)[idx] = v; else ((uint16_t*)dst)[idx] = f32_to_bf16_host(v);
+                        if (dtype == COSY_F32) ((float*)dst)[idx] = v; else ((uint16_t*)dst)[idx] = dtype == COSY_BF16 ? f32_to_bf16_host(v) : f32_to_f16_host(v);
                     }
 }
 
+static bool pw_use_dma(const PwArgs& a);
+static int fuse_et_f32();
 struct PwKArgs {
     const void* A; const void* Wp; void* out; const float* scale; const float* bias; const void* res; const float* gate;
     int M, K, N, HW, silu, MT, NT, nkb_total, nkb_valid;
@@ -287,12 +311,12 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwKArgs a) {
 // (W[n,k]*g[b,k]) at fragment-read time from a gate row staged in LDS; valid when the 64 pixel rows of a wave belong
 // to one sample (HW % 64 == 0); otherwise the launcher falls back to pw_gemm_kernel (gate on the activation rows).
 // ------------------------------------------------------------------------------------------
-template <typename T, int NI, int WN, int NS, bool GATE>
+template <typename T, int NI, int WN, int NS, bool GATE, int MI>
 __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwKArgs a) {
     using D = DT<T>;
     using raw_t = typename D::raw_t;
     constexpr int EPL = D::EPL, KB = D::KB;
-    constexpr int WM = 4 / WN, MI = 4, BM = 64 * WM, BN = 16 * NI * WN;
+    constexpr int WM = 4 / WN, BM = 16 * MI * WM, BN = 16 * NI * WN;
     constexpr int NA = BM / 16, NW = NI * WN, NB = NA + NW;
     constexpr int L = (NB + 3) / 4;   // DMA instructions per wave per k-block
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -311,15 +335,17 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwKArgs a) {
     const int row = lane & 15, kg = lane >> 4;
     const int Kpad = a.nkb_total * KB;
 
+    constexpr bool HALF_GATE = sizeof(T) == 2 && !__is_same(T, bf16_t);   // fp16: the gate multiplies as packed halves
     int gsel = 0;
     if constexpr (GATE) {
         const int b_first = m0 / a.HW;
         for (int i = tid; i < 2 * Kpad; i += 256) {
             const int sidx = i / Kpad, k = i - sidx * Kpad;
             const long mrow = (long)(b_first + sidx) * a.HW;
-            gl[i] = (k < K && mrow < M) ? a.gate[(size_t)(b_first + sidx) * K + k] : 0.f;
+            const float g = (k < K && mrow < M) ? a.gate[(size_t)(b_first + sidx) * K + k] : 0.f;
+            if constexpr (HALF_GATE) ((f16_t*)gl)[i] = (f16_t)g; else gl[i] = g;
         }
-        gsel = (m0 + wm * 64) / a.HW - b_first;
+        gsel = (m0 + wm * 16 * MI) / a.HW - b_first;
         __syncthreads();
     }
 
@@ -363,7 +389,16 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwKArgs a) {
         for (int ni = 0; ni < NI; ++ni) fw[ni] = *(const raw_t*)(st + (NA + wn * NI + ni) * 1024 + lane * 16);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) fa[mi] = *(const raw_t*)(st + (wm * MI + mi) * 1024 + lane * 16);
-        if constexpr (GATE) {
+        if constexpr (GATE && HALF_GATE) {
+            // 4 v_pk_mul_f16 per fragment instead of unpack / multiply / repack
+            const f16x8 g8 = *(const f16x8*)((const f16_t*)gl + gsel * Kpad + kb * KB + kg * EPL);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                f16x8 w8 = __builtin_bit_cast(f16x8, fw[ni]);
+                w8 = w8 * g8;
+                fw[ni] = __builtin_bit_cast(raw_t, w8);
+            }
+        } else if constexpr (GATE) {
             float g[EPL];
             const float* gp = gl + gsel * Kpad + kb * KB + kg * EPL;
 #pragma unroll
@@ -430,25 +465,43 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwKArgs a) {
     }
 }
 
-template <typename T, int NI, int WN, bool GATE, int NS>
-static int launch_pw_dma_ns(const PwKArgs& k, int grid, hipStream_t s) {
-    constexpr int WM = 4 / WN, NB = 64 * WM / 16 + NI * WN;
+template <typename T, int NI, int WN, bool GATE, int NS, int MI>
+static int launch_pw_dma_mi(PwKArgs k, hipStream_t s) {
+    constexpr int WM = 4 / WN, NB = MI * WM + NI * WN;
+    k.MT = cdiv(k.M, 16 * MI * WM);
+    const int grid = cdiv(k.MT, 8) * 8 * k.NT;
     const size_t lds = (size_t)NS * NB * 1024 + 1024 + (GATE ? (size_t)2 * k.nkb_total * DT<T>::KB * 4 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        COSY_CHECK_HIP(hipFuncSetAttribute((const void*)pw_gemm_dma_kernel<T, NI, WN, NS, GATE>,
+        COSY_CHECK_HIP(hipFuncSetAttribute((const void*)pw_gemm_dma_kernel<T, NI, WN, NS, GATE, MI>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((pw_gemm_dma_kernel<T, NI, WN, NS, GATE>), dim3(grid), dim3(256), lds, s, k);
+    hipLaunchKernelGGL((pw_gemm_dma_kernel<T, NI, WN, NS, GATE, MI>), dim3(grid), dim3(256), lds, s, k);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
+}
+// MI = 16-row blocks per wave: 4 (64 rows) by default; 2 halves the accumulators (-> more resident workgroups)
+static int pw_mi(const PwKArgs& k) {
+    static const int mi = getenv("COSY_PW_MI") ? atoi(getenv("COSY_PW_MI")) : 4;
+    return (mi == 2 && k.nkb_valid > 2 && (!k.gate || k.HW % 64 == 0)) ? 2 : 4;
+}
+template <typename T, int NI, int WN, bool GATE, int NS>
+static int launch_pw_dma_ns(const PwKArgs& k, int grid, hipStream_t s) {
+    (void)grid;
+    if (pw_mi(k) == 2) {
+        if constexpr (!GATE) return launch_pw_dma_mi<T, NI, WN, GATE, NS, 2>(k, s);
+        else if (k.HW % 32 == 0 && k.HW >= 64) return launch_pw_dma_mi<T, NI, WN, GATE, NS, 2>(k, s);
+    }
+    return launch_pw_dma_mi<T, NI, WN, GATE, NS, 4>(k, s);
 }
 template <typename T, int NI, int WN, bool GATE>
 static int launch_pw_dma_cfg(const PwKArgs& k, int grid, hipStream_t s) {
     // short k-loops (<= 2 k-blocks: the streaming 1x1 convs of the high-resolution blocks) need no deep ring:
     // 2 stages keep the LDS footprint small so that more workgroups are resident per CU
     if (k.nkb_valid <= 2) return launch_pw_dma_ns<T, NI, WN, GATE, 2>(k, grid, s);
+    static const int deep = getenv("COSY_PW_NS") ? atoi(getenv("COSY_PW_NS")) : 3;
+    if (deep >= 4 && k.nkb_valid >= 8) return launch_pw_dma_ns<T, NI, WN, GATE, 4>(k, grid, s);
     return launch_pw_dma_ns<T, NI, WN, GATE, 3>(k, grid, s);
 }
 template <typename T, bool GATE>
@@ -470,11 +523,7 @@ static int launch_pw_t(const PwArgs& a, PwCfg c, int dtype, hipStream_t s) {
     k.nkb_total = pw_nkb_total(a.K, dtype); k.nkb_valid = cdiv(a.K, pw_kb(dtype));
     const int grid = cdiv(k.MT, 8) * 8 * k.NT;
     k.zeros = a.zeros;
-    static const int use_dma = getenv("COSY_PW_DMA") ? atoi(getenv("COSY_PW_DMA")) : 1;
-    if (use_dma && a.zeros) {
-        if (!a.gate) return launch_pw_dma<T, false>(k, c, grid, s);
-        if (a.HW % 64 == 0) return launch_pw_dma<T, true>(k, c, grid, s);
-    }
+    if (pw_use_dma(a)) return a.gate ? launch_pw_dma<T, true>(k, c, grid, s) : launch_pw_dma<T, false>(k, c, grid, s);
     if (c.NI == 4 && c.WN == 2) hipLaunchKernelGGL((pw_gemm_kernel<T, 4, 2>), dim3(grid), dim3(256), 0, s, k);
     else if (c.NI == 3 && c.WN == 2) hipLaunchKernelGGL((pw_gemm_kernel<T, 3, 2>), dim3(grid), dim3(256), 0, s, k);
     else if (c.NI == 3 && c.WN == 1) hipLaunchKernelGGL((pw_gemm_kernel<T, 3, 1>), dim3(grid), dim3(256), 0, s, k);
@@ -484,10 +533,33 @@ static int launch_pw_t(const PwArgs& a, PwCfg c, int dtype, hipStream_t s) {
     return COSY_OK;
 }
 
+static const char* tname(int dtype) { return dtype == COSY_F32 ? "float" : dtype == COSY_BF16 ? "__bf16" : "_Float16"; }
+static bool pw_use_dma(const PwArgs& a) {
+    static const int use_dma = getenv("COSY_PW_DMA") ? atoi(getenv("COSY_PW_DMA")) : 1;
+    return use_dma && a.zeros && (!a.gate || a.HW % 64 == 0);
+}
+// the kernel symbol (as rocprofv3 demangles it) that launch_pw_gemm will run for these arguments
+void pw_kernel_name(const PwArgs& a, PwCfg c, int dtype, char* buf, size_t n) {
+    if (pw_use_dma(a)) {
+        const int nkb = cdiv(a.K, pw_kb(dtype));
+        static const int deep = getenv("COSY_PW_NS") ? atoi(getenv("COSY_PW_NS")) : 3;
+        snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, %d, %s>", tname(dtype), c.NI, c.WN, nkb <= 2 ? 2 : (deep >= 4 && nkb >= 8 ? 4 : 3),
+                 a.gate ? "true" : "false");
+    } else {
+        snprintf(buf, n, "pw_gemm_kernel<%s, %d, %d>", tname(dtype), c.NI, c.WN);
+    }
+}
+void fuse_kernel_name(int Cin, int k, int s, int dtype, char* buf, size_t n) {
+    const int esz = dtype == COSY_F32 ? 4 : 2;
+    const int et32 = esz == 4 ? 1 : fuse_et_f32();
+    snprintf(buf, n, "mbconv_front_kernel<%s, %s, %d, %d, %d, %d>", tname(dtype), et32 ? "float" : tname(dtype), k, s, s == 1 ? 4 : 2,
+             cdiv(Cin, esz == 2 ? 32 : 16));
+}
+
 int launch_pw_gemm(const PwArgs& a, PwCfg cfg, int dtype, hipStream_t s) {
     if (a.M == 0) return COSY_OK;
     COSY_REQUIRE(a.K % 8 == 0 && a.N % 8 == 0, "pw_gemm: K=%d and N=%d must be multiples of 8", a.K, a.N);
-    return dtype == COSY_F32 ? launch_pw_t<float>(a, cfg, dtype, s) : launch_pw_t<bf16_t>(a, cfg, dtype, s);
+    return COSY_DISPATCH_T(dtype, launch_pw_t<T>(a, cfg, dtype, s));
 }
 
 // ==========================================================================================
@@ -544,6 +616,7 @@ __device__ __forceinline__ void lds_ld8(const bf16_t* p, float* v) {
     v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
 }
 __device__ __forceinline__ void lds_ld8(const float* p, float* v) { load8(p, v); }
+__device__ __forceinline__ void lds_ld8(const f16_t* p, float* v) { load8(p, v); }
 
 template <typename T, int KS, int S>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwKArgs a) {
@@ -698,7 +771,7 @@ static int launch_dw_t(const DwArgs& a, hipStream_t s) {
 int launch_dwconv(const DwArgs& a, int dtype, hipStream_t s) {
     if (a.B == 0) return COSY_OK;
     COSY_REQUIRE(a.C % 8 == 0, "dwconv: C=%d must be a multiple of 8", a.C);
-    return dtype == COSY_F32 ? launch_dw_t<float>(a, s) : launch_dw_t<bf16_t>(a, s);
+    return COSY_DISPATCH_T(dtype, launch_dw_t<T>(a, s));
 }
 
 // ==========================================================================================
@@ -871,7 +944,7 @@ __global__ __launch_bounds__(384) void mbconv_front_kernel(FuseKArgs a) {
 #pragma unroll
                     for (int rr = 0; rr < NROW; ++rr) {
                         float v[CPT];
-                        if constexpr (sizeof(ET) == 2) lds_ld8((const bf16_t*)(col + (size_t)rr * TWin * PITCH), v);
+                        if constexpr (sizeof(ET) == 2) lds_ld8((const ET*)(col + (size_t)rr * TWin * PITCH), v);
                         else load4((const float*)(col + (size_t)rr * TWin * PITCH), v);
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
@@ -933,7 +1006,7 @@ static int launch_fuse_t(const FuseArgs& a, hipStream_t s) {
     k.X = a.X; k.Wp = a.Wp; k.s0 = a.s0; k.b0 = a.b0; k.dww = a.dww; k.s1 = a.s1; k.b1 = a.b1; k.D = a.D; k.partial = a.partial;
     k.zeros = a.zeros; k.H = a.H; k.W = a.W; k.Cin = a.Cin; k.Cmid = a.Cmid; k.Ho = a.Ho; k.Wo = a.Wo; k.lo = a.pad_lo;
     k.TH = p.TH; k.TW = p.TW; k.THin = p.THin; k.TWin = p.TWin; k.MB = p.MB; k.ntx = p.ntx; k.n_tiles = p.ntx * p.nty;
-    k.nkb_total = pw_nkb_total(a.Cin, sizeof(T) == 4 ? COSY_F32 : COSY_BF16);
+    k.nkb_total = pw_nkb_total(a.Cin, sizeof(T) == 4 ? COSY_F32 : COSY_BF16);   // k-block geometry depends on the element size only
     k.rcp_tw = (65536u + p.TWin - 1) / p.TWin;
     for (int q = 0; q < p.MB * 16; ++q)
         if ((int)(((unsigned)q * k.rcp_tw) >> 16) != q / p.TWin) { set_error("mbconv_front: reciprocal division inexact"); return COSY_EINVAL; }
@@ -943,7 +1016,7 @@ static int launch_fuse_t(const FuseArgs& a, hipStream_t s) {
 int launch_mbconv_front(const FuseArgs& a, int dtype, hipStream_t s) {
     if (a.B == 0) return COSY_OK;
     COSY_REQUIRE(fuse_supported(a.Cin, a.Cmid, a.k, a.s, dtype), "mbconv_front: unsupported shape Cin=%d Cmid=%d", a.Cin, a.Cmid);
-    return dtype == COSY_F32 ? launch_fuse_t<float>(a, s) : launch_fuse_t<bf16_t>(a, s);
+    return COSY_DISPATCH_T(dtype, launch_fuse_t<T>(a, s));
 }
 
 // ==========================================================================================
@@ -1068,7 +1141,7 @@ void stem_pack_weights(const float* w, int dtype, void* dst) {
                     const int k = kb * kdepth + kg * epl + e;      // k = tap*8 + ci
                     const int tap = k / 8, ci = k % 8;
                     const float v = (n < 40 && tap < 9 && ci < 6) ? w[((size_t)n * 6 + ci) * 9 + tap] : 0.f;
-                    if (dtype == COSY_F32) ((float*)dst)[idx] = v; else ((uint16_t*)dst)[idx] = f32_to_bf16_host(v);
+                    if (dtype == COSY_F32) ((float*)dst)[idx] = v; else ((uint16_t*)dst)[idx] = dtype == COSY_BF16 ? f32_to_bf16_host(v) : f32_to_f16_host(v);
                 }
 }
 
@@ -1143,10 +1216,7 @@ int launch_stem(const void* x, const void* wp, const float* scale, const float* 
     COSY_REQUIRE((Ho * Wo) % 16 == 0, "stem: Ho*Wo=%d must be a multiple of 16", Ho * Wo);
     const long n_groups = (long)B * Ho * Wo / 16;
     dim3 grid((unsigned)cdiv(n_groups, 4 * STEM_G));
-    if (dtype == COSY_F32)
-        hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)wp, scale, bias, (float*)out, H, W, Ho, Wo, n_groups);
-    else
-        hipLaunchKernelGGL(stem_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)wp, scale, bias, (bf16_t*)out, H, W, Ho, Wo, n_groups);
+    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(stem_kernel<T>, grid, dim3(256), 0, s, (const T*)x, (const T*)wp, scale, bias, (T*)out, H, W, Ho, Wo, n_groups));
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }
@@ -1183,8 +1253,7 @@ int launch_pool_fc(const void* head, const float* fc_w, const float* fc_b, float
     float* f = feat ? feat : feat_scratch;
     COSY_REQUIRE(f, "pool_fc: no feature buffer");
     dim3 grid(1536 / 256, B);
-    if (dtype == COSY_F32) hipLaunchKernelGGL(pool_kernel<float>, grid, dim3(256), 0, s, (const float*)head, f, HW);
-    else hipLaunchKernelGGL(pool_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)head, f, HW);
+    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(pool_kernel<T>, grid, dim3(256), 0, s, (const T*)head, f, HW));
     hipLaunchKernelGGL(fc9_kernel, dim3(B), dim3(576), 0, s, f, fc_w, fc_b, pose);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
@@ -1202,8 +1271,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__
 int launch_nhwc_to_nchw(const void* act, int B, int HW, int C, int dtype, float* out, hipStream_t s) {
     if (B == 0) return COSY_OK;
     dim3 grid(cdiv((long)HW * C, 256), B);
-    if (dtype == COSY_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, s, (const float*)act, HW, C, out);
-    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)act, HW, C, out);
+    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, grid, dim3(256), 0, s, (const T*)act, HW, C, out));
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }
@@ -1235,8 +1303,7 @@ __global__ __launch_bounds__(256) void taps_kernel(const T* __restrict__ act, in
 }
 int launch_taps(const void* act, int B, int HW, int C, int dtype, float* taps, int tap_index, hipStream_t s) {
     if (B == 0) return COSY_OK;
-    if (dtype == COSY_F32) hipLaunchKernelGGL(taps_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)act, HW, C, taps, tap_index);
-    else hipLaunchKernelGGL(taps_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)act, HW, C, taps, tap_index);
+    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(taps_kernel<T>, dim3(B), dim3(256), 0, s, (const T*)act, HW, C, taps, tap_index));
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }

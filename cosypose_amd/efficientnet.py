@@ -15,9 +15,10 @@ import torch
 from torch import nn
 
 from . import arch
-from ._lib import lib, check, ptr, stream, require_device, COSY_F32, COSY_BF16, CosyHipError
+from ._lib import lib, check, ptr, stream, require_device, COSY_F32, COSY_BF16, COSY_F16, CosyHipError
 
-_DTYPES = {'fp32': COSY_F32, 'f32': COSY_F32, 'float32': COSY_F32, 'bf16': COSY_BF16, 'bfloat16': COSY_BF16}
+_DTYPES = {'fp32': COSY_F32, 'f32': COSY_F32, 'float32': COSY_F32, 'bf16': COSY_BF16, 'bfloat16': COSY_BF16,
+           'fp16': COSY_F16, 'f16': COSY_F16, 'float16': COSY_F16, 'half': COSY_F16}
 
 
 class _Block(nn.Module):

@@ -32,7 +32,7 @@ extern "C" {
 enum { COSY_OK = 0, COSY_EINVAL = -1, COSY_ENOMEM = -2, COSY_EHIP = -3, COSY_ESIZE = -4 };
 
 /* storage/compute type of the backbone activations and weights (accumulation is always fp32) */
-enum { COSY_F32 = 0, COSY_BF16 = 1 };
+enum { COSY_F32 = 0, COSY_BF16 = 1, COSY_F16 = 2 };
 
 typedef struct cosy_net cosy_net_t;
 typedef void* cosy_stream_t; /* hipStream_t */
@@ -95,7 +95,7 @@ int cosy_effnet_b3_features_nchw(cosy_net_t* net, int B, float* out, cosy_stream
  * timed launches, mean/min duration, and the ALGORITHMIC bytes and flops of one launch (tensor sizes
  * in+out+weights).  Reading resets the accumulation. */
 typedef struct {
-    char name[48];
+    char name[64];
     int layer;      /* -1 stem, 0..25 MBConv block, 26 head */
     int n;          /* launches timed */
     float ms_avg, ms_min;

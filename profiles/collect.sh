@@ -11,10 +11,10 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-profile $*"
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o t -- python bench.py $ARGS > $OUT/bench_stats.json 2> $OUT/stats.err
+rocprofv3 -M --kernel-trace --stats -f csv -d $OUT/stats -o t -- python bench.py $ARGS > $OUT/bench_stats.json 2> $OUT/stats.err
 pass() { # name counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" -f csv -d $OUT/pmc_$name -o t -- python bench.py $ARGS > /dev/null 2> $OUT/pmc_$name.err || echo "pmc pass $name failed"
+  rocprofv3 -M --kernel-trace --pmc "$@" -f csv -d $OUT/pmc_$name -o t -- python bench.py $ARGS > /dev/null 2> $OUT/pmc_$name.err || echo "pmc pass $name failed"
 }
 pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE
 pass fetch FETCH_SIZE

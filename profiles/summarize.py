@@ -11,15 +11,26 @@ from collections import defaultdict
 
 
 def short(name):
-    """rocprofv3's demangler garbles the __bf16 template arguments; keep the base kernel name and, for the
-    mangled form, the template digits (e.g. pw_gemm_kernel[bf16,3,2])."""
-    m = re.match(r'_ZN4cosy\d+([a-z0-9_]+?)I(.*?)EEv', name)
-    if m:
-        args = re.sub(r'Li(\d+)E', r',\1', m.group(2)).replace('DF16b', 'bf16')
-        return f'{m.group(1)}[{args}]'
-    name = re.sub(r'^void ', '', name)
-    name = re.sub(r'\(.*$', '', name)
-    return name.replace('cosy::', '')
+    """Canonical kernel name from the MANGLED symbol (collect with rocprofv3 -M: its demangler garbles __bf16
+    template arguments).  e.g. _ZN4cosy18pw_gemm_dma_kernelIDF16bLi4ELi2ELi3ELb1EEEvNS_7PwKArgsE ->
+    pw_gemm_dma_kernel<__bf16, 4, 2, 3, true>  (same strings as cosy_effnet_b3_profile_read reports)."""
+    m = re.match(r'_ZN4cosy\d+([a-z0-9_]+?)I(.*)EEv', name) or re.match(r'_ZN4cosy\d+([a-z0-9_]+?)()E', name)
+    if not m:
+        return re.sub(r'\(.*$', '', re.sub(r'^void ', '', name)).replace('cosy::', '')
+    base, targs = m.group(1), m.group(2)
+    if not targs:
+        return base
+    toks, i = [], 0
+    while i < len(targs):
+        if targs.startswith('DF16b', i): toks.append('__bf16'); i += 5
+        elif targs[i] == 'f': toks.append('float'); i += 1
+        elif targs.startswith('Li', i):
+            j = targs.index('E', i); toks.append(targs[i + 2:j]); i = j + 1
+        elif targs.startswith('Lb', i):
+            toks.append('true' if targs[i + 2] == '1' else 'false'); i += 4
+        else:
+            toks.append(targs[i:]); break
+    return f"{base}<{', '.join(toks)}>"
 
 
 def main(root):
@@ -35,6 +46,16 @@ def main(root):
     bykern = defaultdict(lambda: [0.0, 0])
     for (k, g), v in times.items():
         bykern[k][0] += sum(v); bykern[k][1] += len(v)
+    # per-kernel mean HBM traffic per launch from the PMC passes (read ~ 2*FETCH_SIZE KiB on gfx950, see module docstring)
+    import json
+    agg = defaultdict(lambda: defaultdict(list))
+    for (k, g), c in ctr.items():
+        for n in ('FETCH_SIZE', 'WRITE_SIZE'):
+            agg[k][n] += c.get(n, [])
+    traffic = {k: dict(read_bytes=2 * 1024 * sum(v['FETCH_SIZE']) / len(v['FETCH_SIZE']),
+                       write_bytes=1024 * sum(v['WRITE_SIZE']) / len(v['WRITE_SIZE']), launches=len(v['FETCH_SIZE']))
+               for k, v in agg.items() if v['FETCH_SIZE'] and v['WRITE_SIZE'] and not k.startswith('__amd')}
+    json.dump(traffic, open(f'{root}/pmc_traffic.json', 'w'), indent=1)
     print(f'== per-kernel time (rocprofv3 --kernel-trace), total {total / 1e3:.2f} ms')
     for k, (t, n) in sorted(bykern.items(), key=lambda kv: -kv[1][0])[:25]:
         print(f'{100 * t / total:5.1f}%  n={n:5d}  avg {t / n:9.1f} us  {k}')

@@ -180,6 +180,32 @@ def test_backbone_bf16_deviation(model, golden):
     model.compute_dtype = 'fp32'; model.render_size = (240, 320)
 
 
+def test_backbone_fp16_deviation(model, golden):
+    """BASELINE configs[2] names fp16: same kernels with _Float16 storage (saturating converts)."""
+    x = np.random.RandomState(22).random_sample((2, 6, 256, 256)).astype(np.float32)
+    feat, pose, taps = _run_net(model, x, 'fp16')
+    fe, pe = rel_err(feat, golden['bb_256x256_feat']), rel_err(pose, golden['bb_256x256_pose'])
+    print(f'fp16 deviation vs reference fp32: features {fe:.3e}, pose params {pe:.3e}')
+    assert fe < 1e-2      # 11-bit mantissa: ~8x tighter than bf16
+    model.compute_dtype = 'fp32'; model.render_size = (240, 320)
+
+
+@pytest.mark.parametrize('dtype,tol', [('bf16', 2e-2), ('fp16', 3e-3)])
+def test_refiner_loop_low_precision(model, golden, labels21, dtype, tol):
+    """configs[1]/[2] style run (4 refiner iterations, 16-bit backbone) stays close to the fp32 reference poses."""
+    name, B, n_it, (h, w), seed = 'b3_n4_480', 3, 4, (480, 640), 32
+    obj = golden[f'fw_{name}_obj']
+    images = syn.make_frames(seed + 100, B, h, w); K = syn.make_K(B, h, w); TCO = syn.make_TCO(seed + 200, B)
+    model.renderer = FakeRenderer(seed * 1000)
+    model.compute_dtype = dtype
+    with torch.no_grad():
+        out = model(images=dev(images), K=dev(K), labels=labels21[obj], TCO=dev(TCO), n_iterations=n_it)
+    model.compute_dtype = 'fp32'
+    err = rel_err(out[f'iteration={n_it}']['TCO_output'].cpu().numpy(), golden[f'fw_{name}_it{n_it}_TCO_output'])
+    print(f'{dtype}: refined pose deviation after {n_it} iterations = {err:.3e}')
+    assert err < tol
+
+
 def test_backbone_module_api(model, oracle, golden_sd):
     """backbone(x) returns the (B,1536,h,w) feature map like the reference's EfficientNet.forward;
     net_forward(x) returns {'pose': ...}."""
