@@ -70,9 +70,14 @@ struct cosy_net {
     float *stem_scale, *stem_bias, *fc_w, *fc_b;
     cosy::Block blk[26];
     cosy::PwLayer head;
-    void *X, *act[2], *E, *D, *Hd, *actc[2], *Ec, *Dc;
+    void* X;
     int chunk, fuse;
-    float *partial, *gate, *featbuf;
+    // activation workspaces: ws[0] holds max_batch samples; ws[1] (half size) serves the second half-batch when the
+    // forward is split over two internal streams so that VALU-bound and MFMA/bandwidth-bound kernels co-reside
+    struct WS { void *act[2], *E, *D, *Hd, *actc[2], *Ec, *Dc; float *partial, *gate, *featbuf; } ws[2];
+    int nstreams, last_split;
+    hipStream_t side[2];
+    hipEvent_t ev_fork, ev_join[2];
     void* zeros;
     void* wbase; void* abase;
     size_t wbytes, abytes;
@@ -212,9 +217,9 @@ enum { EARLY_BLOCKS = 9 };  // stem + blocks 0..8 (feature maps >= 32x32 at 256^
 // Early segment runs in sample chunks through small buffers that are REUSED for every chunk, so the large
 // high-resolution intermediates stay resident in the 256 MiB Infinity Cache / L2 between producer and consumer
 // kernels instead of round-tripping through HBM; the late segment (small maps, big GEMMs) runs on the full batch.
-static void layout_workspace(cosy_net* n, Bump& b) {
-    const size_t B = n->maxB, e = n->esz;
-    const size_t Bc = (size_t)std::min(n->chunk, n->maxB);
+static void layout_ws(cosy_net* n, Bump& b, cosy_net::WS& w, size_t B) {
+    const size_t e = n->esz;
+    const size_t Bc = std::min((size_t)n->chunk, B);
     size_t act_e = (size_t)n->Hs * n->Ws * STEM_C, ex_e = 0, dw_e = 0, act_l = 0, ex_l = 0, dw_l = 0, part = 0, gate = 0;
     for (int i = 0; i < 26; ++i) {
         const Block& k = n->blk[i];
@@ -222,34 +227,38 @@ static void layout_workspace(cosy_net* n, Bump& b) {
         size_t& act = early ? act_e : act_l; size_t& ex = early ? ex_e : ex_l; size_t& dw = early ? dw_e : dw_l;
         act = std::max(act, (size_t)k.Ho * k.Wo * k.d.cout);
         if (i == EARLY_BLOCKS - 1) act_l = std::max(act_l, (size_t)k.Ho * k.Wo * k.d.cout);  // hand-over tensor
-        if (k.d.e != 1) ex = std::max(ex, (size_t)k.H * k.W * k.cmid);
+        if (k.d.e != 1 && !k.fused) ex = std::max(ex, (size_t)k.H * k.W * k.cmid);
         dw = std::max(dw, (size_t)k.Ho * k.Wo * k.cmid);
         part = std::max(part, (size_t)k.n_tiles * k.cmid * (early ? Bc : B));
         gate = std::max(gate, (size_t)k.cmid);
     }
-    n->X = b.take(B * n->H * n->W * 8 * e);
-    n->actc[0] = b.take(Bc * act_e * e);
-    n->actc[1] = b.take(Bc * act_e * e);
-    n->Ec = b.take(Bc * ex_e * e);
-    n->Dc = b.take(Bc * dw_e * e);
-    n->act[0] = b.take(B * act_l * e);
-    n->act[1] = b.take(B * act_l * e);
-    n->E = b.take(B * ex_l * e);
-    n->D = b.take(B * dw_l * e);
-    n->Hd = b.take(B * (size_t)n->Hf * n->Wf * HEAD_C * e);
-    n->partial = (float*)b.take(part * sizeof(float));
-    n->gate = (float*)b.take(B * gate * sizeof(float));
-    n->featbuf = (float*)b.take(B * (size_t)HEAD_C * sizeof(float));
+    w.actc[0] = b.take(Bc * act_e * e);
+    w.actc[1] = b.take(Bc * act_e * e);
+    w.Ec = b.take(Bc * ex_e * e + 256);
+    w.Dc = b.take(Bc * dw_e * e);
+    w.act[0] = b.take(B * act_l * e);
+    w.act[1] = b.take(B * act_l * e);
+    w.E = b.take(B * ex_l * e);
+    w.D = b.take(B * dw_l * e);
+    w.Hd = b.take(B * (size_t)n->Hf * n->Wf * HEAD_C * e);
+    w.partial = (float*)b.take(part * sizeof(float));
+    w.gate = (float*)b.take(B * gate * sizeof(float));
+    w.featbuf = (float*)b.take(B * (size_t)HEAD_C * sizeof(float));
+}
+static void layout_workspace(cosy_net* n, Bump& b) {
+    n->X = b.take((size_t)n->maxB * n->H * n->W * 8 * n->esz);
     n->zeros = b.take(256);   // stays zero: the workspace is memset at creation and nothing writes here
+    layout_ws(n, b, n->ws[0], n->maxB);
+    if (n->nstreams == 2) layout_ws(n, b, n->ws[1], (n->maxB + 1) / 2);
 }
 
 static const char* dt_name(int dtype) { return dtype == COSY_F32 ? "float" : dtype == COSY_BF16 ? "__bf16" : "_Float16"; }
 
-static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps, hipStream_t s) {
+static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, float* feat, float* pose, float* taps, hipStream_t s, bool allow_prof) {
     int rc;
     const double esz_d = n->esz;
     const size_t e = n->esz;
-    const bool prof = n->prof_on && n->prof_seg < PROF_SEGS && !taps;
+    const bool prof = allow_prof && n->prof_on && n->prof_seg < PROF_SEGS && !taps;
     hipEvent_t* ev = prof ? n->prof_ev + (size_t)n->prof_seg * (PROF_SLOTS + 1) : nullptr;
     int slot = 0;
     if (prof) COSY_CHECK_HIP(hipEventRecord(ev[0], s));
@@ -278,7 +287,7 @@ static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps
         if (b.fused) {
             FuseArgs f{};
             f.X = in; f.Wp = b.exp_wp_fused; f.s0 = b.exp.scale; f.b0 = b.exp.bias; f.dww = b.dw_w; f.s1 = b.dw_scale; f.b1 = b.dw_bias;
-            f.D = Dbuf; f.partial = n->partial; f.zeros = n->zeros;
+            f.D = Dbuf; f.partial = w.partial; f.zeros = n->zeros;
             f.B = Bc; f.H = b.H; f.W = b.W; f.Cin = b.d.cin; f.Cmid = b.cmid; f.Ho = b.Ho; f.Wo = b.Wo; f.k = b.d.k; f.s = b.d.s; f.pad_lo = b.pad_lo;
             if ((rc = launch_mbconv_front(f, n->dtype, s))) return rc;
             fuse_kernel_name(b.d.cin, b.d.k, b.d.s, n->dtype, kn, sizeof(kn));
@@ -295,7 +304,7 @@ static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps
             src = Ebuf;
         }
         DwArgs d{};
-        d.in = src; d.w = b.dw_w; d.scale = b.dw_scale; d.bias = b.dw_bias; d.out = Dbuf; d.partial = n->partial;
+        d.in = src; d.w = b.dw_w; d.scale = b.dw_scale; d.bias = b.dw_bias; d.out = Dbuf; d.partial = w.partial;
         d.B = Bc; d.H = b.H; d.W = b.W; d.C = b.cmid; d.Ho = b.Ho; d.Wo = b.Wo; d.k = b.d.k; d.s = b.d.s; d.pad_lo = b.pad_lo; d.zeros = n->zeros;
         if ((rc = launch_dwconv(d, n->dtype, s))) return rc;
         snprintf(kn, sizeof(kn), "dwconv_kernel<%s, %d, %d>", dt_name(n->dtype), b.d.k, b.d.s);
@@ -303,14 +312,14 @@ static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps
                        2.0 * Bc * b.Ho * b.Wo * b.cmid * b.d.k * b.d.k))) return rc;
         }
         SeArgs se{};
-        se.partial = n->partial; se.n_tiles = b.n_tiles; se.w_red = b.se_wr; se.b_red = b.se_br; se.w_exp = b.se_we; se.b_exp = b.se_be;
-        se.gate = n->gate; se.B = Bc; se.C = b.cmid; se.Cse = b.cse; se.HW = b.Ho * b.Wo;
+        se.partial = w.partial; se.n_tiles = b.n_tiles; se.w_red = b.se_wr; se.b_red = b.se_br; se.w_exp = b.se_we; se.b_exp = b.se_be;
+        se.gate = w.gate; se.B = Bc; se.C = b.cmid; se.Cse = b.cse; se.HW = b.Ho * b.Wo;
         if ((rc = launch_se(se, s))) return rc;
         if ((rc = mark("se_kernel", i, (double)Bc * b.n_tiles * b.cmid * 4 + (double)Bc * b.cmid * 4 + 2.0 * b.cse * b.cmid * 4,
                        4.0 * Bc * b.cse * b.cmid))) return rc;
         PwArgs a{};
         a.A = Dbuf; a.Wp = b.proj.Wp; a.out = out; a.scale = b.proj.scale; a.bias = b.proj.bias;
-        a.res = b.skip ? in : nullptr; a.gate = n->gate;
+        a.res = b.skip ? in : nullptr; a.gate = w.gate;
         a.M = Bc * b.Ho * b.Wo; a.K = b.cmid; a.N = b.d.cout; a.HW = b.Ho * b.Wo; a.silu = 0; a.zeros = n->zeros;
         if ((rc = launch_pw_gemm(a, b.proj.cfg, n->dtype, s))) return rc;
         pw_name(b.proj, a);
@@ -324,16 +333,16 @@ static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps
     const int chunk = std::min(n->chunk, n->maxB);
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int Bc = std::min(chunk, B - b0);
-        const char* x = (const char*)n->X + (size_t)b0 * n->H * n->W * 8 * e;
-        if ((rc = launch_stem(x, n->stem_w, n->stem_scale, n->stem_bias, n->actc[0], Bc, n->H, n->W, n->Hs, n->Ws, n->dtype, s))) return rc;
+        const char* x = (const char*)n->X + (size_t)(x_off + b0) * n->H * n->W * 8 * e;
+        if ((rc = launch_stem(x, n->stem_w, n->stem_scale, n->stem_bias, w.actc[0], Bc, n->H, n->W, n->Hs, n->Ws, n->dtype, s))) return rc;
         snprintf(kn, sizeof(kn), "stem_kernel<%s>", dt_name(n->dtype));
         if ((rc = mark(kn, -1, ((double)Bc * n->H * n->W * 8 + (double)Bc * n->Hs * n->Ws * STEM_C) * esz_d, 2.0 * Bc * n->Hs * n->Ws * STEM_C * IN_C * 9))) return rc;
-        if ((rc = tap(n->actc[0], Bc, b0, n->Hs * n->Ws, STEM_C, 0))) return rc;
+        if ((rc = tap(w.actc[0], Bc, b0, n->Hs * n->Ws, STEM_C, 0))) return rc;
         int cur = 0;
         for (int i = 0; i < EARLY_BLOCKS; ++i) {
             const Block& b = n->blk[i];
-            void* out = (i == EARLY_BLOCKS - 1) ? (void*)((char*)n->act[0] + (size_t)b0 * handover) : n->actc[cur ^ 1];
-            if ((rc = run_block(i, n->actc[cur], out, Bc, n->Ec, n->Dc))) return rc;
+            void* out = (i == EARLY_BLOCKS - 1) ? (void*)((char*)w.act[0] + (size_t)b0 * handover) : w.actc[cur ^ 1];
+            if ((rc = run_block(i, w.actc[cur], out, Bc, w.Ec, w.Dc))) return rc;
             cur ^= 1;
             const int ti = stage_tap_index(i);
             if (ti >= 0 && (rc = tap(out, Bc, b0, b.Ho * b.Wo, b.d.cout, ti))) return rc;
@@ -343,22 +352,41 @@ static int net_forward(cosy_net* n, int B, float* feat, float* pose, float* taps
     int cur = 0;
     for (int i = EARLY_BLOCKS; i < 26; ++i) {
         const Block& b = n->blk[i];
-        if ((rc = run_block(i, n->act[cur], n->act[cur ^ 1], B, n->E, n->D))) return rc;
+        if ((rc = run_block(i, w.act[cur], w.act[cur ^ 1], B, w.E, w.D))) return rc;
         cur ^= 1;
         const int ti = stage_tap_index(i);
-        if (ti >= 0 && (rc = tap(n->act[cur], B, 0, b.Ho * b.Wo, b.d.cout, ti))) return rc;
+        if (ti >= 0 && (rc = tap(w.act[cur], B, 0, b.Ho * b.Wo, b.d.cout, ti))) return rc;
     }
     PwArgs a{};
-    a.A = n->act[cur]; a.Wp = n->head.Wp; a.out = n->Hd; a.scale = n->head.scale; a.bias = n->head.bias;
+    a.A = w.act[cur]; a.Wp = n->head.Wp; a.out = w.Hd; a.scale = n->head.scale; a.bias = n->head.bias;
     a.M = B * n->Hf * n->Wf; a.K = HEAD_IN; a.N = HEAD_C; a.HW = n->Hf * n->Wf; a.silu = 1; a.zeros = n->zeros;
     if ((rc = launch_pw_gemm(a, n->head.cfg, n->dtype, s))) return rc;
     pw_name(n->head, a);
     if ((rc = mark(kn, 26, pw_bytes(a, B), 2.0 * a.M * a.K * a.N))) return rc;
-    if ((rc = tap(n->Hd, B, 0, n->Hf * n->Wf, HEAD_C, 8))) return rc;
-    if ((rc = launch_pool_fc(n->Hd, n->fc_w, n->fc_b, feat, n->featbuf, pose, B, n->Hf * n->Wf, n->dtype, s))) return rc;
+    if ((rc = tap(w.Hd, B, 0, n->Hf * n->Wf, HEAD_C, 8))) return rc;
+    if ((rc = launch_pool_fc(w.Hd, n->fc_w, n->fc_b, feat, w.featbuf, pose, B, n->Hf * n->Wf, n->dtype, s))) return rc;
     snprintf(kn, sizeof(kn), "pool_kernel<%s>+fc9_kernel", dt_name(n->dtype));
     if ((rc = mark(kn, 26, (double)B * n->Hf * n->Wf * HEAD_C * esz_d, 2.0 * B * HEAD_C * (n->Hf * n->Wf + N_POSE)))) return rc;
     if (prof) { n->prof_nslots = slot; ++n->prof_seg; }
+    return COSY_OK;
+}
+
+// Whole-batch entry: one stream, or two half-batches on two internal streams (fork/join with events; capturable).
+static int net_forward_top(cosy_net* n, int B, float* feat, float* pose, float* taps, hipStream_t s) {
+    const bool dual = n->nstreams == 2 && B >= 32 && !taps && !n->prof_on;
+    n->last_split = dual ? (B + 1) / 2 : B;
+    if (!dual) return net_forward(n, n->ws[0], 0, B, feat, pose, taps, s, true);
+    const int B0 = n->last_split, B1 = B - B0;
+    COSY_CHECK_HIP(hipEventRecord(n->ev_fork, s));
+    int rc;
+    for (int i = 0; i < 2; ++i) {
+        COSY_CHECK_HIP(hipStreamWaitEvent(n->side[i], n->ev_fork, 0));
+        const int off = i ? B0 : 0, cnt = i ? B1 : B0;
+        if ((rc = net_forward(n, n->ws[i], off, cnt, feat ? feat + (size_t)off * HEAD_C : nullptr, pose + (size_t)off * N_POSE, nullptr,
+                              n->side[i], false))) return rc;
+        COSY_CHECK_HIP(hipEventRecord(n->ev_join[i], n->side[i]));
+        COSY_CHECK_HIP(hipStreamWaitEvent(s, n->ev_join[i], 0));
+    }
     return COSY_OK;
 }
 
@@ -398,6 +426,8 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
         n->chunk = c <= 0 ? max_batch : c;
         const char* fv = getenv("COSY_FUSE");
         n->fuse = fv ? atoi(fv) : 1;
+        const char* sv = getenv("COSY_STREAMS");
+        n->nstreams = (sv ? atoi(sv) : 1) == 2 && max_batch >= 32 ? 2 : 1;   // measured: 2 streams x half batches is ~10 % slower
     }
     hipError_t herr = hipSuccess;
     Bump wb;
@@ -422,6 +452,12 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
         set_error("create: weight upload failed: %s", hipGetErrorString(herr));
         (void)hipFree(n->wbase); (void)hipFree(n->abase); free(n);
         return COSY_EHIP;
+    }
+    if (n->nstreams == 2) {
+        for (int i = 0; i < 2; ++i) {
+            if (hipStreamCreateWithFlags(&n->side[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&n->ev_join[i], hipEventDisableTiming) != hipSuccess) n->nstreams = 1;
+        }
+        if (hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming) != hipSuccess) n->nstreams = 1;
     }
     *out = n;
     return COSY_OK;
@@ -471,6 +507,10 @@ int cosy_effnet_b3_destroy(cosy_net_t* n) {
         for (size_t i = 0; i < (size_t)PROF_SEGS * (PROF_SLOTS + 1); ++i) (void)hipEventDestroy(n->prof_ev[i]);
         free(n->prof_ev); free(n->prof_rec);
     }
+    if (n->nstreams == 2) {
+        for (int i = 0; i < 2; ++i) { (void)hipStreamDestroy(n->side[i]); (void)hipEventDestroy(n->ev_join[i]); }
+        (void)hipEventDestroy(n->ev_fork);
+    }
     (void)hipFree(n->wbase); (void)hipFree(n->abase);
     free(n);
     return COSY_OK;
@@ -499,13 +539,16 @@ int cosy_crop_pack(cosy_net_t* n, const float* images, const int* im_id, const f
 int cosy_effnet_b3_forward(cosy_net_t* n, int B, float* feat, float* pose9, float* taps, cosy_stream_t stream) {
     COSY_REQUIRE(n && pose9, "forward: null argument");
     COSY_REQUIRE(B >= 0 && B <= n->maxB, "forward: batch %d exceeds max_batch %d", B, n->maxB);
-    return net_forward(n, B, feat, pose9, taps, (hipStream_t)stream);
+    return net_forward_top(n, B, feat, pose9, taps, (hipStream_t)stream);
 }
 
 int cosy_effnet_b3_features_nchw(cosy_net_t* n, int B, float* out, cosy_stream_t stream) {
     COSY_REQUIRE(n && out, "features_nchw: null argument");
     COSY_REQUIRE(B >= 0 && B <= n->maxB, "features_nchw: batch %d exceeds max_batch %d", B, n->maxB);
-    return launch_nhwc_to_nchw(n->Hd, B, n->Hf * n->Wf, HEAD_C, n->dtype, out, (hipStream_t)stream);
+    const int B0 = n->last_split < B ? n->last_split : B;   // the head activation lives in two workspaces after a split forward
+    int rc = launch_nhwc_to_nchw(n->ws[0].Hd, B0, n->Hf * n->Wf, HEAD_C, n->dtype, out, (hipStream_t)stream);
+    if (rc || B0 == B) return rc;
+    return launch_nhwc_to_nchw(n->ws[1].Hd, B - B0, n->Hf * n->Wf, HEAD_C, n->dtype, out + (size_t)B0 * n->Hf * n->Wf * HEAD_C, (hipStream_t)stream);
 }
 
 int cosy_crop_geometry(const float* pts_table, const int* obj_id, const float* K, const int* im_id, const float* TCO, int B, int P,

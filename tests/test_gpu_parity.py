@@ -295,3 +295,39 @@ def test_cpu_tensors_fail_loudly(model):
     from cosypose_amd._lib import CosyHipError
     with pytest.raises(CosyHipError):
         model.net_forward(torch.zeros(1, 6, 240, 320))
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size (BASELINE configs[1]: 256 crops in flight) size-independent properties
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+def test_full_batch_properties(model, labels21, dtype):
+    """At B=256, 256x256 crops: (1) bitwise run-to-run determinism (fixed-order reductions everywhere),
+    (2) a crop's result does not depend on which other crops share the batch (bit-exact vs running it in a batch of 3),
+    (3) permuting the detections permutes the outputs (bit-exact)."""
+    B, h, w = 256, 512, 512
+    rs = np.random.RandomState(77)
+    images = dev(syn.make_frames(5, 4, h, w)); K = dev(syn.make_K(4, h, w))
+    obj = rs.randint(0, 21, B); im = rs.randint(0, 4, B)
+    TCO = dev(syn.make_TCO(6, B))
+    rend = torch.rand(B, 3, 256, 256, device='cuda', generator=torch.Generator(device='cuda').manual_seed(1))
+
+    class R:
+        def __init__(self, sel): self.sel = sel
+        def render(self, obj_infos, TCO, K, resolution): return rend[self.sel]
+    model.compute_dtype = dtype
+    model.render_size = (256, 256)
+
+    def run(sel):
+        model.renderer = R(sel)
+        with torch.no_grad():
+            o = model(images=images, K=K, labels=labels21[obj[sel]], TCO=TCO[sel], n_iterations=2, im_ids=im[sel])
+        return torch.cat([o['iteration=2']['TCO_output'].reshape(len(sel), -1), o['iteration=2']['model_outputs']['pose']], 1)
+    full = np.arange(B)
+    a = run(full); b = run(full)
+    assert torch.isfinite(a).all() and torch.equal(a, b)                 # (1)
+    few = np.array([0, 131, 255])
+    assert torch.equal(run(few), a[few])                                  # (2)
+    perm = rs.permutation(B)
+    assert torch.equal(run(perm), a[perm])                                # (3)
+    model.compute_dtype = 'fp32'; model.render_size = (240, 320)
