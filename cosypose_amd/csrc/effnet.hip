@@ -72,6 +72,7 @@ struct cosy_net {
     cosy::PwLayer head;
     void* X;
     int chunk, fuse;
+    unsigned fuse_mask;   // bit i: MBConv block i runs the fused expand+depthwise front kernel
     // activation workspaces: ws[0] holds max_batch samples; ws[1] (half size) serves the second half-batch when the
     // forward is split over two internal streams so that VALU-bound and MFMA/bandwidth-bound kernels co-reside
     struct WS { void *act[2], *E, *D, *Hd, *actc[2], *Ec, *Dc; float *partial, *gate, *featbuf; } ws[2];
@@ -152,8 +153,8 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         int hi; static_pad(b.d.k, b.d.s, &b.pad_lo, &hi);
         b.skip = (b.d.s == 1 && b.d.cin == b.d.cout);  // id_skip, efficientnet.py:94
         b.n_tiles = dw_num_tiles(b.cmid, b.Ho, b.Wo, b.d.k);
-        // blocks 2..5 (>= 64x64 maps at 256^2, Cin <= 32): expand + depthwise fused, expanded tensor stays in LDS
-        b.fused = n->fuse && b.d.e != 1 && i >= 2 && i <= 5 && fuse_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype);
+        // selected blocks (default 2-5 and 8): expand + depthwise fused, the expanded tensor stays in LDS
+        b.fused = n->fuse && b.d.e != 1 && ((n->fuse_mask >> i) & 1) && fuse_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype);
         b.exp_wp_fused = nullptr;
         if (b.d.e != 1) {
             mk_pw(b.exp, p, b.d.cin, b.cmid, p + (size_t)b.cmid * b.d.cin);
@@ -426,6 +427,10 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
         n->chunk = c <= 0 ? max_batch : c;
         const char* fv = getenv("COSY_FUSE");
         n->fuse = fv ? atoi(fv) : 1;
+        // measured per block (256^2, bf16): fused wins for blocks 2-5 and 8; it loses for the k=5 stride-1 blocks 6/7
+        // (halo recompute x1.9) and is not built for Cin > 64 (blocks 9+)
+        const char* fm = getenv("COSY_FUSE_MASK");
+        n->fuse_mask = fm ? (unsigned)strtoul(fm, nullptr, 0) : 0x13cu;
         const char* sv = getenv("COSY_STREAMS");
         n->nstreams = (sv ? atoi(sv) : 1) == 2 && max_batch >= 32 ? 2 : 1;   // measured: 2 streams x half batches is ~10 % slower
     }
