@@ -136,10 +136,13 @@ void pw_pack_weights(const float* w, int K, int N, PwCfg c, int dtype, void* dst
 
 static bool pw_use_dma(const PwArgs& a);
 static int fuse_et_f32();
+// samples an m-tile of bm rows can touch when a sample has hw rows
+static inline int pw_gate_nsamp(int bm, int hw) { return (bm + hw - 2) / hw + 1; }
 struct PwKArgs {
     const void* A; const void* Wp; void* out; const float* scale; const float* bias; const void* res; const float* gate;
     int M, K, N, HW, silu, MT, NT, nkb_total, nkb_valid;
     const void* zeros;
+    int nsamp, rowgate;   // DMA kernel gate: samples under one m-tile; 1 = gate the activation fragments per row
 };
 
 template <typename T, int NI, int WN>
@@ -308,8 +311,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwKArgs a) {
 // DMA queue).  Every wave issues the same number L of DMA instructions per k-block (surplus ones land in a dummy
 // block) so that the vmcnt immediates are compile-time constants.
 // SE gate (project convs): out = sum_k D[m,k] g[b,k] W[n,k]; the gate is folded into the WEIGHT fragments
-// (W[n,k]*g[b,k]) at fragment-read time from a gate row staged in LDS; valid when the 64 pixel rows of a wave belong
-// to one sample (HW % 64 == 0); otherwise the launcher falls back to pw_gemm_kernel (gate on the activation rows).
+// (W[n,k]*g[b,k]) at fragment-read time from a gate row staged in LDS when the 64 pixel rows of a wave belong to one
+// sample (HW % 64 == 0); otherwise (240x320 input) each lane scales its ACTIVATION fragments with its own row's gate.
 // ------------------------------------------------------------------------------------------
 template <typename T, int NI, int WN, int NS, bool GATE, int MI>
 __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwKArgs a) {
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwKArgs a) {
     constexpr int L = (NB + 3) / 4;   // DMA instructions per wave per k-block
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* dummy = lds + NS * NB * 1024;
-    float* gl = (float*)(dummy + 1024);   // GATE: [2][Kpad] gate rows of the (<= 2) samples under this m-tile
+    float* gl = (float*)(dummy + 1024);   // GATE: [nsamp][Kpad] gate rows of the samples under this m-tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -336,16 +339,18 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwKArgs a) {
     const int Kpad = a.nkb_total * KB;
 
     constexpr bool HALF_GATE = sizeof(T) == 2 && !__is_same(T, bf16_t);   // fp16: the gate multiplies as packed halves
-    int gsel = 0;
+    int gsel = 0, grow[MI];
     if constexpr (GATE) {
         const int b_first = m0 / a.HW;
-        for (int i = tid; i < 2 * Kpad; i += 256) {
+        for (int i = tid; i < a.nsamp * Kpad; i += 256) {
             const int sidx = i / Kpad, k = i - sidx * Kpad;
             const long mrow = (long)(b_first + sidx) * a.HW;
             const float g = (k < K && mrow < M) ? a.gate[(size_t)(b_first + sidx) * K + k] : 0.f;
             if constexpr (HALF_GATE) ((f16_t*)gl)[i] = (f16_t)g; else gl[i] = g;
         }
         gsel = (m0 + wm * 16 * MI) / a.HW - b_first;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) grow[mi] = min((m0 + (wm * MI + mi) * 16 + row) / a.HW - b_first, a.nsamp - 1) * Kpad;
         __syncthreads();
     }
 
@@ -389,7 +394,28 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwKArgs a) {
         for (int ni = 0; ni < NI; ++ni) fw[ni] = *(const raw_t*)(st + (NA + wn * NI + ni) * 1024 + lane * 16);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) fa[mi] = *(const raw_t*)(st + (wm * MI + mi) * 1024 + lane * 16);
-        if constexpr (GATE && HALF_GATE) {
+        if (GATE && a.rowgate) {
+            // maps whose pixel count is not a multiple of 64 (240x320 input): a wave's rows straddle samples, so the
+            // gate multiplies the ACTIVATION fragments, each lane with the gate row of its own pixel's sample
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                if constexpr (HALF_GATE) {
+                    const f16x8 g8 = *(const f16x8*)((const f16_t*)gl + grow[mi] + kb * KB + kg * EPL);
+                    f16x8 a8 = __builtin_bit_cast(f16x8, fa[mi]);
+                    a8 = a8 * g8;
+                    fa[mi] = __builtin_bit_cast(raw_t, a8);
+                } else {
+                    float g[EPL], f[EPL];
+                    const float* gp = gl + grow[mi] + kb * KB + kg * EPL;
+#pragma unroll
+                    for (int e = 0; e < EPL; e += 4) load4(gp + e, g + e);
+                    to_f32(fa[mi], f);
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) f[e] *= g[e];
+                    from_f32(fa[mi], f);
+                }
+            }
+        } else if constexpr (GATE && HALF_GATE) {
             // 4 v_pk_mul_f16 per fragment instead of unpack / multiply / repack
             const f16x8 g8 = *(const f16x8*)((const f16_t*)gl + gsel * Kpad + kb * KB + kg * EPL);
 #pragma unroll
@@ -470,7 +496,9 @@ static int launch_pw_dma_mi(PwKArgs k, hipStream_t s) {
     constexpr int WM = 4 / WN, NB = MI * WM + NI * WN;
     k.MT = cdiv(k.M, 16 * MI * WM);
     const int grid = cdiv(k.MT, 8) * 8 * k.NT;
-    const size_t lds = (size_t)NS * NB * 1024 + 1024 + (GATE ? (size_t)2 * k.nkb_total * DT<T>::KB * 4 : 0);
+    k.rowgate = GATE && (k.HW % 64 != 0);
+    k.nsamp = k.rowgate ? pw_gate_nsamp(16 * MI * WM, k.HW) : 2;
+    const size_t lds = (size_t)NS * NB * 1024 + 1024 + (GATE ? (size_t)k.nsamp * k.nkb_total * DT<T>::KB * 4 : 0);
     static bool attr_set = false;
     if (!attr_set) {
         COSY_CHECK_HIP(hipFuncSetAttribute((const void*)pw_gemm_dma_kernel<T, NI, WN, NS, GATE, MI>,
@@ -536,15 +564,18 @@ static int launch_pw_t(const PwArgs& a, PwCfg c, int dtype, hipStream_t s) {
 static const char* tname(int dtype) { return dtype == COSY_F32 ? "float" : dtype == COSY_BF16 ? "__bf16" : "_Float16"; }
 static bool pw_use_dma(const PwArgs& a) {
     static const int use_dma = getenv("COSY_PW_DMA") ? atoi(getenv("COSY_PW_DMA")) : 1;
-    return use_dma && a.zeros && (!a.gate || a.HW % 64 == 0);
+    // gate rows of every sample under a 128-row m-tile sit in LDS: bound them (tiny maps fall back to pw_gemm_kernel)
+    return use_dma && a.zeros && (!a.gate || a.HW % 64 == 0 || pw_gate_nsamp(128, a.HW) <= 4);
 }
 // the kernel symbol (as rocprofv3 demangles it) that launch_pw_gemm will run for these arguments
 void pw_kernel_name(const PwArgs& a, PwCfg c, int dtype, char* buf, size_t n) {
     if (pw_use_dma(a)) {
         const int nkb = cdiv(a.K, pw_kb(dtype));
         static const int deep = getenv("COSY_PW_NS") ? atoi(getenv("COSY_PW_NS")) : 3;
-        snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, %d, %s>", tname(dtype), c.NI, c.WN, nkb <= 2 ? 2 : (deep >= 4 && nkb >= 8 ? 4 : 3),
-                 a.gate ? "true" : "false");
+        static const int mi_env = getenv("COSY_PW_MI") ? atoi(getenv("COSY_PW_MI")) : 4;
+        const int mi = (mi_env == 2 && nkb > 2 && (!a.gate || a.HW % 64 == 0)) ? 2 : 4;
+        snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, %d, %s, %d>", tname(dtype), c.NI, c.WN,
+                 nkb <= 2 ? 2 : (deep >= 4 && nkb >= 8 ? 4 : 3), a.gate ? "true" : "false", mi);
     } else {
         snprintf(buf, n, "pw_gemm_kernel<%s, %d, %d>", tname(dtype), c.NI, c.WN);
     }
