@@ -91,3 +91,20 @@ def require_device(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise CosyHipError('cosypose_amd runs on a ROCm device only (got a CPU tensor); there is no CPU fallback')
+
+
+def ints_to_device(values, device):
+    """int32 device tensor from host ids (list / numpy / CPU tensor) without draining the stream: the ids go through
+    pinned memory and a non-blocking copy, so the host keeps running ahead of the GPU (a pageable H2D copy would wait
+    for every kernel already queued on the stream).  Device tensors are only cast."""
+    import numpy as np
+    import torch
+    if values is None:
+        return None
+    if isinstance(values, torch.Tensor) and values.device.type != 'cpu':
+        return values.to(device=device, dtype=torch.int32).contiguous()
+    host = torch.as_tensor(np.ascontiguousarray(np.asarray(values.cpu() if isinstance(values, torch.Tensor) else values),
+                                                dtype=np.int32))
+    if torch.device(device).type == 'cpu' or host.numel() == 0:
+        return host.to(device)
+    return host.pin_memory().to(device, non_blocking=True)

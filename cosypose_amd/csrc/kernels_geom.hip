@@ -244,7 +244,31 @@ __device__ __forceinline__ void roi_pixel_nhwc4(const f32x4* __restrict__ img, i
     axis_taps(x1, bin_w, pw, w, tx);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     if (ty.last >= 0 && tx.last >= 0) {
-        if (ty.last - ty.first < 6 && tx.last - tx.first < 6) {
+        if (ty.last - ty.first < 4 && tx.last - tx.first < 4) {
+            // common case (bins up to ~2.6 frame pixels): a 4x4 window, all 16 loads issued back to back so that their
+            // latencies overlap; positions past `last` carry weight 0 and read a clamped (valid) address
+            float ax[4], ay[4];
+            int ox[4], oy[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                ax[d] = axis_weight(tx, tx.first + d);
+                ay[d] = axis_weight(ty, ty.first + d);
+                ox[d] = min(tx.first + d, w - 1);
+                oy[d] = min(ty.first + d, h - 1) * w;
+            }
+            f32x4 p[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) p[r][d] = img[oy[r] + ox[d]];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const float wgt = ay[r] * ax[d];
+                    a0 += wgt * p[r][d][0]; a1 += wgt * p[r][d][1]; a2 += wgt * p[r][d][2];
+                }
+        } else if (ty.last - ty.first < 6 && tx.last - tx.first < 6) {
             float ax[6];
 #pragma unroll
             for (int d = 0; d < 6; ++d) ax[d] = axis_weight(tx, tx.first + d);

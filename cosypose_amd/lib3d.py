@@ -13,7 +13,7 @@ the HIP kernels in libcosyhip.so.  Inputs/outputs are torch tensors on a ROCm de
 import torch
 
 from . import _lib
-from ._lib import lib, check, ptr, stream, require_device
+from ._lib import lib, check, ptr, stream, require_device, ints_to_device
 
 
 def _f32(t):
@@ -23,7 +23,7 @@ def _f32(t):
 def _i32(t, device):
     if t is None:
         return None
-    return torch.as_tensor(t).to(device=device, dtype=torch.int32).contiguous()
+    return ints_to_device(t, device)
 
 
 def crop_geometry(point_table, obj_ids, K, TCO, im_size, render_size, im_ids=None, lamb=1.4, z_min=0.1):

@@ -67,8 +67,9 @@ class BatchedMeshes(TensorCollection):
     # ---- device-side fast path -------------------------------------------------------------
     def object_ids(self, labels, device=None):
         """int32 row indices of `labels` in the point table."""
-        ids = torch.as_tensor(np.fromiter((self.label_to_id[l] for l in labels), dtype=np.int32, count=len(labels)))
-        return ids.to(device if device is not None else self.points.device)
+        from ._lib import ints_to_device
+        ids = np.fromiter((self.label_to_id[l] for l in labels), dtype=np.int32, count=len(labels))
+        return ints_to_device(ids, device if device is not None else self.points.device)
 
     def point_table(self, n_points=2000):
         """(n_obj, n_points, 3) fp32 contiguous on the points' device: points[:, deterministic ids]."""

@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from . import lib3d, arch
-from ._lib import lib, check, ptr, stream, require_device, CosyHipError
+from ._lib import lib, check, ptr, stream, require_device, ints_to_device, CosyHipError
 from .efficientnet import NetEngine
 
 
@@ -102,7 +102,7 @@ class PosePredictor(nn.Module):
             assert n_im == bsz and K.shape == (bsz, 3, 3)
         else:
             assert K.shape == (n_im, 3, 3) and len(im_ids) == bsz
-            im_ids = torch.as_tensor(im_ids).to(device=TCO.device, dtype=torch.int32).contiguous()
+            im_ids = ints_to_device(im_ids, TCO.device)
         images = images.detach().float().contiguous()
         K = K.detach().float().contiguous()
         dev = TCO.device

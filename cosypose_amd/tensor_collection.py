@@ -7,6 +7,7 @@ The one behavioural difference: `gather_distributed` collects ranks with a
 torch.distributed all-gather (RCCL on MI355X) instead of files on a shared disk
 (reference :142-163); see cosypose_amd/distributed.py.
 """
+import numpy as np
 import pandas as pd
 import torch
 
@@ -50,6 +51,7 @@ class TensorCollection:
             self.__dict__[name] = value
 
     def __getitem__(self, ids):
+        ids = _as_slice(ids)
         return TensorCollection(**{k: v[ids] for k, v in self._tensors.items()})
 
     def __repr__(self):
@@ -108,6 +110,7 @@ class PandasTensorCollection(TensorCollection):
         return s + '-' * 40 + '\n    infos:\n' + repr(self.infos) + '\n)'
 
     def __getitem__(self, ids):
+        ids = _as_slice(ids)
         infos = self.infos.iloc[ids].reset_index(drop=True)
         return PandasTensorCollection(infos, **super().__getitem__(ids).tensors)
 
@@ -129,6 +132,16 @@ class PandasTensorCollection(TensorCollection):
     def __setstate__(self, state):
         self.__init__(state['infos'], **state['tensors'])
         self.meta = state['meta']
+
+
+def _as_slice(ids):
+    """A run of consecutive row ids (the chunks of batched_model_predictions) as a slice: tensor views instead of
+    an index upload + one gather per field."""
+    if isinstance(ids, np.ndarray) and ids.ndim == 1 and ids.dtype.kind in 'iu' and len(ids) > 0:
+        first = int(ids[0])
+        if first >= 0 and int(ids[-1]) - first + 1 == len(ids) and (len(ids) < 2 or bool(np.all(np.diff(ids) == 1))):
+            return slice(first, first + len(ids))
+    return ids
 
 
 def concatenate(datas):
