@@ -159,10 +159,15 @@ def main():
     profile = not args.no_profile
     sync()
     t0 = time.perf_counter()
+    host_ms = []
     for _ in range(args.steps):
+        th = time.perf_counter()
         step()
+        host_ms.append((time.perf_counter() - th) * 1e3)   # host enqueue time of the step (the GPU runs behind)
     sync()
     dt = time.perf_counter() - t0
+    if args.layers and rank == 0:
+        print('host enqueue ms/step: ' + ' '.join(f'{v:.2f}' for v in host_ms), file=sys.stderr)
     if world > 1:
         t = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

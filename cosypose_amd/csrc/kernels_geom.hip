@@ -211,19 +211,23 @@ int launch_frames_to_nhwc4(const float* images, float* out, int N, int h, int w,
 // One axis of the 4 roi_align sample points of an output pixel (torchvision 0.4.2 rules, see roi_pixel):
 // validity, clamped low/high pixel and the two bilinear weights of every sample.
 struct AxisTaps { int lo[4], hi[4]; float wl[4], wh[4]; int first, last; };
+// sample i (0..3) of output position p along one axis; returns validity (weights are 0 when invalid)
+__device__ __forceinline__ bool axis_sample(float start, float bin, int p, int size, int i, int& lo, int& hi, float& wl, float& wh) {
+    float c = start + p * bin + ((float)i + .5f) * bin / 4.f;
+    const bool valid = c >= -1.0f && c <= (float)size;   // NaN coordinates (non-finite poses) count as outside
+    if (!valid || c <= 0) c = 0;
+    lo = (int)c;
+    if (lo >= size - 1) { hi = lo = size - 1; c = (float)lo; } else hi = lo + 1;
+    const float l = c - lo, h = 1.f - l;
+    wl = valid ? h : 0.f; wh = valid ? l : 0.f;
+    return valid;
+}
 __device__ __forceinline__ void axis_taps(float start, float bin, int p, int size, AxisTaps& t) {
     t.first = 0x7fffffff; t.last = -1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        float c = start + p * bin + ((float)i + .5f) * bin / 4.f;
-        const bool valid = c >= -1.0f && c <= (float)size;   // NaN coordinates (non-finite poses) count as outside
-        if (!valid || c <= 0) c = 0;
-        int lo = (int)c, hi;
-        if (lo >= size - 1) { hi = lo = size - 1; c = (float)lo; } else hi = lo + 1;
-        const float l = c - lo, h = 1.f - l;
-        t.lo[i] = lo; t.hi[i] = hi;
-        t.wl[i] = valid ? h : 0.f; t.wh[i] = valid ? l : 0.f;
-        if (valid) { t.first = lo < t.first ? lo : t.first; t.last = hi > t.last ? hi : t.last; }
+        const bool valid = axis_sample(start, bin, p, size, i, t.lo[i], t.hi[i], t.wl[i], t.wh[i]);
+        if (valid) { t.first = t.lo[i] < t.first ? t.lo[i] : t.first; t.last = t.hi[i] > t.last ? t.hi[i] : t.last; }
     }
 }
 __device__ __forceinline__ float axis_weight(const AxisTaps& t, int q) {
@@ -285,17 +289,24 @@ __device__ __forceinline__ void roi_pixel_nhwc4(const f32x4* __restrict__ img, i
                     }
             }
         } else {
+            // huge bins: the plain 16-sample loop.  Taps are recomputed per sample (no dynamically indexed arrays:
+            // those would push the tap tables of every path into scratch)
 #pragma unroll 1
-            for (int iy = 0; iy < 4; ++iy)
+            for (int iy = 0; iy < 4; ++iy) {
+                int ylo, yhi; float ywl, ywh;
+                axis_sample(y1, bin_h, ph, h, iy, ylo, yhi, ywl, ywh);
 #pragma unroll 1
                 for (int ix = 0; ix < 4; ++ix) {
-                    const f32x4 p1 = img[(size_t)ty.lo[iy] * w + tx.lo[ix]], p2 = img[(size_t)ty.lo[iy] * w + tx.hi[ix]];
-                    const f32x4 p3 = img[(size_t)ty.hi[iy] * w + tx.lo[ix]], p4 = img[(size_t)ty.hi[iy] * w + tx.hi[ix]];
-                    const float w1 = ty.wl[iy] * tx.wl[ix], w2 = ty.wl[iy] * tx.wh[ix], w3 = ty.wh[iy] * tx.wl[ix], w4 = ty.wh[iy] * tx.wh[ix];
+                    int xlo, xhi; float xwl, xwh;
+                    axis_sample(x1, bin_w, pw, w, ix, xlo, xhi, xwl, xwh);
+                    const f32x4 p1 = img[(size_t)ylo * w + xlo], p2 = img[(size_t)ylo * w + xhi];
+                    const f32x4 p3 = img[(size_t)yhi * w + xlo], p4 = img[(size_t)yhi * w + xhi];
+                    const float w1 = ywl * xwl, w2 = ywl * xwh, w3 = ywh * xwl, w4 = ywh * xwh;
                     a0 += w1 * p1[0] + w2 * p2[0] + w3 * p3[0] + w4 * p4[0];
                     a1 += w1 * p1[1] + w2 * p2[1] + w3 * p3[1] + w4 * p4[1];
                     a2 += w1 * p1[2] + w2 * p2[2] + w3 * p3[2] + w4 * p4[2];
                 }
+            }
         }
     }
     acc[0] = a0 / 16.f; acc[1] = a1 / 16.f; acc[2] = a2 / 16.f;
