@@ -34,6 +34,11 @@ _SIGNATURES = {
     'cosy_tco_init_from_boxes': ([_P, _P, _P, _I, _F, _P, _P], _I),
     'cosy_tco_init_zup_autodepth': ([_P, _P, _P, _P, _P, _I, _I, _P, _P], _I),
     'cosy_scatter_argmin': ([_P, _P, _I, _I, _P, _P], _I),
+    'cosy_expand_ids_for_symmetry': ([_P, _I, _P, _P, _P, _P], _I),
+    'cosy_symmetric_distance': ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P], _I),
+    'cosy_loss_co_symmetric': ([_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P], _I),
+    'cosy_loss_refiner_disentangled': ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P], _I),
+    'cosy_dists_add': ([_P, _P, _P, _P, _I, _I, _I, _P, _P], _I),
 }
 EXPORTS = tuple(_SIGNATURES)
 

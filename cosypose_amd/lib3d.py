@@ -9,6 +9,7 @@ the HIP kernels in libcosyhip.so.  Inputs/outputs are torch tensors on a ROCm de
                              = update_pose                                  cosypose/models/pose.py:69-79
   TCO_init_from_boxes, TCO_init_from_boxes_zup_autodepth                    cosypose/lib3d/cosypose_ops.py:121-173
   scatter_argmin                                                             cosypose/lib3d/symmetric_distances.py:13-16
+  loss_CO_symmetric, loss_refiner_CO_disentangled (forward values)           cosypose/lib3d/cosypose_ops.py:34-82
 """
 import torch
 
@@ -100,3 +101,33 @@ def scatter_argmin(dists, ids_expand, n_segments=None):
     out = torch.empty(n_segments, dtype=torch.int32, device=dists.device)
     check(lib().cosy_scatter_argmin(ptr(dists), ptr(ids), dists.shape[0], n_segments, ptr(out), stream()))
     return out
+
+
+def loss_CO_symmetric(TCO_possible_gt, TCO_pred, points):
+    """Forward value of the reference's loss_CO_symmetric with l1 (cosypose_ops.py:34-46): (loss (B,), TCO_assign (B,4,4)).
+    No autograd graph is built (the training step, SURVEY 8a-13, is not part of this library yet)."""
+    bsz = TCO_possible_gt.shape[0]
+    assert TCO_possible_gt.dim() == 4 and TCO_possible_gt.shape[-2:] == (4, 4)
+    assert TCO_pred.shape == (bsz, 4, 4)
+    assert points.dim() == 3 and points.shape[0] == bsz and points.shape[-1] == 3
+    require_device(TCO_possible_gt, TCO_pred, points)
+    gt, pred, pts = _f32(TCO_possible_gt), _f32(TCO_pred), _f32(points)
+    loss = torch.empty(bsz, device=gt.device)
+    assign = torch.empty(bsz, 4, 4, device=gt.device)
+    check(lib().cosy_loss_co_symmetric(ptr(gt), ptr(pred), ptr(pts), None, bsz, gt.shape[1], pts.shape[1], ptr(loss), None,
+                                       ptr(assign), stream()))
+    return loss, assign
+
+
+def loss_refiner_CO_disentangled(TCO_possible_gt, TCO_input, refiner_outputs, K_crop, points):
+    """Forward value of the refiner's disentangled loss (cosypose_ops.py:49-82): (B,)."""
+    bsz = TCO_possible_gt.shape[0]
+    assert TCO_input.shape == (bsz, 4, 4) and refiner_outputs.shape == (bsz, 9) and K_crop.shape == (bsz, 3, 3)
+    assert points.dim() == 3 and points.shape[0] == bsz and points.shape[-1] == 3
+    assert TCO_possible_gt.dim() == 4 and TCO_possible_gt.shape[-2:] == (4, 4)
+    require_device(TCO_possible_gt, TCO_input, refiner_outputs, K_crop, points)
+    gt, Ti, out9, K, pts = (_f32(t) for t in (TCO_possible_gt, TCO_input, refiner_outputs, K_crop, points))
+    loss = torch.empty(bsz, device=gt.device)
+    check(lib().cosy_loss_refiner_disentangled(ptr(gt), ptr(Ti), ptr(out9), ptr(K), ptr(pts), None, bsz, gt.shape[1], pts.shape[1],
+                                               ptr(loss), stream()))
+    return loss

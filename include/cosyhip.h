@@ -140,6 +140,38 @@ int cosy_tco_init_zup_autodepth(const float* boxes, const float* pts_table, cons
  * ids (M) int32 on the device. */
 int cosy_scatter_argmin(const float* dists, const int* ids, int M, int n_seg, int* out, cosy_stream_t stream);
 
+/* expand_ids_for_symmetry (cosypose/csrc/cosypose_cext.cpp:247-259): for item n (in order), for k < n_sym_item[n]:
+ * ids_expand[m] = n, sym_ids[m] = k.  n_sym_item (B) int32 = n_symmetries[labels[n]] (the label lookup is the caller's
+ * dict).  The caller sizes the outputs with M = sum(n_sym_item); *total (optional, device) receives M. */
+int cosy_expand_ids_for_symmetry(const int* n_sym_item, int B, int* ids_expand, int* sym_ids, int* total, cosy_stream_t stream);
+
+/* ---- symmetric pose distances / losses' argmin / ADD(-S) (fp32; index outputs follow the reference's tie rule) ----
+ * Points come from a per-object table pts_table (n_obj,P,3) indexed by obj_id (B) int32; obj_id == NULL means the
+ * table is already per sample, (B,P,3) -- the layout the reference passes.
+ *
+ * cosy_symmetric_distance: symmetric_distance_batched (mode 0) / symmetric_distance_batched_fast (mode 1),
+ * cosypose/lib3d/symmetric_distances.py:19-57.  sym_table (n_obj,S,4,4) is the identity-padded symmetry table,
+ * n_sym (n_obj) the real counts (mode 0 scans only those, like expand_ids_for_symmetry + scatter_argmin: strict <,
+ * first wins; mode 1 scans all S rows and takes the first minimum of the mean SQUARED distance, like argmin).
+ * -> min_dists (B), best_sym (B) int32, S12 (B,4,4) = sym_table[obj, best]. */
+int cosy_symmetric_distance(const float* T1, const float* T2, const int* obj_id, const float* pts_table, const float* sym_table,
+                            const int* n_sym, int B, int P, int S, int mode, float* min_dists, int* best_sym, float* S12,
+                            cosy_stream_t stream);
+/* loss_CO_symmetric with l1 (cosypose/lib3d/cosypose_ops.py:34-46), forward value: per sample the minimum over the S
+ * possible ground truths of mean |pred points - gt points| (first minimum wins, torch.min) -> loss (B), min_id (B)
+ * int32 (optional), TCO_assign (B,4,4) (optional). */
+int cosy_loss_co_symmetric(const float* TCO_possible_gt, const float* TCO_pred, const float* pts_table, const int* obj_id, int B,
+                           int S, int P, float* loss, int* min_id, float* TCO_assign, cosy_stream_t stream);
+/* loss_refiner_CO_disentangled (cosypose_ops.py:49-82), forward value -> loss (B). */
+int cosy_loss_refiner_disentangled(const float* TCO_possible_gt, const float* TCO_input, const float* refiner_outputs,
+                                   const float* K_crop, const float* pts_table, const int* obj_id, int B, int S, int P, float* loss,
+                                   cosy_stream_t stream);
+/* dists_add (symmetric = 0) / dists_add_symmetric (symmetric = 1), cosypose/lib3d/distances.py:5-21 -> dists (B,P,3):
+ * gt point minus predicted point (ADD), or minus the NEAREST predicted point (ADD-S; first minimum of the squared
+ * distance wins). */
+int cosy_dists_add(const float* TXO_pred, const float* TXO_gt, const float* pts_table, const int* obj_id, int B, int P,
+                   int symmetric, float* dists, cosy_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,7 @@ def lib():
         _lib.cosy_oracle_b3_param_count.restype = ctypes.c_long
         _lib.cosy_oracle_b3_forward.restype = ctypes.c_int
         _lib.cosy_oracle_scatter_argmin.restype = ctypes.c_int
+        _lib.cosy_oracle_expand_ids_for_symmetry.restype = ctypes.c_int
     return _lib
 
 
@@ -190,6 +191,50 @@ def scatter_argmin(dists, ids, n_seg):
     out = np.empty(n_seg, np.int32)
     rc = lib().cosy_oracle_scatter_argmin(dp, ip, dists.shape[0], out.ctypes.data_as(ctypes.c_void_p), int(n_seg))
     assert rc == 0
+    return out
+
+
+def expand_ids_for_symmetry(n_sym_item):
+    n, npp = _i(n_sym_item)
+    M = int(n.sum())
+    a = np.empty(M, np.int32); b = np.empty(M, np.int32)
+    m = lib().cosy_oracle_expand_ids_for_symmetry(npp, n.shape[0], a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p))
+    assert m == M
+    return a, b
+
+
+def symmetric_distance(T1, T2, obj, pts, sym, n_sym, fast=False):
+    """-> (min_dists (B,), best_sym (B,) int32, S12 (B,4,4)); fast=False: symmetric_distance_batched, True: ..._fast"""
+    T1, t1 = _f(T1); T2, t2 = _f(T2); obj, op = _i(obj); pts, pp = _f(pts); sym, sp = _f(sym); n_sym, npp = _i(n_sym)
+    B, P, S = T1.shape[0], pts.shape[1], sym.shape[1]
+    d = np.empty(B, np.float32); best = np.empty(B, np.int32); S12 = np.empty((B, 4, 4), np.float32)
+    lib().cosy_oracle_symmetric_distance(t1, t2, op, pp, sp, npp, B, P, S, int(bool(fast)), d.ctypes.data_as(ctypes.c_void_p),
+                                         best.ctypes.data_as(ctypes.c_void_p), S12.ctypes.data_as(ctypes.c_void_p))
+    return d, best, S12
+
+
+def loss_co_symmetric(gt, pred, points):
+    gt, gp = _f(gt); pred, pp = _f(pred); points, ptp = _f(points)
+    B, S, P = gt.shape[0], gt.shape[1], points.shape[1]
+    loss = np.empty(B, np.float32); mid = np.empty(B, np.int32); assign = np.empty((B, 4, 4), np.float32)
+    lib().cosy_oracle_loss_co_symmetric(gp, pp, ptp, B, S, P, loss.ctypes.data_as(ctypes.c_void_p), mid.ctypes.data_as(ctypes.c_void_p),
+                                        assign.ctypes.data_as(ctypes.c_void_p))
+    return loss, mid, assign
+
+
+def loss_refiner_disentangled(gt, TCO_in, out9, K_crop, points):
+    gt, gp = _f(gt); TCO_in, tp = _f(TCO_in); out9, op = _f(out9); K_crop, kp = _f(K_crop); points, ptp = _f(points)
+    B, S, P = gt.shape[0], gt.shape[1], points.shape[1]
+    loss = np.empty(B, np.float32)
+    lib().cosy_oracle_loss_refiner_disentangled(gp, tp, op, kp, ptp, B, S, P, loss.ctypes.data_as(ctypes.c_void_p))
+    return loss
+
+
+def dists_add(pred, gt, points, symmetric=False):
+    pred, pp = _f(pred); gt, gp = _f(gt); points, ptp = _f(points)
+    B, P = points.shape[:2]
+    out = np.empty((B, P, 3), np.float32)
+    lib().cosy_oracle_dists_add(pp, gp, ptp, B, P, int(bool(symmetric)), out.ctypes.data_as(ctypes.c_void_p))
     return out
 
 

@@ -20,6 +20,12 @@ def golden():
 
 
 @pytest.fixture(scope='session')
+def golden_dist():
+    """distance-op fixtures (symmetric distances, loss argmin, ADD/ADD-S) generated from the reference's Python"""
+    return dict(np.load(REPO / 'tests' / 'golden' / 'reference_golden_dist.npz', allow_pickle=False))
+
+
+@pytest.fixture(scope='session')
 def oracle():
     import cosy_oracle
     cosy_oracle.build()

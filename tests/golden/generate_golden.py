@@ -230,14 +230,94 @@ def g_cext(out):
     out['cext_expand_nsym'] = np.array([n_sym[l] for l in labels], np.int32)
 
 
+def _rand_poses(rs, n, t_scale=0.05, z=0.8):
+    """random rigid transforms (n,4,4) float32: QR rotations (det +1), translations in front of the camera"""
+    T = np.tile(np.eye(4, dtype=np.float32), (n, 1, 1))
+    for i in range(n):
+        q, r = np.linalg.qr(rs.randn(3, 3))
+        q = q * np.sign(np.diag(r))
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        T[i, :3, :3] = q.astype(np.float32)
+        T[i, :3, 3] = (rs.randn(3) * t_scale + np.array([0, 0, z])).astype(np.float32)
+    return T
+
+
+def g_distances(out):
+    """a-12 / 8f-2: symmetric distances, loss_CO_symmetric argmin, the refiner's disentangled loss (forward), ADD / ADD-S
+    point distances -- outputs of the reference's lib3d/symmetric_distances.py, cosypose_ops.py and distances.py."""
+    sys.path.insert(0, str(REPO / 'oracle' / '_ref'))
+    import cosypose_cext  # noqa: F401  (the reference imports it at module load)
+    from cosypose.lib3d.rigid_mesh_database import BatchedMeshes
+    from cosypose.lib3d import symmetric_distances as sdist
+    from cosypose.lib3d import cosypose_ops as cops
+    from cosypose.lib3d import distances as dst
+    rs = np.random.RandomState(77)
+    n_obj, P, S = 4, 257, 4
+    n_sym = np.array([1, 2, 4, 3], np.int32)
+    labels_all = [f'obj_{i:06d}' for i in range(1, n_obj + 1)]
+    pts = (rs.uniform(-1, 1, (n_obj, P, 3)) * rs.uniform(0.03, 0.12, (n_obj, 1, 3))).astype(np.float32)
+    sym = np.tile(np.eye(4, dtype=np.float32), (n_obj, S, 1, 1))
+    for o in range(n_obj):
+        for k in range(1, n_sym[o]):                     # discrete rotations about z + a small offset: distinct symmetries
+            a = 2 * np.pi * k / n_sym[o]
+            sym[o, k, :3, :3] = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+            sym[o, k, :3, 3] = (rs.randn(3) * 0.002).astype(np.float32)
+    infos = {l: dict(label=l, n_points=P, n_sym=int(n_sym[i])) for i, l in enumerate(labels_all)}
+    mesh_db = BatchedMeshes(infos, np.array(labels_all), torch.from_numpy(pts), torch.from_numpy(sym)).float()
+    B = 9
+    obj = rs.randint(0, n_obj, B).astype(np.int32); obj[:4] = [0, 1, 2, 3]
+    labels = np.array(labels_all)[obj]
+    T2 = _rand_poses(rs, B)
+    T1 = T2.copy()
+    for b in range(B):      # T1 = T2 . (some symmetry of the object) . small perturbation -> a non-trivial best symmetry
+        k = rs.randint(0, n_sym[obj[b]])
+        d = _rand_poses(rs, 1, t_scale=0.003, z=0.0)[0]
+        d[:3, :3] = np.eye(3, dtype=np.float32) + 0.02 * rs.randn(3, 3).astype(np.float32)
+        T1[b] = (T2[b] @ np.linalg.inv(sym[obj[b], k]) @ d).astype(np.float32)
+    out['sd_pts'] = pts; out['sd_sym'] = sym; out['sd_nsym'] = n_sym; out['sd_obj'] = obj; out['sd_T1'] = T1; out['sd_T2'] = T2
+    with torch.no_grad():
+        d0, S0 = sdist.symmetric_distance_batched(torch.from_numpy(T1), torch.from_numpy(T2), labels, mesh_db)
+        d1, S1 = sdist.symmetric_distance_batched_fast(torch.from_numpy(T1), torch.from_numpy(T2), labels, mesh_db)
+    out['sd_batched_dists'] = d0.numpy(); out['sd_batched_S12'] = S0.numpy()
+    out['sd_fast_dists'] = d1.numpy(); out['sd_fast_S12'] = S1.numpy()
+
+    # loss_CO_symmetric / loss_refiner_CO_disentangled (cosypose_ops.py:34-82)
+    points = torch.from_numpy(pts[obj])                                     # (B,P,3)
+    gt = torch.from_numpy(T2).unsqueeze(1) @ torch.from_numpy(sym[obj])      # (B,S,4,4) possible GTs = T . S_k
+    pred = torch.from_numpy(T1)
+    with torch.no_grad():
+        loss, assign = cops.loss_CO_symmetric(gt, pred, points)
+    out['lc_gt'] = gt.numpy(); out['lc_pred'] = pred.numpy(); out['lc_loss'] = loss.numpy(); out['lc_assign'] = assign.numpy()
+    refiner_outputs = torch.from_numpy((rs.randn(B, 9) * 0.1 + np.array([1, 0, 0, 0, 1, 0, 0, 0, 1])).astype(np.float32))
+    K_crop = torch.from_numpy(np.tile(np.array([[600., 0, 160], [0, 610., 120], [0, 0, 1]], np.float32), (B, 1, 1)))
+    with torch.no_grad():
+        ld = cops.loss_refiner_CO_disentangled(gt, pred, refiner_outputs, K_crop, points)
+    out['lc_refiner_outputs'] = refiner_outputs.numpy(); out['lc_K_crop'] = K_crop.numpy(); out['lc_disentangled'] = ld.numpy()
+
+    # ADD / ADD-S point distances (distances.py:5-21)
+    with torch.no_grad():
+        da = dst.dists_add(pred, torch.from_numpy(T2), points)
+        ds = dst.dists_add_symmetric(pred, torch.from_numpy(T2), points)
+    out['add_dists'] = da.numpy(); out['adds_dists'] = ds.numpy()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=str(HERE / 'reference_golden.npz'))
+    ap.add_argument('--dist-out', default=str(HERE / 'reference_golden_dist.npz'))
+    ap.add_argument('--only-dist', action='store_true', help='only (re)generate the distance-op fixtures')
     args = ap.parse_args()
     assert REF.exists(), 'reference checkout not mounted; goldens can only be generated in the build container'
     install_stubs()
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    dist = {}
+    g_distances(dist)
+    np.savez_compressed(args.dist_out, **dist)
+    print('wrote', args.dist_out, os.path.getsize(args.dist_out) / 1e6, 'MB,', len(dist), 'arrays')
+    if args.only_dist:
+        return
     out = {}
     sd = syn.golden_state_dict(0)
     n_obj = 21

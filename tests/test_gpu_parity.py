@@ -331,3 +331,101 @@ def test_full_batch_properties(model, labels21, dtype):
     perm = rs.permutation(B)
     assert torch.equal(run(perm), a[perm])                                # (3)
     model.compute_dtype = 'fp32'; model.render_size = (240, 320)
+
+
+# ---------------------------------------------------------------------------------------------
+# symmetric distances / loss argmin / ADD(-S)  
+# ---------------------------------------------------------------------------------------------
+DIST_TOL = 1e-5   # relative; per-point values are bit-identical, the P-term sums run in a different order
+
+
+def _dist_mesh_db(g):
+    from cosypose_amd.mesh_db import BatchedMeshes
+    n_obj = g['sd_pts'].shape[0]
+    labels = np.array([f'obj_{i:06d}' for i in range(1, n_obj + 1)])
+    infos = {l: dict(label=l, n_points=g['sd_pts'].shape[1], n_sym=int(g['sd_nsym'][i])) for i, l in enumerate(labels)}
+    return BatchedMeshes(infos, labels, torch.from_numpy(g['sd_pts']), torch.from_numpy(g['sd_sym'])).float().cuda(), labels
+
+
+@pytest.mark.parametrize('name,fast', [('batched', False), ('fast', True)])
+def test_symmetric_distance_vs_reference_and_oracle(oracle, golden_dist, name, fast):
+    from cosypose_amd import symmetric_distances as sd
+    g = golden_dist
+    mesh_db, labels = _dist_mesh_db(g)
+    fn = sd.symmetric_distance_batched_fast if fast else sd.symmetric_distance_batched
+    d, S12 = fn(dev(g['sd_T1']), dev(g['sd_T2']), labels[g['sd_obj']], mesh_db)
+    assert rel_err(d.cpu().numpy(), g[f'sd_{name}_dists']) < DIST_TOL
+    assert np.array_equal(S12.cpu().numpy(), g[f'sd_{name}_S12'])          # chosen symmetry exact vs the reference
+    # larger seeded case against the oracle, incl. exact ties (identity-padded rows must lose to the first identical row)
+    rs = np.random.RandomState(5)
+    n_obj, P, S, B = 6, 1500, 8, 200
+    pts = (rs.uniform(-1, 1, (n_obj, P, 3)) * 0.1).astype(np.float32)
+    n_sym = rs.randint(1, S + 1, n_obj).astype(np.int32)
+    sym = np.tile(np.eye(4, dtype=np.float32), (n_obj, S, 1, 1))
+    for o in range(n_obj):
+        for k in range(1, n_sym[o]):
+            a = 2 * np.pi * k / n_sym[o]
+            sym[o, k, :3, :3] = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+    obj = rs.randint(0, n_obj, B).astype(np.int32)
+    T2 = syn_poses(rs, B); T1 = np.stack([T2[b] @ sym[obj[b], rs.randint(0, n_sym[obj[b]])] for b in range(B)]).astype(np.float32)
+    T1[:, :3, 3] += (rs.randn(B, 3) * 1e-3).astype(np.float32)
+    labels2 = np.array([f'o{i}' for i in range(n_obj)])
+    from cosypose_amd.mesh_db import BatchedMeshes
+    db = BatchedMeshes({l: dict(label=l, n_sym=int(n_sym[i])) for i, l in enumerate(labels2)}, labels2, torch.from_numpy(pts),
+                       torch.from_numpy(sym)).float().cuda()
+    d, S12 = fn(dev(T1), dev(T2), labels2[obj], db)
+    d_o, best_o, S12_o = oracle.symmetric_distance(T1, T2, obj, pts, sym, n_sym, fast=fast)
+    assert rel_err(d.cpu().numpy(), d_o) < DIST_TOL
+    assert np.array_equal(S12.cpu().numpy(), S12_o)
+    d0, _ = fn(dev(T1[:0]), dev(T2[:0]), labels2[:0], db)                  # empty batch (reference :43-44)
+    assert d0.shape == (0,)
+
+
+def syn_poses(rs, n):
+    T = np.tile(np.eye(4, dtype=np.float32), (n, 1, 1))
+    for i in range(n):
+        q, r = np.linalg.qr(rs.randn(3, 3))
+        q = q * np.sign(np.diag(r))
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        T[i, :3, :3] = q
+        T[i, :3, 3] = rs.randn(3) * 0.05 + np.array([0, 0, 0.8])
+    return T
+
+
+def test_loss_argmin_and_disentangled_loss(oracle, golden_dist):
+    from cosypose_amd import lib3d
+    g = golden_dist
+    pts = g['sd_pts'][g['sd_obj']]
+    loss, assign = lib3d.loss_CO_symmetric(dev(g['lc_gt']), dev(g['lc_pred']), dev(pts))
+    assert rel_err(loss.cpu().numpy(), g['lc_loss']) < DIST_TOL
+    assert np.array_equal(assign.cpu().numpy(), g['lc_assign'])            # assigned ground truth exact vs the reference
+    ld = lib3d.loss_refiner_CO_disentangled(dev(g['lc_gt']), dev(g['lc_pred']), dev(g['lc_refiner_outputs']), dev(g['lc_K_crop']), dev(pts))
+    assert rel_err(ld.cpu().numpy(), g['lc_disentangled']) < DIST_TOL
+    assert rel_err(ld.cpu().numpy(), oracle.loss_refiner_disentangled(g['lc_gt'], g['lc_pred'], g['lc_refiner_outputs'], g['lc_K_crop'], pts)) < DIST_TOL
+
+
+def test_add_adds_bit_exact(oracle, golden_dist):
+    from cosypose_amd import distances
+    g = golden_dist
+    pts = g['sd_pts'][g['sd_obj']]
+    a = distances.dists_add(dev(g['lc_pred']), dev(g['sd_T2']), dev(pts)).cpu().numpy()
+    s = distances.dists_add_symmetric(dev(g['lc_pred']), dev(g['sd_T2']), dev(pts)).cpu().numpy()
+    assert np.array_equal(a, g['add_dists']) and np.array_equal(s, g['adds_dists'])      # vs the reference: bit-exact
+    rs = np.random.RandomState(8)                      # P > one LDS chunk, not a multiple of 256, duplicated points (ties)
+    B, P = 3, 4500
+    p = (rs.uniform(-1, 1, (B, P, 3)) * 0.1).astype(np.float32); p[:, 100:200] = p[:, :100]
+    Tp, Tg = syn_poses(rs, B), syn_poses(rs, B)
+    s = distances.dists_add_symmetric(dev(Tp), dev(Tg), dev(p)).cpu().numpy()
+    assert np.array_equal(s, oracle.dists_add(Tp, Tg, p, symmetric=True))
+
+
+def test_expand_ids_device_bit_exact(golden):
+    from cosypose_amd.symmetric_distances import expand_ids_for_symmetry_device
+    a, b = expand_ids_for_symmetry_device(torch.from_numpy(golden['cext_expand_nsym']).cuda())
+    assert np.array_equal(a.cpu().numpy(), golden['cext_expand_ids']) and np.array_equal(b.cpu().numpy(), golden['cext_sym_ids'])
+    rs = np.random.RandomState(2)
+    n = rs.randint(0, 7, 1000).astype(np.int32)       # > one scan block, zeros included
+    a, b = expand_ids_for_symmetry_device(torch.from_numpy(n).cuda())
+    assert np.array_equal(a.cpu().numpy(), np.repeat(np.arange(1000), n))
+    assert np.array_equal(b.cpu().numpy(), np.concatenate([np.arange(k) for k in n]))

@@ -107,3 +107,54 @@ def test_scatter_argmin_vs_reference_cext(oracle, golden):
         pytest.skip('cext goldens absent')
     got = oracle.scatter_argmin(golden['cext_dists'], golden['cext_ids'], len(golden['cext_argmin']))
     assert np.array_equal(got, golden['cext_argmin'])
+
+
+# ---------------------------------------------------------------------------------------------
+# symmetric distances / loss argmin / ADD(-S): the C restatement against the reference's own outputs
+# ---------------------------------------------------------------------------------------------
+DIST_TOL = 1e-5   # relative, fp32 sums over P points in a different order than torch's
+
+
+def _best_from_S12(g, key):
+    sym, obj = g['sd_sym'], g['sd_obj']
+    return np.array([int(np.argmax([np.array_equal(sym[obj[b], k], g[key][b]) for k in range(sym.shape[1])]))
+                     for b in range(len(obj))])
+
+
+def test_expand_ids_vs_reference_cext(oracle, golden):
+    a, b = oracle.expand_ids_for_symmetry(golden['cext_expand_nsym'])
+    assert np.array_equal(a, golden['cext_expand_ids']) and np.array_equal(b, golden['cext_sym_ids'])
+    # the product's host enumeration (numpy) against the same vector
+    from cosypose_amd.symmetric_distances import expand_ids_for_symmetry
+    labels = [f'l{i}' for i in range(len(golden['cext_expand_nsym']))]
+    a2, b2 = expand_ids_for_symmetry(labels, {l: int(n) for l, n in zip(labels, golden['cext_expand_nsym'])})
+    assert np.array_equal(a2, golden['cext_expand_ids']) and np.array_equal(b2, golden['cext_sym_ids'])
+    assert a2.dtype == np.int32 and b2.dtype == np.int32
+
+
+@pytest.mark.parametrize('name,fast', [('batched', False), ('fast', True)])
+def test_symmetric_distance_vs_reference(oracle, golden_dist, name, fast):
+    g = golden_dist
+    d, best, S12 = oracle.symmetric_distance(g['sd_T1'], g['sd_T2'], g['sd_obj'], g['sd_pts'], g['sd_sym'], g['sd_nsym'], fast=fast)
+    assert rel_err(d, g[f'sd_{name}_dists']) < DIST_TOL
+    assert np.array_equal(S12, g[f'sd_{name}_S12'])                       # the chosen symmetry: exact
+    assert np.array_equal(best, _best_from_S12(g, f'sd_{name}_S12'))
+    assert (best < g['sd_nsym'][g['sd_obj']]).all() and len(set(best.tolist())) > 2   # non-trivial choices
+
+
+def test_loss_argmin_and_disentangled_loss_vs_reference(oracle, golden_dist):
+    g = golden_dist
+    pts = g['sd_pts'][g['sd_obj']]
+    loss, mid, assign = oracle.loss_co_symmetric(g['lc_gt'], g['lc_pred'], pts)
+    assert rel_err(loss, g['lc_loss']) < DIST_TOL
+    assert np.array_equal(assign, g['lc_assign'])                         # assigned ground truth: exact
+    assert np.array_equal(g['lc_gt'][np.arange(len(mid)), mid], g['lc_assign'])
+    ld = oracle.loss_refiner_disentangled(g['lc_gt'], g['lc_pred'], g['lc_refiner_outputs'], g['lc_K_crop'], pts)
+    assert rel_err(ld, g['lc_disentangled']) < DIST_TOL
+
+
+def test_add_adds_vs_reference(oracle, golden_dist):
+    g = golden_dist
+    pts = g['sd_pts'][g['sd_obj']]
+    assert np.array_equal(oracle.dists_add(g['lc_pred'], g['sd_T2'], pts), g['add_dists'])
+    assert np.array_equal(oracle.dists_add(g['lc_pred'], g['sd_T2'], pts, symmetric=True), g['adds_dists'])   # nearest point: exact
