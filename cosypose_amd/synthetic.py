@@ -126,3 +126,13 @@ def make_TCO(seed, n, z_range=(0.6, 1.4), xy=0.15):
 def make_renders(seed, n, H, W):
     """Deterministic stand-in for renderer.render: (n,3,H,W) in [0,1)."""
     return np.random.RandomState(seed).random_sample((n, 3, H, W)).astype(np.float32)
+
+
+def make_training_batch(seed, B, n_obj=21, h=480, w=640):
+    """One synthetic training batch: uint8 frames (B,3,h,w), K (B,3,3), ground-truth
+    poses (B,4,4) and object ids (B,)."""
+    frames = (make_frames(seed, B, h, w) * 255).astype(np.uint8)
+    K = make_K(B, h, w)
+    TCO = make_TCO(seed + 1, B)
+    obj = np.random.RandomState(seed + 2).randint(0, n_obj, B).astype(np.int32)
+    return frames, K, TCO, obj

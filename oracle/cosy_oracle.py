@@ -371,11 +371,14 @@ class TorchRef:
             x = F.pad(x, (lo, hi, lo, hi))
         return F.conv2d(x, w, bias, stride=s, groups=groups)
 
+    train = False        # True: batch-statistics BatchNorm, running stats updated in place (momentum 0.01)
+    drop = None          # train mode: {block index: (keep_prob, (B,) 0/1 mask)} for drop_connect (efficientnet_utils.py:83-92)
+
     def _bn(self, x, p):
         F = self.torch.nn.functional
         sd = self.sd
         return F.batch_norm(x, sd[p + '.running_mean'], sd[p + '.running_var'], sd[p + '.weight'], sd[p + '.bias'],
-                            False, 0.01, 1e-3)
+                            self.train, 0.01, 1e-3)
 
     def extract_features(self, x, stages=None):
         torch = self.torch; sd = self.sd
@@ -396,6 +399,9 @@ class TorchRef:
             x = torch.sigmoid(q) * x
             x = self._bn(self._conv(x, sd[p + '_project_conv.weight'], 1, 1), p + '_bn2')
             if s == 1 and cin == cout:
+                if self.train and self.drop and i in self.drop:
+                    keep, mask = self.drop[i]
+                    x = x / keep * mask.reshape(-1, 1, 1, 1)
                 x = x + inp
             if stages is not None and i in ends:
                 stages.append(x)
@@ -411,3 +417,59 @@ class TorchRef:
             f = self.extract_features(x).flatten(2).mean(-1)
             pose = torch.nn.functional.linear(f, self.sd['pose_fc.weight'], self.sd['pose_fc.bias'])
         return f.numpy(), pose.numpy()
+
+
+    # ---- training step: train-mode forward, disentangled loss, backward -- torch-CPU autograd over the
+    # functional restatement above; pinned against the reference's own loss / gradients (tests/golden/*train*)
+    @staticmethod
+    def ortho6d(p6, torch):
+        """compute_rotation_matrix_from_ortho6d, lib3d/rotations.py:6-21"""
+        a, b = p6[:, 0:3], p6[:, 3:6]
+        x = a / torch.norm(a, p=2, dim=1, keepdim=True)
+        z = torch.cross(x, b, dim=1)
+        z = z / torch.norm(z, p=2, dim=1, keepdim=True)
+        y = torch.cross(z, x, dim=1)
+        return torch.stack((x, y, z), dim=-1)
+
+    def disentangled_loss(self, gt, TCO_in, out9, K_crop, points):
+        """loss_refiner_CO_disentangled + loss_CO_symmetric(l1), lib3d/cosypose_ops.py:34-82 -> (B,)"""
+        torch = self.torch
+
+        def tp(T, pts):   # transform_pts
+            if T.dim() == 4:
+                return (T[..., :3, :3].unsqueeze(2) @ pts.unsqueeze(1).unsqueeze(-1)).squeeze(-1) + T[..., :3, 3].unsqueeze(2)
+            return (T[:, :3, :3].unsqueeze(1) @ pts.unsqueeze(-1)).squeeze(-1) + T[:, :3, 3].unsqueeze(1)
+
+        def co_sym(pred):
+            d = (tp(pred, points).unsqueeze(1) - tp(gt, points)).flatten(-2, -1).abs().mean(-1)
+            return d.min(dim=1)[0]
+        dR = self.ortho6d(out9[:, 0:6], torch)
+        g0 = gt[:, 0]
+        orn = g0.clone(); orn[:, :3, :3] = dR @ TCO_in[:, :3, :3]
+        xy = g0.clone()
+        z_gt, z_in = g0[:, 2, [3]], TCO_in[:, 2, [3]]
+        fxfy = K_crop[:, [0, 1], [0, 1]]
+        xy[:, :2, 3] = ((out9[:, 6:8] / fxfy) + (TCO_in[:, :2, 3] / z_in.repeat(1, 2))) * z_gt.repeat(1, 2)
+        zz = g0.clone(); zz[:, [2], [3]] = out9[:, [8]] * z_in
+        return co_sym(orn) + co_sym(xy) + co_sym(zz)
+
+    def train_forward_backward(self, x, gt, TCO_in, K_crop, points, drop=None):
+        """x (B,6,H,W) network input.  -> loss (float), pose (B,9), {param name: grad}.  Running BN stats in self.sd
+        are updated in place, exactly as one nn.Module forward in train mode would."""
+        torch = self.torch
+        t = lambda a: a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a, np.float32))
+        names = [k for k in self.sd if not (k.endswith('running_mean') or k.endswith('running_var'))]
+        for k in names:
+            self.sd[k] = self.sd[k].detach().clone().requires_grad_(True)
+        self.train, self.drop = True, drop
+        try:
+            f = self.extract_features(t(x)).flatten(2).mean(-1)
+            pose = torch.nn.functional.linear(f, self.sd['pose_fc.weight'], self.sd['pose_fc.bias'])
+            loss = self.disentangled_loss(t(gt), t(TCO_in), pose, t(K_crop), t(points)).mean()
+            loss.backward()
+        finally:
+            self.train, self.drop = False, None
+        grads = {k: self.sd[k].grad.detach().numpy() for k in names}
+        for k in names:
+            self.sd[k] = self.sd[k].detach()
+        return float(loss.item()), pose.detach().numpy(), grads

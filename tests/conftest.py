@@ -26,6 +26,12 @@ def golden_dist():
 
 
 @pytest.fixture(scope='session')
+def golden_train():
+    """one reference training step (loss, pose outputs, gradients, BN running statistics, Adam update)"""
+    return dict(np.load(REPO / 'tests' / 'golden' / 'reference_golden_train.npz', allow_pickle=False))
+
+
+@pytest.fixture(scope='session')
 def oracle():
     import cosy_oracle
     cosy_oracle.build()

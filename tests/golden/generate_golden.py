@@ -302,16 +302,86 @@ def g_distances(out):
     out['add_dists'] = da.numpy(); out['adds_dists'] = ds.numpy()
 
 
+
+class _Meter:
+    def __init__(self): self.vals = []
+    def add(self, v): self.vals.append(v)
+
+
+def g_training(out):
+    """a-13: one training step of the refiner as the reference runs it (train_pose.py:317-331): h_pose forward in train
+    mode (batch-statistics BatchNorm; drop_connect forced to 0 for determinism), disentangled loss, backward,
+    clip_grad_norm_(0.5), Adam(lr=3e-4)."""
+    import types as _t
+    from collections import defaultdict
+    from cosypose.training import pose_forward_loss as pfl
+    pfl.cast = lambda x: x
+    sd = syn.golden_state_dict(0)
+    n_obj = 21
+    labels_all = np.array([f'obj_{i:06d}' for i in range(1, n_obj + 1)])
+    mesh_points = syn.make_mesh_points(7, n_obj, 2500)
+    model, mesh_db = build_ref_model(sd, mesh_points, labels_all)
+    model.renderer = FakeRenderer(900)
+    model.train()
+    model.backbone._global_params = model.backbone._global_params._replace(drop_connect_rate=0.0)
+    B = 4
+    frames, K, TCO, obj = syn.make_training_batch(61, B)
+    labels = labels_all[obj]
+    pts = torch.from_numpy(mesh_points[obj])
+    from cosypose.lib3d.camera_geometry import project_points, boxes_from_uv
+    uv = project_points(pts, torch.from_numpy(K), torch.from_numpy(TCO))
+    bboxes = boxes_from_uv(uv)
+    data = _t.SimpleNamespace(images=torch.from_numpy(frames), K=torch.from_numpy(K), TCO=torch.from_numpy(TCO),
+                              objects=[dict(name=l) for l in labels], bboxes=bboxes)
+    cfg = argparse.Namespace(n_points_loss=600, loss_disentangled=True, n_pose_dims=9, init_method='v0')
+    captured = []
+    hook = model.pose_fc.register_forward_hook(lambda m, i, o: captured.append(o.detach().clone()))
+    np.random.seed(123)                       # sample_points(deterministic=False) draws from the global numpy RNG
+    out['tr_point_ids'] = np.random.RandomState(123).choice(2500, size=600, replace=False)
+    opt = torch.optim.Adam(model.parameters(), lr=3e-4, weight_decay=0.)
+    opt.zero_grad()
+    loss = pfl.h_pose(model=model, mesh_db=mesh_db, data=data, meters=defaultdict(_Meter), cfg=cfg, n_iterations=1,
+                      input_generator='fixed')
+    loss.backward()
+    hook.remove()
+    out['tr_bboxes'] = bboxes.numpy(); out['tr_loss'] = np.float32(loss.item()); out['tr_pose'] = captured[0].numpy()
+    names = [n for n, p in model.named_parameters()]
+    out['tr_param_names'] = np.array(names)
+    out['tr_grad_norms'] = np.array([p.grad.norm().item() for n, p in model.named_parameters()], np.float32)
+    for n, p in model.named_parameters():
+        if p.numel() <= 14000:
+            out['tr_grad/' + n] = p.grad.numpy().copy()
+    bn = dict(model.named_buffers())
+    for n in ('backbone._bn0', 'backbone._blocks.0._bn1', 'backbone._blocks.10._bn0', 'backbone._blocks.25._bn2', 'backbone._bn1'):
+        out[f'tr_bn/{n}.running_mean'] = bn[n + '.running_mean'].numpy().copy()
+        out[f'tr_bn/{n}.running_var'] = bn[n + '.running_var'].numpy().copy()
+    total = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=0.5, norm_type=2)
+    out['tr_total_grad_norm'] = np.float32(float(total))
+    opt.step()
+    for n, p in model.named_parameters():
+        if p.numel() <= 2000:
+            out['tr_after_adam/' + n] = p.detach().numpy().copy()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=str(HERE / 'reference_golden.npz'))
     ap.add_argument('--dist-out', default=str(HERE / 'reference_golden_dist.npz'))
     ap.add_argument('--only-dist', action='store_true', help='only (re)generate the distance-op fixtures')
+    ap.add_argument('--train-out', default=str(HERE / 'reference_golden_train.npz'))
+    ap.add_argument('--only-train', action='store_true', help='only (re)generate the training-step fixtures')
     args = ap.parse_args()
     assert REF.exists(), 'reference checkout not mounted; goldens can only be generated in the build container'
     install_stubs()
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if not args.only_dist:
+        tr = {}
+        g_training(tr)
+        np.savez_compressed(args.train_out, **tr)
+        print('wrote', args.train_out, os.path.getsize(args.train_out) / 1e6, 'MB,', len(tr), 'arrays')
+        if args.only_train:
+            return
     dist = {}
     g_distances(dist)
     np.savez_compressed(args.dist_out, **dist)

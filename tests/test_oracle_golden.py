@@ -158,3 +158,31 @@ def test_add_adds_vs_reference(oracle, golden_dist):
     pts = g['sd_pts'][g['sd_obj']]
     assert np.array_equal(oracle.dists_add(g['lc_pred'], g['sd_T2'], pts), g['add_dists'])
     assert np.array_equal(oracle.dists_add(g['lc_pred'], g['sd_T2'], pts, symmetric=True), g['adds_dists'])   # nearest point: exact
+
+
+# ---------------------------------------------------------------------------------------------
+# training step: the torch-CPU restatement against the reference's own loss and gradients
+# ---------------------------------------------------------------------------------------------
+def grad_err(a, b, scale):
+    """max |a-b| relative to the gradient scale of the tensor's layer family"""
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / scale)
+
+
+def test_training_step_vs_reference(oracle, golden_train, golden_sd, mesh_table):
+    import train_case
+    g = golden_train
+    c = train_case.build(oracle, g, mesh_table)
+    ref = oracle.TorchRef(golden_sd)
+    loss, pose, grads = ref.train_forward_backward(c['x'], c['gt'], c['TCO_input'], c['K_crop'], c['points'])
+    assert abs(loss - float(g['tr_loss'])) < 1e-5 * abs(float(g['tr_loss']))
+    assert rel_err(pose, g['tr_pose']) < 1e-5
+    names = list(g['tr_param_names'])
+    norms = dict(zip(names, g['tr_grad_norms']))
+    for n in names:
+        mine = np.linalg.norm(grads[n].ravel())
+        assert abs(mine - norms[n]) < 2e-3 * norms[n] + 1e-8, (n, mine, norms[n])
+        if 'tr_grad/' + n in g:
+            assert grad_err(grads[n], g['tr_grad/' + n], max(norms[n], 1e-6)) < 2e-3, n
+    for k in g:
+        if k.startswith('tr_bn/'):
+            assert rel_err(ref.sd[k[len('tr_bn/'):]].numpy(), g[k]) < 1e-5, k      # running statistics after the step
