@@ -11,7 +11,7 @@ COSY_F32, COSY_BF16, COSY_F16 = 0, 1, 2
 _lib = None
 
 _c = ctypes
-_P, _I, _F, _SZ = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
+_P, _I, _F, _SZ, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t, _c.c_long
 
 _SIGNATURES = {
     'cosy_version': ([], _I),
@@ -39,6 +39,24 @@ _SIGNATURES = {
     'cosy_loss_co_symmetric': ([_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P], _I),
     'cosy_loss_refiner_disentangled': ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P], _I),
     'cosy_dists_add': ([_P, _P, _P, _P, _I, _I, _I, _P, _P], _I),
+    'cosy_train_workspace_bytes': ([], _c.c_size_t),
+    'cosy_crop_pack_to': ([_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
+    'cosy_bn_train_stats': ([_P, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P], _I),
+    'cosy_bn_train_apply': ([_P, _P, _P, _P, _P, _L, _I, _I, _P, _I, _P, _P, _P], _I),
+    'cosy_bn_train_backward': ([_P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P], _I),
+    'cosy_dw_train_forward': ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _P], _I),
+    'cosy_dw_train_backward_data': ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _P], _I),
+    'cosy_dw_train_backward_weight': ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P], _I),
+    'cosy_rows_mean': ([_P, _I, _I, _I, _P, _P], _I),
+    'cosy_rows_dot': ([_P, _P, _I, _I, _I, _P, _P], _I),
+    'cosy_rows_scale': ([_P, _P, _P, _F, _I, _I, _I, _P, _P], _I),
+    'cosy_rows_broadcast': ([_P, _F, _I, _I, _I, _P, _P], _I),
+    'cosy_act_forward': ([_P, _L, _I, _P, _P], _I),
+    'cosy_act_backward': ([_P, _P, _L, _I, _P, _P], _I),
+    'cosy_stem_im2col': ([_P, _I, _I, _I, _P, _P], _I),
+    'cosy_loss_refiner_disentangled_backward': ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P], _I),
+    'cosy_grad_norm_clip': ([_P, _L, _F, _P, _P, _P], _I),
+    'cosy_adam_step': ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P], _I),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -1,0 +1,732 @@
+// Training-step kernels of the refiner network (reference: cosypose/models/efficientnet.py:71-98,
+// efficientnet_utils.py:37-48 (Swish backward) / :83-92 (drop_connect), training/pose_forward_loss.py:17-84,
+// lib3d/cosypose_ops.py:49-82, training/train_pose.py:317-331).
+//
+// fp32 throughout (the reference trains in fp32), activations NHWC = row-major (rows = B*H*W pixels, C channels).
+// The 1x1 convolutions / linear layers and their two gradients are PLAIN GEMMs and go to rocBLAS from the host side;
+// everything else of the step is here: batch-statistics BatchNorm (+Swish) forward/backward, depthwise convolution
+// forward / data gradient / weight gradient, squeeze-excite scale and its gradients, pooling, stem im2col,
+// the disentangled loss gradient, gradient norm + clip + Adam on the flat parameter buffer.
+//
+// Per-channel reductions over rows are bandwidth-bound: lanes map to channels (coalesced rows), waves and slabs to
+// rows; every thread accumulates in double, partial sums go to a workspace and are combined in a fixed order
+// (deterministic, no atomics).
+#include "cosy_common.h"
+
+namespace cosy {
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// d/dy of y*sigmoid(y) as the reference writes it (efficientnet_utils.py:44-48)
+__device__ __forceinline__ float swish_grad(float y) {
+    const float sg = sigmoidf_(y);
+    return sg * (1.f + y * (1.f - sg));
+}
+
+struct RedGeom { int cgroups, nslab, rows_per_slab; };
+RedGeom red_geom(long M, int C) {
+    RedGeom g;
+    g.cgroups = cdiv(C, 64);
+    long target = 4096 / g.cgroups;            // ~4096 workgroups in flight at most
+    if (target < 1) target = 1;
+    long rows = cdiv(M, target);
+    if (rows < 64) rows = 64;
+    g.rows_per_slab = (int)rows;
+    g.nslab = cdiv(M, rows);
+    return g;
+}
+
+// ---- cross-wave combine of NQ per-thread double accumulators (lane = channel), result written by wave 0
+template <int NQ>
+__device__ __forceinline__ void slab_write(const double* acc, double* lds /*[4][64][NQ]*/, double* partial, int slab, int C, int c) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) lds[(wave * 64 + lane) * NQ + q] = acc[q];
+    __syncthreads();
+    if (wave == 0 && c < C) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const double v = ((lds[(0 * 64 + lane) * NQ + q] + lds[(1 * 64 + lane) * NQ + q]) + lds[(2 * 64 + lane) * NQ + q]) +
+                             lds[(3 * 64 + lane) * NQ + q];
+            partial[((size_t)slab * NQ + q) * C + c] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm, training mode
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long M, int C, int rows_per_slab,
+                                                       double* __restrict__ partial) {
+    __shared__ double lds[4 * 64 * 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, slab = blockIdx.y;
+    const long r0 = (long)slab * rows_per_slab, r1 = min(M, r0 + rows_per_slab);
+    double acc[2] = {0., 0.};
+    if (c < C)
+        for (long r = r0 + wave; r < r1; r += 4) {
+            const double v = x[r * C + c];
+            acc[0] += v; acc[1] += v * v;
+        }
+    slab_write<2>(acc, lds, partial, slab, C, c);
+}
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ partial, int nslab, long M, int C, float eps,
+                                                             float momentum, float* __restrict__ mean, float* __restrict__ rstd,
+                                                             float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0., ss = 0.;
+    for (int k = 0; k < nslab; ++k) { s += partial[((size_t)k * 2 + 0) * C + c]; ss += partial[((size_t)k * 2 + 1) * C + c]; }
+    const double m = s / (double)M;
+    double var = ss / (double)M - m * m;
+    if (var < 0.) var = 0.;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {   // nn.BatchNorm2d: running <- (1-mom) running + mom batch; the variance unbiased
+        const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+}
+
+// out = act(bn(x)) [* rowscale[b]] [+ res];  act: 0 none, 1 swish.  Vectorised over 4 channels.
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, long n4, int C4, int act,
+                                                       const float* __restrict__ rowscale, int HW, const float* __restrict__ res,
+                                                       float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c4 = (int)(i % C4);
+    const long row = i / C4;
+    const f32x4 v = ((const f32x4*)x)[i], m = ((const f32x4*)mean)[c4], r = ((const f32x4*)rstd)[c4];
+    const f32x4 g = ((const f32x4*)gamma)[c4], b = ((const f32x4*)beta)[c4];
+    const float rs = rowscale ? rowscale[row / HW] : 1.f;
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float y = (v[k] - m[k]) * r[k] * g[k] + b[k];
+        if (act == 1) y = y * sigmoidf_(y);
+        o[k] = y * rs;
+    }
+    if (res) {
+        const f32x4 q = ((const f32x4*)res)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] += q[k];
+    }
+    ((f32x4*)out)[i] = o;
+}
+
+// gradient wrt the BN output for one element: upstream * rowscale * act'(y)
+__device__ __forceinline__ float bn_dy(float dout, float xhat, float g, float b, int act, float rs) {
+    float d = dout * rs;
+    if (act == 1) d *= swish_grad(xhat * g + b);
+    return d;
+}
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, long M,
+                                                            int C, int act, const float* __restrict__ rowscale, int HW,
+                                                            int rows_per_slab, double* __restrict__ partial) {
+    __shared__ double lds[4 * 64 * 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, slab = blockIdx.y;
+    const long r0 = (long)slab * rows_per_slab, r1 = min(M, r0 + rows_per_slab);
+    double acc[2] = {0., 0.};
+    if (c < C) {
+        const float m = mean[c], rs_ = rstd[c], g = gamma[c], b = beta[c];
+        for (long r = r0 + wave; r < r1; r += 4) {
+            const float xhat = (x[r * C + c] - m) * rs_;
+            const float d = bn_dy(dout[r * C + c], xhat, g, b, act, rowscale ? rowscale[r / HW] : 1.f);
+            acc[0] += d; acc[1] += (double)d * xhat;
+        }
+    }
+    slab_write<2>(acc, lds, partial, slab, C, c);
+}
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restrict__ partial, int nslab, int C, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0., ss = 0.;
+    for (int k = 0; k < nslab; ++k) { s += partial[((size_t)k * 2 + 0) * C + c]; ss += partial[((size_t)k * 2 + 1) * C + c]; }
+    if (accumulate) { dbeta[c] += (float)s; dgamma[c] += (float)ss; } else { dbeta[c] = (float)s; dgamma[c] = (float)ss; }
+}
+// dx = gamma * rstd * (dy - sum(dy)/M - xhat * sum(dy*xhat)/M); sum_dy / sum_dyx are THIS call's sums (not accumulated grads)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ sum_dy, const float* __restrict__ sum_dyx, long n4,
+                                                           int C4, float inv_M, int act, const float* __restrict__ rowscale, int HW,
+                                                           float* __restrict__ dx) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c4 = (int)(i % C4);
+    const long row = i / C4;
+    const f32x4 v = ((const f32x4*)x)[i], d0 = ((const f32x4*)dout)[i], m = ((const f32x4*)mean)[c4], r = ((const f32x4*)rstd)[c4];
+    const f32x4 g = ((const f32x4*)gamma)[c4], b = ((const f32x4*)beta)[c4], s1 = ((const f32x4*)sum_dy)[c4], s2 = ((const f32x4*)sum_dyx)[c4];
+    const float rs = rowscale ? rowscale[row / HW] : 1.f;
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float xhat = (v[k] - m[k]) * r[k];
+        const float d = bn_dy(d0[k], xhat, g[k], b[k], act, rs);
+        o[k] = g[k] * r[k] * (d - s1[k] * inv_M - xhat * s2[k] * inv_M);
+    }
+    ((f32x4*)dx)[i] = o;
+}
+
+// ------------------------------------------------------------------------------------------
+// depthwise convolution (static "same" padding: lo = pad before), weights as (k*k, C)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wt, int H, int W, int C4,
+                                                     int Ho, int Wo, int k, int s, int lo, long n4, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c4 = (int)(i % C4);
+    long p = i / C4;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho);
+    const long b = p / Ho;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < k; ++ky) {
+        const int iy = oy * s - lo + ky;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < k; ++kx) {
+            const int ix = ox * s - lo + kx;
+            if (ix < 0 || ix >= W) continue;
+            const f32x4 v = ((const f32x4*)x)[((b * H + iy) * W + ix) * C4 + c4];
+            const f32x4 w = ((const f32x4*)wt)[(size_t)(ky * k + kx) * C4 + c4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += v[q] * w[q];
+        }
+    }
+    ((f32x4*)out)[i] = acc;
+}
+__global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ wt, int H, int W, int C4,
+                                                          int Ho, int Wo, int k, int s, int lo, long n4, float* __restrict__ dx) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c4 = (int)(i % C4);
+    long p = i / C4;
+    const int ix = (int)(p % W); p /= W;
+    const int iy = (int)(p % H);
+    const long b = p / H;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < k; ++ky) {
+        const int ty = iy + lo - ky;
+        if (ty < 0 || ty % s) continue;
+        const int oy = ty / s;
+        if (oy >= Ho) continue;
+        for (int kx = 0; kx < k; ++kx) {
+            const int tx = ix + lo - kx;
+            if (tx < 0 || tx % s) continue;
+            const int ox = tx / s;
+            if (ox >= Wo) continue;
+            const f32x4 v = ((const f32x4*)dy)[((b * Ho + oy) * Wo + ox) * C4 + c4];
+            const f32x4 w = ((const f32x4*)wt)[(size_t)(ky * k + kx) * C4 + c4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += v[q] * w[q];
+        }
+    }
+    ((f32x4*)dx)[i] = acc;
+}
+// dw[tap][c] = sum over output pixels of dy[p][c] * x[p_in(tap)][c]; lanes = channels, waves/slabs = output pixels
+template <int KK>
+__global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy, int H, int W, int C,
+                                                            int Ho, int Wo, int s, int lo, long Mo, int rows_per_slab,
+                                                            double* __restrict__ partial) {
+    constexpr int K = KK == 9 ? 3 : 5;
+    __shared__ double lds[4 * 64 * KK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, slab = blockIdx.y;
+    const long r0 = (long)slab * rows_per_slab, r1 = min(Mo, r0 + rows_per_slab);
+    double acc[KK];
+#pragma unroll
+    for (int q = 0; q < KK; ++q) acc[q] = 0.;
+    if (c < C)
+        for (long r = r0 + wave; r < r1; r += 4) {
+            const int ox = (int)(r % Wo);
+            const long t = r / Wo;
+            const int oy = (int)(t % Ho);
+            const long b = t / Ho;
+            const float d = dy[r * C + c];
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                const int iy = oy * s - lo + ky;
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const int ix = ox * s - lo + kx;
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) acc[ky * K + kx] += (double)d * x[((b * H + iy) * W + ix) * C + c];
+                }
+            }
+        }
+    slab_write<KK>(acc, lds, partial, slab, C, c);
+}
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int nslab, long n, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.;
+    for (int k = 0; k < nslab; ++k) s += partial[(size_t)k * n + i];
+    out[i] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------------
+// squeeze-excite pieces, pooling, activations
+// ------------------------------------------------------------------------------------------
+// out[b][c] = scale * sum_p f(a[b][p][c] (, a2[b][p][c]));  MODE 0: a;  MODE 1: a * a2.  One workgroup per (b, 64 channels).
+template <int MODE>
+__global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ a, const float* __restrict__ a2, int HW, int C,
+                                                          float scale, float* __restrict__ out) {
+    __shared__ double lds[4 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, b = blockIdx.y;
+    double acc = 0.;
+    if (c < C)
+        for (int p = wave; p < HW; p += 4) {
+            const size_t o = ((size_t)b * HW + p) * C + c;
+            acc += MODE == 0 ? (double)a[o] : (double)a[o] * a2[o];
+        }
+    lds[wave * 64 + lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < C)
+        out[(size_t)b * C + c] = (float)((((lds[lane] + lds[64 + lane]) + lds[128 + lane]) + lds[192 + lane]) * (double)scale);
+}
+// out = a * g[b][c] (+ add[b][c] * add_scale)
+__global__ __launch_bounds__(256) void rows_scale_kernel(const float* __restrict__ a, const float* __restrict__ g, const float* __restrict__ add,
+                                                         float add_scale, long n4, int C4, int HW, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c4 = (int)(i % C4);
+    const long b = i / C4 / HW;
+    const f32x4 v = ((const f32x4*)a)[i], gg = ((const f32x4*)g)[b * C4 + c4];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = v[k] * gg[k];
+    if (add) {
+        const f32x4 ad = ((const f32x4*)add)[b * C4 + c4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] += ad[k] * add_scale;
+    }
+    ((f32x4*)out)[i] = o;
+}
+// out[b][p][c] = v[b][c] * scale   (gradient of the mean over pixels)
+__global__ __launch_bounds__(256) void rows_broadcast_kernel(const float* __restrict__ v, float scale, long n4, int C4, int HW,
+                                                             float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c4 = (int)(i % C4);
+    const long b = i / C4 / HW;
+    f32x4 o = ((const f32x4*)v)[b * C4 + c4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] *= scale;
+    ((f32x4*)out)[i] = o;
+}
+// kind 0 swish, 1 sigmoid; bwd: dx = dy * f'(x)
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, long n, int kind, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i], sg = sigmoidf_(v);
+    out[i] = kind == 0 ? v * sg : sg;
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, long n, int kind,
+                                                      float* __restrict__ dx) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    if (kind == 0) dx[i] = dy[i] * swish_grad(v);
+    else { const float sg = sigmoidf_(v); dx[i] = dy[i] * (sg * (1.f - sg)); }
+}
+
+// stem: 3x3 stride-2 patches of the 8-channel NHWC input (6 used) as GEMM rows: cols[p][(ky*3+kx)*6 + c]
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ x8, int H, int W, int Ho, int Wo, int lo, long n,
+                                                          float* __restrict__ cols) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;   // one thread per (pixel, tap)
+    if (i >= n) return;
+    const int tap = (int)(i % 9);
+    long p = i / 9;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho);
+    const long b = p / Ho;
+    const int iy = oy * 2 - lo + tap / 3, ix = ox * 2 - lo + tap % 3;
+    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+        const float* s = x8 + ((b * H + iy) * W + ix) * 8;
+        const f32x4 a = *(const f32x4*)s;
+        const f32x2 c = *(const f32x2*)(s + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = c[0]; v[5] = c[1];
+    }
+    float* o = cols + (i / 9) * 54 + tap * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = v[k];
+}
+
+// ------------------------------------------------------------------------------------------
+// gradient of loss_refiner_CO_disentangled wrt the network outputs (B,9)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum256(float v, float* scratch) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
+}
+__device__ __forceinline__ void xform3(const float* T, float x, float y, float z, float* q) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) q[i] = T[i * 4 + 0] * x + T[i * 4 + 1] * y + T[i * 4 + 2] * z + T[i * 4 + 3];
+}
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+__device__ __forceinline__ void cross3(const float* u, const float* v, float* c) {
+    c[0] = u[1] * v[2] - u[2] * v[1]; c[1] = u[2] * v[0] - u[0] * v[2]; c[2] = u[0] * v[1] - u[1] * v[0];
+}
+
+__global__ __launch_bounds__(256) void loss_disentangled_bwd_kernel(const float* __restrict__ gt, const float* __restrict__ TCO_in,
+                                                                    const float* __restrict__ out9, const float* __restrict__ K_crop,
+                                                                    const float* __restrict__ pts, const int* __restrict__ obj, int S,
+                                                                    int P, const float* __restrict__ dloss, float* __restrict__ dout9) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* p = pts + (size_t)(obj ? obj[b] : b) * P * 3;
+    const float* g0 = gt + (size_t)b * S * 16;
+    float Ti[16], o[9], G[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { Ti[i] = TCO_in[(size_t)b * 16 + i]; G[i] = g0[i]; }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o[i] = out9[(size_t)b * 9 + i];
+    const float fx = K_crop[(size_t)b * 9], fy = K_crop[(size_t)b * 9 + 4];
+    // forward pieces of ortho6d
+    const float a[3] = {o[0], o[1], o[2]}, bb[3] = {o[3], o[4], o[5]};
+    const float na = sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    const float x[3] = {a[0] / na, a[1] / na, a[2] / na};
+    float w[3]; cross3(x, bb, w);
+    const float nw = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    const float z[3] = {w[0] / nw, w[1] / nw, w[2] / nw};
+    float y[3]; cross3(z, x, y);
+    const float dR[9] = {x[0], y[0], z[0], x[1], y[1], z[1], x[2], y[2], z[2]};
+
+    float grad[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) grad[i] = 0.f;
+    float GdR[9];   // dL/d dR
+#pragma unroll
+    for (int i = 0; i < 9; ++i) GdR[i] = 0.f;
+    const float inv = 1.f / (float)(3 * P);
+#pragma unroll 1
+    for (int t = 0; t < 3; ++t) {
+        float pr[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pr[i] = G[i];
+        if (t == 0) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) pr[i * 4 + j] = dR[i * 3 + 0] * Ti[0 * 4 + j] + dR[i * 3 + 1] * Ti[1 * 4 + j] + dR[i * 3 + 2] * Ti[2 * 4 + j];
+        } else if (t == 1) {
+            pr[3] = (o[6] / fx + Ti[3] / Ti[11]) * G[11];
+            pr[7] = (o[7] / fy + Ti[7] / Ti[11]) * G[11];
+        } else {
+            pr[11] = o[8] * Ti[11];
+        }
+        // the assigned ground truth of this term: first minimum of the mean L1 (as the forward does)
+        int arg = 0; float best = 0.f;
+        for (int s = 0; s < S; ++s) {
+            float gsm[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) gsm[i] = g0[(size_t)s * 16 + i];
+            float acc = 0.f;
+            for (int i = tid; i < P; i += 256) {
+                float q1[3], q2[3];
+                xform3(pr, p[i * 3], p[i * 3 + 1], p[i * 3 + 2], q1);
+                xform3(gsm, p[i * 3], p[i * 3 + 1], p[i * 3 + 2], q2);
+                acc += fabsf(q1[0] - q2[0]) + fabsf(q1[1] - q2[1]) + fabsf(q1[2] - q2[2]);
+            }
+            const float l = block_sum256(acc, red);
+            if (s == 0 || l < best) { best = l; arg = s; }
+        }
+        float gsm[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gsm[i] = g0[(size_t)arg * 16 + i];
+        // sums over the points of sign(pred - gt) (x point coordinates for the rotation term)
+        float s9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s3[3] = {0.f, 0.f, 0.f};
+        for (int i = tid; i < P; i += 256) {
+            const float px = p[i * 3], py = p[i * 3 + 1], pz = p[i * 3 + 2];
+            float q1[3], q2[3];
+            xform3(pr, px, py, pz, q1);
+            xform3(gsm, px, py, pz, q2);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float sg = sgn(q1[r] - q2[r]);
+                s3[r] += sg;
+                if (t == 0) { s9[r * 3 + 0] += sg * px; s9[r * 3 + 1] += sg * py; s9[r * 3 + 2] += sg * pz; }
+            }
+        }
+        if (t == 0) {
+            float GRp[9];   // dL/d(dR Rin)
+#pragma unroll
+            for (int q = 0; q < 9; ++q) GRp[q] = block_sum256(s9[q], red) * inv;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) GdR[i * 3 + k] = GRp[i * 3 + 0] * Ti[k * 4 + 0] + GRp[i * 3 + 1] * Ti[k * 4 + 1] + GRp[i * 3 + 2] * Ti[k * 4 + 2];
+        } else if (t == 1) {
+            const float gx = block_sum256(s3[0], red) * inv, gy = block_sum256(s3[1], red) * inv;
+            grad[6] = gx * G[11] / fx;
+            grad[7] = gy * G[11] / fy;
+        } else {
+            grad[8] = block_sum256(s3[2], red) * inv * Ti[11];
+        }
+    }
+    // ortho6d backward: R = [x y z] columns; x = a/|a|, w = x x b, z = w/|w|, y = z x x
+    const float gx[3] = {GdR[0], GdR[3], GdR[6]}, gy[3] = {GdR[1], GdR[4], GdR[7]}, gz[3] = {GdR[2], GdR[5], GdR[8]};
+    float t1[3], t2[3];
+    cross3(x, gy, t1);                       // dz from y = z x x
+    cross3(gy, z, t2);                       // dx from y = z x x
+    const float gz_t[3] = {gz[0] + t1[0], gz[1] + t1[1], gz[2] + t1[2]};
+    const float zd = z[0] * gz_t[0] + z[1] * gz_t[1] + z[2] * gz_t[2];
+    const float dw[3] = {(gz_t[0] - z[0] * zd) / nw, (gz_t[1] - z[1] * zd) / nw, (gz_t[2] - z[2] * zd) / nw};
+    float t3[3], db[3];
+    cross3(bb, dw, t3);                      // dx from w = x x b
+    cross3(dw, x, db);                       // db
+    const float gx_t[3] = {gx[0] + t2[0] + t3[0], gx[1] + t2[1] + t3[1], gx[2] + t2[2] + t3[2]};
+    const float xd = x[0] * gx_t[0] + x[1] * gx_t[1] + x[2] * gx_t[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { grad[i] = (gx_t[i] - x[i] * xd) / na; grad[3 + i] = db[i]; }
+    if (tid == 0) {
+        const float up = dloss[b];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) dout9[(size_t)b * 9 + i] = grad[i] * up;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// optimizer on the flat buffers: squared gradient norm, clip + Adam
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, long n, double* __restrict__ partial) {
+    __shared__ double lds[256];
+    double acc = 0.;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc += (double)g[i] * g[i];
+    lds[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) lds[threadIdx.x] += lds[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = lds[0];
+}
+__global__ __launch_bounds__(256) void sqnorm_final_kernel(const double* __restrict__ partial, int nparts, float max_norm, float* __restrict__ out /*[norm, clip_coef]*/) {
+    __shared__ double lds[256];
+    double acc = 0.;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += partial[i];
+    lds[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) lds[threadIdx.x] += lds[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt(lds[0]);
+        out[0] = norm;
+        const float coef = max_norm / (norm + 1e-6f);     // torch.nn.utils.clip_grad_norm_
+        out[1] = max_norm > 0.f ? (coef < 1.f ? coef : 1.f) : 1.f;
+    }
+}
+// torch.optim.Adam (amsgrad off): g <- clip*g (+ wd*p); m, v moments; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
+                                                   float bc1, float bc2_sqrt, const float* __restrict__ clip /*[norm, coef]*/) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i] * (clip ? clip[1] : 1.f);
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+}
+
+}  // namespace
+}  // namespace cosy
+
+using namespace cosy;
+
+#define LAUNCH1D(kernel, n, s, ...)                                                            \
+    do {                                                                                       \
+        hipLaunchKernelGGL(kernel, dim3((unsigned)cdiv((n), 256)), dim3(256), 0, s, __VA_ARGS__); \
+        COSY_CHECK_HIP(hipGetLastError());                                                     \
+    } while (0)
+
+extern "C" {
+
+size_t cosy_train_workspace_bytes(void) { return (size_t)64 << 20; }   // >= (4096 + 64) slabs*groups x 64 channels x 25 taps doubles
+
+int cosy_crop_pack_to(void* x_nhwc8, int dtype, const float* frames_nhwc4, const int* im_id, const float* boxes_crop,
+                      const float* renders, int B, int N, int h, int w, int H, int W, cosy_stream_t stream) {
+    COSY_REQUIRE(x_nhwc8 && frames_nhwc4 && boxes_crop && renders, "crop_pack_to: null argument");
+    COSY_REQUIRE(dtype == COSY_F32 || dtype == COSY_BF16 || dtype == COSY_F16, "crop_pack_to: dtype %d", dtype);
+    return launch_crop_pack(x_nhwc8, dtype, frames_nhwc4, im_id, boxes_crop, renders, B, N, h, w, H, W, (hipStream_t)stream);
+}
+
+int cosy_bn_train_stats(const float* x, long M, int C, float eps, float momentum, float* mean, float* rstd, float* running_mean,
+                        float* running_var, void* workspace, cosy_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    COSY_REQUIRE(x && mean && rstd && workspace && M > 0 && C > 0, "bn_train_stats: bad argument");
+    const RedGeom g = red_geom(M, C);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(g.cgroups, g.nslab), dim3(256), 0, s, x, M, C, g.rows_per_slab, (double*)workspace);
+    COSY_CHECK_HIP(hipGetLastError());
+    LAUNCH1D(bn_stats_final_kernel, C, s, (const double*)workspace, g.nslab, M, C, eps, momentum, mean, rstd, running_mean, running_var);
+    return COSY_OK;
+}
+
+int cosy_bn_train_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, long M, int C,
+                        int act, const float* rowscale, int HW, const float* res, float* out, cosy_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    COSY_REQUIRE(x && mean && rstd && gamma && beta && out && C % 4 == 0 && HW > 0, "bn_train_apply: bad argument (C=%d)", C);
+    if (M == 0) return COSY_OK;
+    LAUNCH1D(bn_apply_kernel, M * (C / 4), s, x, mean, rstd, gamma, beta, M * (C / 4), C / 4, act, rowscale, HW, res, out);
+    return COSY_OK;
+}
+
+int cosy_bn_train_backward(const float* dout, const float* x, const float* mean, const float* rstd, const float* gamma,
+                           const float* beta, long M, int C, int act, const float* rowscale, int HW, float* dgamma, float* dbeta,
+                           int accumulate, float* dx, float* sums /*2*C scratch*/, void* workspace, cosy_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    COSY_REQUIRE(dout && x && mean && rstd && gamma && beta && dgamma && dbeta && dx && sums && workspace && C % 4 == 0 && M > 0 && HW > 0,
+                 "bn_train_backward: bad argument");
+    const RedGeom g = red_geom(M, C);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.cgroups, g.nslab), dim3(256), 0, s, dout, x, mean, rstd, gamma, beta, M, C, act, rowscale,
+                       HW, g.rows_per_slab, (double*)workspace);
+    COSY_CHECK_HIP(hipGetLastError());
+    // this call's sums (needed by dx) into `sums`; the parameter gradients accumulate on request
+    LAUNCH1D(bn_bwd_final_kernel, C, s, (const double*)workspace, g.nslab, C, sums + C, sums, 0);
+    LAUNCH1D(bn_bwd_final_kernel, C, s, (const double*)workspace, g.nslab, C, dgamma, dbeta, accumulate);
+    LAUNCH1D(bn_bwd_apply_kernel, M * (C / 4), s, dout, x, mean, rstd, gamma, beta, sums, sums + C, M * (C / 4), C / 4, 1.f / (float)M, act,
+             rowscale, HW, dx);
+    return COSY_OK;
+}
+
+int cosy_dw_train_forward(const float* x, const float* wt, int B, int H, int W, int C, int k, int stride, float* out,
+                          cosy_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    COSY_REQUIRE(x && wt && out && C % 4 == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2), "dw_train_forward: bad argument");
+    const int lo = stride == 1 ? (k - 1) / 2 : (k - 2) / 2;
+    const int Ho = stride == 1 ? H : (H + (k - 2) - k) / 2 + 1, Wo = stride == 1 ? W : (W + (k - 2) - k) / 2 + 1;
+    const long n4 = (long)B * Ho * Wo * (C / 4);
+    if (n4 == 0) return COSY_OK;
+    LAUNCH1D(dw_fwd_kernel, n4, s, x, wt, H, W, C / 4, Ho, Wo, k, stride, lo, n4, out);
+    return COSY_OK;
+}
+
+int cosy_dw_train_backward_data(const float* dy, const float* wt, int B, int H, int W, int C, int k, int stride, float* dx,
+                                cosy_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    COSY_REQUIRE(dy && wt && dx && C % 4 == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2), "dw_train_backward_data: bad argument");
+    const int lo = stride == 1 ? (k - 1) / 2 : (k - 2) / 2;
+    const int Ho = stride == 1 ? H : (H + (k - 2) - k) / 2 + 1, Wo = stride == 1 ? W : (W + (k - 2) - k) / 2 + 1;
+    const long n4 = (long)B * H * W * (C / 4);
+    if (n4 == 0) return COSY_OK;
+    LAUNCH1D(dw_bwd_data_kernel, n4, s, dy, wt, H, W, C / 4, Ho, Wo, k, stride, lo, n4, dx);
+    return COSY_OK;
+}
+
+int cosy_dw_train_backward_weight(const float* x, const float* dy, int B, int H, int W, int C, int k, int stride, float* dwt,
+                                  void* workspace, cosy_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    COSY_REQUIRE(x && dy && dwt && workspace && (k == 3 || k == 5) && (stride == 1 || stride == 2), "dw_train_backward_weight: bad argument");
+    const int lo = stride == 1 ? (k - 1) / 2 : (k - 2) / 2;
+    const int Ho = stride == 1 ? H : (H + (k - 2) - k) / 2 + 1, Wo = stride == 1 ? W : (W + (k - 2) - k) / 2 + 1;
+    const long Mo = (long)B * Ho * Wo;
+    COSY_REQUIRE(Mo > 0, "dw_train_backward_weight: empty batch");
+    const RedGeom g = red_geom(Mo, C);
+    if (k == 3)
+        hipLaunchKernelGGL(dw_bwd_weight_kernel<9>, dim3(g.cgroups, g.nslab), dim3(256), 0, s, x, dy, H, W, C, Ho, Wo, stride, lo, Mo,
+                           g.rows_per_slab, (double*)workspace);
+    else
+        hipLaunchKernelGGL(dw_bwd_weight_kernel<25>, dim3(g.cgroups, g.nslab), dim3(256), 0, s, x, dy, H, W, C, Ho, Wo, stride, lo, Mo,
+                           g.rows_per_slab, (double*)workspace);
+    COSY_CHECK_HIP(hipGetLastError());
+    LAUNCH1D(sum_partials_kernel, (long)k * k * C, s, (const double*)workspace, g.nslab, (long)k * k * C, dwt);
+    return COSY_OK;
+}
+
+int cosy_rows_mean(const float* a, int B, int HW, int C, float* out, cosy_stream_t stream) {
+    COSY_REQUIRE(a && out && B > 0 && HW > 0 && C > 0, "rows_mean: bad argument");
+    hipLaunchKernelGGL(rows_reduce_kernel<0>, dim3(cdiv(C, 64), B), dim3(256), 0, (hipStream_t)stream, a, (const float*)nullptr, HW, C,
+                       1.f / (float)HW, out);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+int cosy_rows_dot(const float* a, const float* a2, int B, int HW, int C, float* out, cosy_stream_t stream) {
+    COSY_REQUIRE(a && a2 && out && B > 0 && HW > 0 && C > 0, "rows_dot: bad argument");
+    hipLaunchKernelGGL(rows_reduce_kernel<1>, dim3(cdiv(C, 64), B), dim3(256), 0, (hipStream_t)stream, a, a2, HW, C, 1.f, out);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+int cosy_rows_scale(const float* a, const float* g, const float* add, float add_scale, int B, int HW, int C, float* out,
+                    cosy_stream_t stream) {
+    COSY_REQUIRE(a && g && out && C % 4 == 0 && B > 0 && HW > 0, "rows_scale: bad argument");
+    const long n4 = (long)B * HW * (C / 4);
+    LAUNCH1D(rows_scale_kernel, n4, (hipStream_t)stream, a, g, add, add_scale, n4, C / 4, HW, out);
+    return COSY_OK;
+}
+int cosy_rows_broadcast(const float* v, float scale, int B, int HW, int C, float* out, cosy_stream_t stream) {
+    COSY_REQUIRE(v && out && C % 4 == 0 && B > 0 && HW > 0, "rows_broadcast: bad argument");
+    const long n4 = (long)B * HW * (C / 4);
+    LAUNCH1D(rows_broadcast_kernel, n4, (hipStream_t)stream, v, scale, n4, C / 4, HW, out);
+    return COSY_OK;
+}
+int cosy_act_forward(const float* x, long n, int kind, float* out, cosy_stream_t stream) {
+    COSY_REQUIRE(x && out && (kind == 0 || kind == 1), "act_forward: bad argument");
+    if (n == 0) return COSY_OK;
+    LAUNCH1D(act_fwd_kernel, n, (hipStream_t)stream, x, n, kind, out);
+    return COSY_OK;
+}
+int cosy_act_backward(const float* x, const float* dy, long n, int kind, float* dx, cosy_stream_t stream) {
+    COSY_REQUIRE(x && dy && dx && (kind == 0 || kind == 1), "act_backward: bad argument");
+    if (n == 0) return COSY_OK;
+    LAUNCH1D(act_bwd_kernel, n, (hipStream_t)stream, x, dy, n, kind, dx);
+    return COSY_OK;
+}
+int cosy_stem_im2col(const float* x_nhwc8, int B, int H, int W, float* cols, cosy_stream_t stream) {
+    COSY_REQUIRE(x_nhwc8 && cols && B > 0, "stem_im2col: bad argument");
+    const int Ho = (H + 1 - 3) / 2 + 1, Wo = (W + 1 - 3) / 2 + 1;   // static same padding of k=3,s=2: pad total 1, all after
+    const long n = (long)B * Ho * Wo * 9;
+    LAUNCH1D(stem_im2col_kernel, n, (hipStream_t)stream, x_nhwc8, H, W, Ho, Wo, 0, n, cols);
+    return COSY_OK;
+}
+
+int cosy_loss_refiner_disentangled_backward(const float* TCO_possible_gt, const float* TCO_input, const float* refiner_outputs,
+                                            const float* K_crop, const float* pts_table, const int* obj_id, int B, int S, int P,
+                                            const float* dloss, float* d_refiner_outputs, cosy_stream_t stream) {
+    COSY_REQUIRE(B >= 0 && P > 0 && S > 0, "loss_refiner_disentangled_backward: B=%d S=%d P=%d", B, S, P);
+    if (B == 0) return COSY_OK;
+    COSY_REQUIRE(TCO_possible_gt && TCO_input && refiner_outputs && K_crop && pts_table && dloss && d_refiner_outputs,
+                 "loss_refiner_disentangled_backward: null pointer");
+    hipLaunchKernelGGL(loss_disentangled_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, TCO_possible_gt, TCO_input, refiner_outputs,
+                       K_crop, pts_table, obj_id, S, P, dloss, d_refiner_outputs);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+
+int cosy_grad_norm_clip(const float* grads, long n, float max_norm, float* norm_and_coef, void* workspace, cosy_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    COSY_REQUIRE(grads && norm_and_coef && workspace && n > 0, "grad_norm_clip: bad argument");
+    const int parts = 1024;
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(parts), dim3(256), 0, s, grads, n, (double*)workspace);
+    COSY_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, s, (const double*)workspace, parts, max_norm, norm_and_coef);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+
+int cosy_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, const float* norm_and_coef, cosy_stream_t stream) {
+    COSY_REQUIRE(params && grads && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adam_step: bad argument");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    LAUNCH1D(adam_kernel, n, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2),
+             norm_and_coef);
+    return COSY_OK;
+}
+
+}  // extern "C"

@@ -108,7 +108,8 @@ class NetEngine:
 
     def ensure(self, B, H, W, dtype, device):
         if self.backbone.training:
-            raise CosyHipError('cosypose_amd implements eval-mode inference; call .eval() (training step is a later round)')
+            raise CosyHipError('the inference engine runs eval-mode BatchNorm: call .eval(); the train-mode forward '
+                               '(cosypose_amd.train_engine) needs gradients enabled')
         key = (H, W, _DTYPES[dtype], device.index, self._weights_version())
         if self.handle is not None and key == self.key and B <= self.capacity:
             return self.handle

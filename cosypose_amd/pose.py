@@ -13,8 +13,8 @@ There is no CPU / eager fallback: tensors must live on a ROCm device.
 import torch
 from torch import nn
 
-from . import lib3d, arch
-from ._lib import lib, check, ptr, stream, require_device, ints_to_device, CosyHipError
+from . import lib3d, arch, train_engine
+from ._lib import lib, check, ptr, stream, require_device, ints_to_device, CosyHipError, COSY_F32
 from .efficientnet import NetEngine
 
 
@@ -35,6 +35,7 @@ class PosePredictor(nn.Module):
         self.debug = False
         self.tmp_debug = dict()
         self.compute_dtype = 'fp32'
+        self.drop_connect_rate = train_engine.DROP_CONNECT_RATE   # train mode only (efficientnet.py:182-185)
         self.__dict__['_engine'] = NetEngine(backbone, self.pose_fc)
 
     def enable_debug(self):
@@ -110,7 +111,8 @@ class PosePredictor(nn.Module):
         frames4 = torch.empty(n_im, h, w, 4, device=dev, dtype=torch.float32)
         check(lib().cosy_frames_to_nhwc4(ptr(images), ptr(frames4), n_im, h, w, stream()))
         obj_ids = self.mesh_db.object_ids(labels, dev)
-        net = self._net(bsz, dev)
+        train = self.training and torch.is_grad_enabled()
+        net = None if train else self._net(bsz, dev)
         H, W = self.render_size
 
         outputs = dict()
@@ -123,11 +125,21 @@ class PosePredictor(nn.Module):
             require_device(renders)
             renders = renders.detach().float().contiguous()
             assert renders.shape == (bsz, 3, H, W), renders.shape
-            check(lib().cosy_crop_pack(net, ptr(frames4), ptr(im_ids), ptr(boxes_crop), ptr(renders), bsz, n_im, h, w, stream()))
-            pose = torch.empty(bsz, self.pose_dim, device=dev)
-            check(lib().cosy_effnet_b3_forward(net, bsz, None, ptr(pose), None, stream()))
+            if train:
+                # train mode: fp32, batch-statistics BatchNorm, drop_connect; `pose` carries the autograd
+                # graph of the parameters (train_engine.backbone_train), the pose update itself is not differentiated
+                # (the reference's default loss, loss_refiner_CO_disentangled, only consumes model_outputs['pose'])
+                x8 = torch.empty(bsz, H, W, 8, device=dev)
+                check(lib().cosy_crop_pack_to(ptr(x8), COSY_F32, ptr(frames4), ptr(im_ids), ptr(boxes_crop), ptr(renders), bsz, n_im,
+                                              h, w, H, W, stream()))
+                drop = train_engine.make_drop_connect_scales(bsz, dev, self.drop_connect_rate)
+                pose = train_engine.backbone_train(self, x8, drop)
+            else:
+                check(lib().cosy_crop_pack(net, ptr(frames4), ptr(im_ids), ptr(boxes_crop), ptr(renders), bsz, n_im, h, w, stream()))
+                pose = torch.empty(bsz, self.pose_dim, device=dev)
+                check(lib().cosy_effnet_b3_forward(net, bsz, None, ptr(pose), None, stream()))
             model_outputs = dict(pose=pose)
-            TCO_output = lib3d.update_pose(TCO_input, K_crop, pose)
+            TCO_output = lib3d.update_pose(TCO_input, K_crop, pose.detach())
 
             outputs[f'iteration={n+1}'] = {
                 'TCO_input': TCO_input,

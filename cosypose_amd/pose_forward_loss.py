@@ -1,0 +1,88 @@
+"""h_pose: forward + loss of one training batch, same surface as the reference's
+cosypose/training/pose_forward_loss.py:17-84 (the function train_pose.py:317-331 differentiates).
+
+`data` carries images (B,3,h,w) uint8, K, TCO (ground truth), objects [{'name': label}], bboxes; `cfg` carries
+n_points_loss, loss_disentangled, n_pose_dims, init_method.  The returned loss is a scalar attached to the model's
+parameters through the HIP training engine (cosypose_amd.train_engine), so `loss.backward()` works as in the reference.
+Supported: the disentangled loss with 9-d pose outputs (every released CosyPose model); the ablation losses
+(quaternion outputs, plain ADD-L1) are not built.
+"""
+import numpy as np
+import torch
+
+from . import lib3d, train_engine
+
+
+def cast(obj):
+    return obj.cuda(non_blocking=True)
+
+
+def add_noise(TCO, euler_deg_std=(15, 15, 15), trans_std=(0.01, 0.01, 0.05)):
+    """Random rigid perturbation of the poses (cosypose/lib3d/transform_ops.py:35-51): R <- R R_noise(euler 'sxyz'),
+    t <- t + N(0, trans_std).  Host-side numpy RNG, drawn in the reference's order."""
+    TCO_out = TCO.clone()
+    bsz = TCO.shape[0]
+    eul = np.concatenate([np.random.normal(loc=0, scale=s, size=bsz)[:, None] for s in euler_deg_std], axis=1) * np.pi / 180
+    R = np.zeros((bsz, 3, 3), np.float64)
+    for b, (ai, aj, ak) in enumerate(eul):          # transforms3d.euler.euler2mat(ai, aj, ak), default 'sxyz'
+        ci, si, cj, sj, ck, sk = np.cos(ai), np.sin(ai), np.cos(aj), np.sin(aj), np.cos(ak), np.sin(ak)
+        R[b] = [[cj * ck, sj * si * ck - ci * sk, sj * ci * ck + si * sk],
+                [cj * sk, sj * si * sk + ci * ck, sj * ci * sk - si * ck],
+                [-sj, cj * si, cj * ci]]
+    R = torch.as_tensor(R, dtype=TCO.dtype).to(TCO.device)
+    t = np.concatenate([np.random.normal(loc=0, scale=s, size=bsz)[:, None] for s in trans_std], axis=1)
+    t = torch.as_tensor(t, dtype=TCO.dtype).to(TCO.device)
+    TCO_out[:, :3, :3] = TCO_out[:, :3, :3] @ R
+    TCO_out[:, :3, 3] += t
+    return TCO_out
+
+
+def h_pose(model, mesh_db, data, meters, cfg, n_iterations=1, input_generator='fixed'):
+    batch_size, _, h, w = data.images.shape
+
+    images = cast(data.images).float() / 255.
+    K = cast(data.K).float()
+    TCO_gt = cast(data.TCO).float()
+    labels = np.array([obj['name'] for obj in data.objects])
+    bboxes = cast(data.bboxes).float()
+
+    meshes = mesh_db.select(labels)
+    points = meshes.sample_points(cfg.n_points_loss, deterministic=False)
+    TCO_possible_gt = TCO_gt.unsqueeze(1) @ meshes.symmetries
+
+    if input_generator == 'fixed':
+        TCO_init = lib3d.TCO_init_from_boxes(z_range=(1.0, 1.0), boxes=bboxes, K=K)
+    elif input_generator == 'gt+noise':
+        TCO_init = add_noise(TCO_possible_gt[:, 0], euler_deg_std=[15, 15, 15], trans_std=[0.01, 0.01, 0.05])
+    elif input_generator == 'fixed+trans_noise':
+        assert cfg.init_method == 'z-up+auto-depth'
+        TCO_init = lib3d.TCO_init_from_boxes_zup_autodepth(bboxes, points, torch.arange(batch_size, dtype=torch.int32, device=bboxes.device), K)
+        TCO_init = add_noise(TCO_init, euler_deg_std=[0, 0, 0], trans_std=[0.01, 0.01, 0.05])
+    else:
+        raise ValueError('Unknown input generator', input_generator)
+
+    module = model.module if hasattr(model, 'module') else model
+    outputs = module(images=images, K=K, labels=labels, TCO=TCO_init, n_iterations=n_iterations)
+
+    losses_TCO_iter = []
+    for n in range(n_iterations):
+        iter_outputs = outputs[f'iteration={n+1}']
+        K_crop = iter_outputs['K_crop']
+        TCO_input = iter_outputs['TCO_input']
+        model_outputs = iter_outputs['model_outputs']
+
+        if cfg.loss_disentangled and cfg.n_pose_dims == 9:
+            loss_TCO_iter = train_engine.loss_refiner_CO_disentangled(
+                TCO_possible_gt=TCO_possible_gt, TCO_input=TCO_input, refiner_outputs=model_outputs['pose'],
+                K_crop=K_crop, points=points)
+        else:
+            raise ValueError('only the disentangled loss on 9-d pose outputs is built (cfg.loss_disentangled, n_pose_dims=9)')
+
+        meters[f'loss_TCO-iter={n+1}'].add(loss_TCO_iter.mean().item())
+        losses_TCO_iter.append(loss_TCO_iter)
+
+    loss_TCO = torch.cat(losses_TCO_iter).mean()
+    loss = loss_TCO
+    meters['loss_TCO'].add(loss_TCO.item())
+    meters['loss_total'].add(loss.item())
+    return loss

@@ -1,0 +1,411 @@
+"""Training step of the refiner network on the MI355X.
+
+Reference: MBConvBlock.forward / EfficientNet.extract_features in train mode (cosypose/models/efficientnet.py:71-98,
+:174-190; batch-statistics BatchNorm, momentum 0.01, eps 1e-3), SwishImplementation.backward and drop_connect
+(efficientnet_utils.py:37-48, :83-92), PosePredictor.net_forward (models/pose.py:81-87), the train step
+(training/train_pose.py:317-331: backward, clip_grad_norm_(0.5), Adam) and DDP's gradient averaging.
+
+Design: fp32, activations NHWC (rows = pixels, so every 1x1 convolution and its two gradients are plain row-major
+GEMMs -> rocBLAS through torch.mm); everything else -- BatchNorm statistics / apply / backward with the Swish fused
+in, depthwise forward / data / weight gradients, squeeze-excite scaling and its gradients, pooling, the stem's
+im2col, the loss gradient, gradient norm + clip + Adam on flat buffers -- is hand-written HIP in
+csrc/kernels_train.hip behind the C ABI.  The whole network is ONE autograd node (`backbone_train`): its backward
+fills the gradients of all 340 parameter tensors, so the reference's loop (`loss.backward(); clip; optimizer.step()`)
+runs unchanged on top of it; `FlatAdam` is the fused alternative on flat parameter / gradient buffers, and
+`allreduce_gradients` averages them across ranks with one RCCL all-reduce.
+With 288 GB of HBM per GPU nothing is recomputed: every conv output and activation of the step stays resident
+(~0.3 GB per 240x320 crop).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import arch
+from ._lib import lib, check, ptr, stream, require_device
+
+BN_EPS, BN_MOM = arch.BN_EPS, 0.01
+DROP_CONNECT_RATE = 0.2          # efficientnet_utils.py: efficientnet('efficientnet-b3') global params
+
+
+# ---------------------------------------------------------------------------------------------
+# thin wrappers over the C ABI (all tensors fp32, contiguous, on the device)
+# ---------------------------------------------------------------------------------------------
+_ws = {}
+
+
+def _workspace(dev):
+    w = _ws.get(dev)
+    if w is None:
+        w = _ws[dev] = torch.empty(lib().cosy_train_workspace_bytes(), dtype=torch.uint8, device=dev)
+    return w
+
+
+def bn_stats(x, M, C, running_mean=None, running_var=None):
+    mean = torch.empty(C, device=x.device); rstd = torch.empty(C, device=x.device)
+    check(lib().cosy_bn_train_stats(ptr(x), M, C, BN_EPS, BN_MOM, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
+                                    ptr(_workspace(x.device)), stream()))
+    return mean, rstd
+
+
+def bn_apply(x, mean, rstd, gamma, beta, M, C, act, rowscale=None, HW=1, res=None):
+    out = torch.empty_like(x)
+    check(lib().cosy_bn_train_apply(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), M, C, act, ptr(rowscale), HW, ptr(res), ptr(out),
+                                    stream()))
+    return out
+
+
+def bn_backward(dout, x, mean, rstd, gamma, beta, M, C, act, rowscale=None, HW=1):
+    dgamma = torch.empty(C, device=x.device); dbeta = torch.empty(C, device=x.device)
+    dx = torch.empty_like(x); sums = torch.empty(2 * C, device=x.device)
+    check(lib().cosy_bn_train_backward(ptr(dout), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), M, C, act, ptr(rowscale), HW,
+                                       ptr(dgamma), ptr(dbeta), 0, ptr(dx), ptr(sums), ptr(_workspace(x.device)), stream()))
+    return dx, dgamma, dbeta
+
+
+def _dw_out(H, W, k, s):
+    return (H, W) if s == 1 else ((H - 2) // 2 + 1, (W - 2) // 2 + 1)
+
+
+def dw_forward(x, wt, B, H, W, C, k, s):
+    Ho, Wo = _dw_out(H, W, k, s)
+    out = torch.empty(B * Ho * Wo, C, device=x.device)
+    check(lib().cosy_dw_train_forward(ptr(x), ptr(wt), B, H, W, C, k, s, ptr(out), stream()))
+    return out
+
+
+def dw_backward(x, dy, wt, B, H, W, C, k, s):
+    dx = torch.empty(B * H * W, C, device=x.device)
+    check(lib().cosy_dw_train_backward_data(ptr(dy), ptr(wt), B, H, W, C, k, s, ptr(dx), stream()))
+    dwt = torch.empty(k * k, C, device=x.device)
+    check(lib().cosy_dw_train_backward_weight(ptr(x), ptr(dy), B, H, W, C, k, s, ptr(dwt), ptr(_workspace(x.device)), stream()))
+    return dx, dwt
+
+
+def rows_mean(a, B, HW, C):
+    out = torch.empty(B, C, device=a.device)
+    check(lib().cosy_rows_mean(ptr(a), B, HW, C, ptr(out), stream()))
+    return out
+
+
+def rows_dot(a, a2, B, HW, C):
+    out = torch.empty(B, C, device=a.device)
+    check(lib().cosy_rows_dot(ptr(a), ptr(a2), B, HW, C, ptr(out), stream()))
+    return out
+
+
+def rows_scale(a, g, B, HW, C, add=None, add_scale=0.0):
+    out = torch.empty_like(a)
+    check(lib().cosy_rows_scale(ptr(a), ptr(g), ptr(add), add_scale, B, HW, C, ptr(out), stream()))
+    return out
+
+
+def rows_broadcast(v, scale, B, HW, C):
+    out = torch.empty(B * HW, C, device=v.device)
+    check(lib().cosy_rows_broadcast(ptr(v), scale, B, HW, C, ptr(out), stream()))
+    return out
+
+
+def act_forward(x, kind):
+    out = torch.empty_like(x)
+    check(lib().cosy_act_forward(ptr(x), x.numel(), kind, ptr(out), stream()))
+    return out
+
+
+def act_backward(x, dy, kind):
+    dx = torch.empty_like(x)
+    check(lib().cosy_act_backward(ptr(x), ptr(dy), x.numel(), kind, ptr(dx), stream()))
+    return dx
+
+
+SWISH, SIGMOID = 0, 1
+
+
+# ---------------------------------------------------------------------------------------------
+# the network as one autograd node
+# ---------------------------------------------------------------------------------------------
+def param_names():
+    """Trainable tensors of PosePredictor in named_parameters() order (reference state_dict names)."""
+    names = ['backbone._conv_stem.weight', 'backbone._bn0.weight', 'backbone._bn0.bias']
+    for i, (k, s, e, cin, cout) in enumerate(arch.B3_BLOCKS):
+        p = f'backbone._blocks.{i}.'
+        if e != 1:
+            names += [p + '_expand_conv.weight', p + '_bn0.weight', p + '_bn0.bias']
+        names += [p + '_depthwise_conv.weight', p + '_bn1.weight', p + '_bn1.bias',
+                  p + '_se_reduce.weight', p + '_se_reduce.bias', p + '_se_expand.weight', p + '_se_expand.bias',
+                  p + '_project_conv.weight', p + '_bn2.weight', p + '_bn2.bias']
+    names += ['backbone._conv_head.weight', 'backbone._bn1.weight', 'backbone._bn1.bias', 'pose_fc.weight', 'pose_fc.bias']
+    return names
+
+
+def make_drop_connect_scales(B, device, rate=DROP_CONNECT_RATE, generator=None):
+    """{block index: (B,) mask/keep_prob} as drop_connect draws them (efficientnet_utils.py:83-92): blocks with a skip
+    connection only, rate scaled by idx/26 (efficientnet.py:182-185)."""
+    out = {}
+    if not rate:
+        return out
+    n = len(arch.B3_BLOCKS)
+    for i, (k, s, e, cin, cout) in enumerate(arch.B3_BLOCKS):
+        r = rate * float(i) / n
+        if s == 1 and cin == cout and r:
+            keep = 1.0 - r
+            rnd = keep + torch.rand(B, device=device, generator=generator)
+            out[i] = (torch.floor(rnd) / keep).contiguous()
+    return out
+
+
+class _Net:
+    """Forward (saving what the backward needs) and backward of backbone + pooling + pose_fc."""
+
+    def __init__(self, P, buffers):
+        self.P, self.buf = P, buffers
+
+    # ---- helpers
+    def _bn_f(self, tape, name, raw, M, C, act, rowscale=None, HW=1, res=None):
+        rm, rv = self.buf.get(name + '.running_mean'), self.buf.get(name + '.running_var')
+        mean, rstd = bn_stats(raw, M, C, rm, rv)
+        nb = self.buf.get(name + '.num_batches_tracked')
+        if nb is not None:
+            nb += 1
+        tape[name] = (raw, mean, rstd, M, C, act, rowscale, HW)
+        return bn_apply(raw, mean, rstd, self.P[name + '.weight'], self.P[name + '.bias'], M, C, act, rowscale, HW, res)
+
+    def _bn_b(self, tape, grads, name, dout):
+        raw, mean, rstd, M, C, act, rowscale, HW = tape[name]
+        dx, dg, db = bn_backward(dout, raw, mean, rstd, self.P[name + '.weight'], self.P[name + '.bias'], M, C, act, rowscale, HW)
+        grads[name + '.weight'], grads[name + '.bias'] = dg, db
+        return dx
+
+    def forward(self, x8, drop):
+        P = self.P
+        tape = {}
+        B, H, W, _ = x8.shape
+        dev = x8.device
+        # stem: im2col + GEMM, BN, Swish
+        Ho, Wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
+        cols = torch.empty(B * Ho * Wo, 54, device=dev)
+        check(lib().cosy_stem_im2col(ptr(x8), B, H, W, ptr(cols), stream()))
+        w2d = P['backbone._conv_stem.weight'].permute(0, 2, 3, 1).reshape(arch.STEM_C, 54)
+        raw = cols @ w2d.t()
+        tape['stem'] = cols
+        x = self._bn_f(tape, 'backbone._bn0', raw, B * Ho * Wo, arch.STEM_C, 1)
+        H, W = Ho, Wo
+        for i, (k, s, e, cin, cout) in enumerate(arch.B3_BLOCKS):
+            p = f'backbone._blocks.{i}.'
+            M, cmid = B * H * W, cin * e
+            inp = x
+            if e != 1:
+                raw = inp @ P[p + '_expand_conv.weight'].view(cmid, cin).t()
+                a0 = self._bn_f(tape, p + '_bn0', raw, M, cmid, 1)
+            else:
+                a0 = inp
+            wt = P[p + '_depthwise_conv.weight'].view(cmid, k * k).t().contiguous()
+            raw = dw_forward(a0, wt, B, H, W, cmid, k, s)
+            Ho, Wo = _dw_out(H, W, k, s)
+            Mo, HWo = B * Ho * Wo, Ho * Wo
+            a1 = self._bn_f(tape, p + '_bn1', raw, Mo, cmid, 1)
+            # squeeze-excite
+            pooled = rows_mean(a1, B, HWo, cmid)
+            cse = P[p + '_se_reduce.bias'].numel()
+            h_pre = torch.addmm(P[p + '_se_reduce.bias'], pooled, P[p + '_se_reduce.weight'].view(cse, cmid).t())
+            h = act_forward(h_pre, SWISH)
+            g_pre = torch.addmm(P[p + '_se_expand.bias'], h, P[p + '_se_expand.weight'].view(cmid, cse).t())
+            g = act_forward(g_pre, SIGMOID)
+            a2 = rows_scale(a1, g, B, HWo, cmid)
+            raw = a2 @ P[p + '_project_conv.weight'].view(cout, cmid).t()
+            skip = s == 1 and cin == cout
+            rowscale = drop.get(i) if (skip and drop) else None
+            x = self._bn_f(tape, p + '_bn2', raw, Mo, cout, 0, rowscale, HWo, inp if skip else None)
+            tape[p] = (inp, a0, wt, a1, pooled, h_pre, h, g_pre, g, a2, H, W, Ho, Wo)
+            H, W = Ho, Wo
+        M = B * H * W
+        raw = x @ P['backbone._conv_head.weight'].view(arch.HEAD_C, -1).t()
+        a = self._bn_f(tape, 'backbone._bn1', raw, M, arch.HEAD_C, 1)
+        feat = rows_mean(a, B, H * W, arch.HEAD_C)
+        pose = torch.addmm(P['pose_fc.bias'], feat, P['pose_fc.weight'].t())
+        tape['head'] = (x, feat, B, H, W)
+        return pose, tape
+
+    def backward(self, tape, dpose):
+        P = self.P
+        grads = {}
+        x_head, feat, B, H, W = tape['head']
+        grads['pose_fc.weight'] = dpose.t() @ feat
+        grads['pose_fc.bias'] = dpose.sum(0)
+        dfeat = dpose @ P['pose_fc.weight']
+        da = rows_broadcast(dfeat, 1.0 / (H * W), B, H * W, arch.HEAD_C)
+        draw = self._bn_b(tape, grads, 'backbone._bn1', da)
+        wh = P['backbone._conv_head.weight']
+        grads['backbone._conv_head.weight'] = (draw.t() @ x_head).view_as(wh)
+        dx = draw @ wh.view(arch.HEAD_C, -1)
+        for i in reversed(range(len(arch.B3_BLOCKS))):
+            k, s, e, cin, cout = arch.B3_BLOCKS[i]
+            p = f'backbone._blocks.{i}.'
+            inp, a0, wt, a1, pooled, h_pre, h, g_pre, g, a2, H, W, Ho, Wo = tape[p]
+            cmid, HWo = cin * e, Ho * Wo
+            skip = s == 1 and cin == cout
+            dout = dx
+            draw = self._bn_b(tape, grads, p + '_bn2', dout)
+            wp = P[p + '_project_conv.weight']
+            grads[p + '_project_conv.weight'] = (draw.t() @ a2).view_as(wp)
+            da2 = draw @ wp.view(cout, cmid)
+            # squeeze-excite backward
+            dg = rows_dot(da2, a1, B, HWo, cmid)
+            dg_pre = act_backward(g_pre, dg, SIGMOID)
+            w2, w1 = P[p + '_se_expand.weight'], P[p + '_se_reduce.weight']
+            cse = w1.shape[0]
+            grads[p + '_se_expand.bias'] = dg_pre.sum(0)
+            grads[p + '_se_expand.weight'] = (dg_pre.t() @ h).view_as(w2)
+            dh = dg_pre @ w2.view(cmid, cse)
+            dh_pre = act_backward(h_pre, dh, SWISH)
+            grads[p + '_se_reduce.bias'] = dh_pre.sum(0)
+            grads[p + '_se_reduce.weight'] = (dh_pre.t() @ pooled).view_as(w1)
+            dpooled = dh_pre @ w1.view(cse, cmid)
+            da1 = rows_scale(da2, g, B, HWo, cmid, add=dpooled, add_scale=1.0 / HWo)
+            draw = self._bn_b(tape, grads, p + '_bn1', da1)
+            da0, dwt = dw_backward(a0, draw, wt, B, H, W, cmid, k, s)
+            grads[p + '_depthwise_conv.weight'] = dwt.t().reshape(cmid, 1, k, k)
+            if e != 1:
+                draw = self._bn_b(tape, grads, p + '_bn0', da0)
+                we = P[p + '_expand_conv.weight']
+                grads[p + '_expand_conv.weight'] = (draw.t() @ inp).view_as(we)
+                dinp = draw @ we.view(cmid, cin)
+            else:
+                dinp = da0
+            dx = dinp + dout if skip else dinp
+        draw = self._bn_b(tape, grads, 'backbone._bn0', dx)
+        cols = tape['stem']
+        grads['backbone._conv_stem.weight'] = (draw.t() @ cols).view(arch.STEM_C, 3, 3, 6).permute(0, 3, 1, 2).contiguous()
+        return grads
+
+
+class _BackboneTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x8, drop, buffers, names, *params):
+        net = _Net({n: p.detach() for n, p in zip(names, params)}, buffers)
+        pose, tape = net.forward(x8.detach(), drop)
+        ctx.net, ctx.tape, ctx.names = net, tape, names
+        return pose
+
+    @staticmethod
+    def backward(ctx, dpose):
+        grads = ctx.net.backward(ctx.tape, dpose.contiguous().float())
+        ctx.tape = None
+        return (None, None, None, None) + tuple(grads[n] for n in ctx.names)
+
+
+def backbone_train(model, x8, drop=None):
+    """pose outputs (B,9) of `model` (a PosePredictor) in train mode for the packed NHWC8 fp32 input `x8`, attached to
+    the autograd graph of the model's parameters.  BatchNorm running statistics are updated in place."""
+    require_device(x8)
+    names = param_names()
+    named = dict(model.named_parameters())
+    missing = [n for n in names if n not in named]
+    if missing or len(named) != len(names):
+        raise ValueError(f'model parameters do not match the efficientnet-b3 pose network ({len(named)} vs {len(names)}; missing {missing[:3]})')
+    params = [named[n] for n in names]
+    for p_ in params:
+        if p_.dtype != torch.float32 or not p_.is_contiguous():
+            raise ValueError('training runs on contiguous fp32 parameters')
+    buffers = dict(model.named_buffers())
+    return _BackboneTrainFn.apply(x8, drop or {}, buffers, names, *params)
+
+
+# ---------------------------------------------------------------------------------------------
+# loss with its hand-written gradient
+# ---------------------------------------------------------------------------------------------
+class _DisentangledLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, refiner_outputs, gt, TCO_input, K_crop, points):
+        B, S, Pn = gt.shape[0], gt.shape[1], points.shape[1]
+        out9 = refiner_outputs.detach().float().contiguous()
+        loss = torch.empty(B, device=out9.device)
+        check(lib().cosy_loss_refiner_disentangled(ptr(gt), ptr(TCO_input), ptr(out9), ptr(K_crop), ptr(points), None, B, S, Pn, ptr(loss),
+                                                   stream()))
+        ctx.saved = (out9, gt, TCO_input, K_crop, points)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        out9, gt, TCO_input, K_crop, points = ctx.saved
+        B, S, Pn = gt.shape[0], gt.shape[1], points.shape[1]
+        d = torch.empty(B, 9, device=out9.device)
+        check(lib().cosy_loss_refiner_disentangled_backward(ptr(gt), ptr(TCO_input), ptr(out9), ptr(K_crop), ptr(points), None, B, S, Pn,
+                                                            ptr(dloss.contiguous().float()), ptr(d), stream()))
+        return d, None, None, None, None
+
+
+def loss_refiner_CO_disentangled(TCO_possible_gt, TCO_input, refiner_outputs, K_crop, points):
+    """(B,) loss of cosypose/lib3d/cosypose_ops.py:49-82, differentiable wrt refiner_outputs."""
+    bsz = TCO_possible_gt.shape[0]
+    assert TCO_input.shape == (bsz, 4, 4) and refiner_outputs.shape == (bsz, 9) and K_crop.shape == (bsz, 3, 3)
+    assert points.dim() == 3 and points.shape[0] == bsz and points.shape[-1] == 3
+    assert TCO_possible_gt.dim() == 4 and TCO_possible_gt.shape[-2:] == (4, 4)
+    require_device(TCO_possible_gt, TCO_input, refiner_outputs, K_crop, points)
+    f = lambda t: t.detach().float().contiguous()
+    return _DisentangledLossFn.apply(refiner_outputs, f(TCO_possible_gt), f(TCO_input), f(K_crop), f(points))
+
+
+# ---------------------------------------------------------------------------------------------
+# optimizer on flat buffers, gradient averaging across ranks
+# ---------------------------------------------------------------------------------------------
+def _bump_version(t):
+    inc = getattr(torch.autograd.graph, 'increment_version', None)
+    if inc is not None:
+        inc(t)
+    else:
+        t.add_(0)
+
+
+class FlatAdam:
+    """clip_grad_norm_(max_norm) + torch.optim.Adam semantics (train_pose.py:325-329, :282) as two kernel launches over
+    ONE flat fp32 buffer.  Construction re-homes the parameters (and their .grad) as views of flat buffers, in
+    named_parameters() order; the module keeps working as before."""
+
+    def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_grad_norm=0.5):
+        params = [p for p in model.parameters()]
+        dev = params[0].device
+        require_device(params[0])
+        n = sum(p.numel() for p in params)
+        self.flat = torch.empty(n, device=dev)
+        self.grad = torch.zeros(n, device=dev)
+        off = 0
+        for p in params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view_as(p.data)
+            p.grad = self.grad[off:off + k].view_as(p.data)
+            off += k
+        self.params = params
+        self.m = torch.zeros(n, device=dev); self.v = torch.zeros(n, device=dev)
+        self.norm_coef = torch.ones(2, device=dev)
+        self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, clip_grad_norm
+        self.step_count = 0
+
+    def zero_grad(self):
+        self.grad.zero_()
+        off = 0
+        for p in self.params:       # re-attach views in case something set .grad to None
+            if p.grad is None:
+                p.grad = self.grad[off:off + p.numel()].view_as(p.data)
+            off += p.numel()
+
+    def step(self):
+        """-> total gradient norm before clipping (device scalar)"""
+        n = self.flat.numel()
+        check(lib().cosy_grad_norm_clip(ptr(self.grad), n, float(self.max_norm or 0.0), ptr(self.norm_coef), ptr(_workspace(self.flat.device)),
+                                        stream()))
+        self.step_count += 1
+        check(lib().cosy_adam_step(ptr(self.flat), ptr(self.grad), ptr(self.m), ptr(self.v), n, self.lr, self.betas[0], self.betas[1],
+                                   self.eps, self.wd, self.step_count, ptr(self.norm_coef), stream()))
+        _bump_version(self.flat)     # the kernel wrote through raw pointers: let torch (and the inference engine's cache) know
+        return self.norm_coef[0]
+
+
+def allreduce_gradients(flat_grad):
+    """DDP's gradient averaging as ONE all-reduce of the flat gradient buffer (42.8 MB fp32 for this network)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        flat_grad.div_(dist.get_world_size())
+    return flat_grad

@@ -172,6 +172,57 @@ int cosy_loss_refiner_disentangled(const float* TCO_possible_gt, const float* TC
 int cosy_dists_add(const float* TXO_pred, const float* TXO_gt, const float* pts_table, const int* obj_id, int B, int P,
                    int symmetric, float* dists, cosy_stream_t stream);
 
+/* ---- training step of the refiner network, fp32, activations NHWC = rows x channels --------------
+ * The 1x1 convolutions / linear layers and their gradients are plain GEMMs run by the host side (rocBLAS); these
+ * entry points are everything else of cosypose/training/train_pose.py:317-331's step.  `workspace` is a device buffer
+ * of cosy_train_workspace_bytes() bytes shared by the reductions (deterministic two-stage sums, no atomics). */
+size_t cosy_train_workspace_bytes(void);
+/* crop + render pack (as cosy_crop_pack) into a caller-owned NHWC8 buffer of element type `dtype` */
+int cosy_crop_pack_to(void* x_nhwc8, int dtype, const float* frames_nhwc4, const int* im_id, const float* boxes_crop,
+                      const float* renders, int B, int N, int h, int w, int H, int W, cosy_stream_t stream);
+/* nn.BatchNorm2d in train mode (efficientnet.py:49-68; eps 1e-3, momentum 0.01): batch mean / 1/sqrt(biased var + eps)
+ * per channel over the M rows; running_mean/var (optional) updated in place with the unbiased variance. */
+int cosy_bn_train_stats(const float* x, long M, int C, float eps, float momentum, float* mean, float* rstd, float* running_mean,
+                        float* running_var, void* workspace, cosy_stream_t stream);
+/* out = act((x-mean)*rstd*gamma+beta) [* rowscale[row/HW]] [+ res];  act 0 none / 1 Swish; rowscale = drop_connect's
+ * per-sample mask/keep_prob (efficientnet_utils.py:83-92), res = the block's skip input. */
+int cosy_bn_train_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, long M, int C,
+                        int act, const float* rowscale, int HW, const float* res, float* out, cosy_stream_t stream);
+/* backward of the above (+ SwishImplementation.backward, efficientnet_utils.py:44-48): dgamma, dbeta (accumulated when
+ * `accumulate`), dx.  `sums` = 2*C floats of scratch. */
+int cosy_bn_train_backward(const float* dout, const float* x, const float* mean, const float* rstd, const float* gamma,
+                           const float* beta, long M, int C, int act, const float* rowscale, int HW, float* dgamma, float* dbeta,
+                           int accumulate, float* dx, float* sums, void* workspace, cosy_stream_t stream);
+/* depthwise convolution with the reference's static "same" padding; weights transposed to (k*k, C) */
+int cosy_dw_train_forward(const float* x, const float* wt, int B, int H, int W, int C, int k, int stride, float* out,
+                          cosy_stream_t stream);
+int cosy_dw_train_backward_data(const float* dy, const float* wt, int B, int H, int W, int C, int k, int stride, float* dx,
+                                cosy_stream_t stream);
+int cosy_dw_train_backward_weight(const float* x, const float* dy, int B, int H, int W, int C, int k, int stride, float* dwt,
+                                  void* workspace, cosy_stream_t stream);
+/* per-sample reductions / broadcasts over the HW pixels of a (B,HW,C) activation: mean (adaptive_avg_pool2d),
+ * sum of a*a2 (gradient of the squeeze-excite gate), a*g[b,c] (+ add[b,c]*add_scale), v[b,c]*scale broadcast */
+int cosy_rows_mean(const float* a, int B, int HW, int C, float* out, cosy_stream_t stream);
+int cosy_rows_dot(const float* a, const float* a2, int B, int HW, int C, float* out, cosy_stream_t stream);
+int cosy_rows_scale(const float* a, const float* g, const float* add, float add_scale, int B, int HW, int C, float* out,
+                    cosy_stream_t stream);
+int cosy_rows_broadcast(const float* v, float scale, int B, int HW, int C, float* out, cosy_stream_t stream);
+/* elementwise Swish (kind 0) / sigmoid (kind 1) and their gradients */
+int cosy_act_forward(const float* x, long n, int kind, float* out, cosy_stream_t stream);
+int cosy_act_backward(const float* x, const float* dy, long n, int kind, float* dx, cosy_stream_t stream);
+/* stem 3x3 stride-2 patches of the NHWC8 input as GEMM rows: cols (B*Ho*Wo, 54), column = (ky*3+kx)*6 + c */
+int cosy_stem_im2col(const float* x_nhwc8, int B, int H, int W, float* cols, cosy_stream_t stream);
+/* gradient of loss_refiner_CO_disentangled (cosypose_ops.py:49-82) wrt refiner_outputs, times the upstream dloss (B) */
+int cosy_loss_refiner_disentangled_backward(const float* TCO_possible_gt, const float* TCO_input, const float* refiner_outputs,
+                                            const float* K_crop, const float* pts_table, const int* obj_id, int B, int S, int P,
+                                            const float* dloss, float* d_refiner_outputs, cosy_stream_t stream);
+/* torch.nn.utils.clip_grad_norm_(max_norm, 2) on a flat gradient buffer -> norm_and_coef[0] = total norm,
+ * [1] = min(1, max_norm/(norm+1e-6)) (1 when max_norm <= 0); torch.optim.Adam step on flat buffers, gradients scaled by
+ * norm_and_coef[1] when given (train_pose.py:325-329). */
+int cosy_grad_norm_clip(const float* grads, long n, float max_norm, float* norm_and_coef, void* workspace, cosy_stream_t stream);
+int cosy_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, const float* norm_and_coef, cosy_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

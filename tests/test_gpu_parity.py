@@ -429,3 +429,131 @@ def test_expand_ids_device_bit_exact(golden):
     a, b = expand_ids_for_symmetry_device(torch.from_numpy(n).cuda())
     assert np.array_equal(a.cpu().numpy(), np.repeat(np.arange(1000), n))
     assert np.array_equal(b.cpu().numpy(), np.concatenate([np.arange(k) for k in n]))
+
+
+# ---------------------------------------------------------------------------------------------
+# training step
+# ---------------------------------------------------------------------------------------------
+GRAD_TOL = 2e-3   # max |g - g_ref| relative to the tensor's reference gradient norm (fp32 sums over up to 1.2M rows)
+
+
+def _grad_err(a, b, scale):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / scale)
+
+
+def _train_model(golden_sd, mesh_table_np=None):
+    import argparse
+    from cosypose_amd.pose_models_cfg import create_model_refiner
+    from cosypose_amd.mesh_db import BatchedMeshes
+    n_obj = 21
+    labels = np.array([f'obj_{i:06d}' for i in range(1, n_obj + 1)])
+    pts = syn.make_mesh_points(7, n_obj, 2500)
+    infos = {l: dict(label=l, n_points=2500, n_sym=1) for l in labels}
+    mesh_db = BatchedMeshes(infos, labels, torch.from_numpy(pts), torch.eye(4).reshape(1, 1, 4, 4).repeat(n_obj, 1, 1, 1)).float().cuda()
+
+    class R:
+        calls = 0
+
+        def render(self, obj_infos, TCO, K, resolution):
+            r = syn.make_renders(900 + self.calls, len(obj_infos), *resolution)
+            self.calls += 1
+            return torch.from_numpy(r).cuda()
+    cfg = argparse.Namespace(backbone_str='efficientnet-b3', n_pose_dims=9, init_method='v0')
+    model = create_model_refiner(cfg, R(), mesh_db)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in golden_sd.items()}, strict=True)
+    return model.cuda(), mesh_db, labels
+
+
+def test_training_step_vs_reference(oracle, golden_train, golden_sd):
+    """h_pose forward + backward + clip + Adam on the GPU against the reference's own numbers"""
+    import argparse, types
+    from collections import defaultdict
+    from cosypose_amd import pose_forward_loss as pfl, train_engine
+    g = golden_train
+    model, mesh_db, labels_all = _train_model(golden_sd)
+    model.train()
+    model.drop_connect_rate = 0.0
+    B = 4
+    frames, K, TCO, obj = syn.make_training_batch(61, B)
+    data = types.SimpleNamespace(images=torch.from_numpy(frames), K=torch.from_numpy(K), TCO=torch.from_numpy(TCO),
+                                 objects=[dict(name=l) for l in labels_all[obj]], bboxes=torch.from_numpy(g['tr_bboxes']))
+    cfg = argparse.Namespace(n_points_loss=600, loss_disentangled=True, n_pose_dims=9, init_method='v0')
+
+    class M:
+        def add(self, v): pass
+    captured = []
+    hook_fn = train_engine.backbone_train
+
+    def spy(*a, **k):
+        out = hook_fn(*a, **k); captured.append(out.detach().clone()); return out
+    import cosypose_amd.pose as pose_mod
+    pose_mod.train_engine.backbone_train = spy
+    try:
+        opt = train_engine.FlatAdam(model, lr=3e-4, clip_grad_norm=0.5)
+        opt.zero_grad()
+        np.random.seed(123)
+        loss = pfl.h_pose(model=model, mesh_db=mesh_db, data=data, meters=defaultdict(M), cfg=cfg, n_iterations=1, input_generator='fixed')
+        loss.backward()
+    finally:
+        pose_mod.train_engine.backbone_train = hook_fn
+    assert abs(loss.item() - float(g['tr_loss'])) < 1e-4 * abs(float(g['tr_loss']))
+    assert rel_err(captured[0].cpu().numpy(), g['tr_pose']) < 1e-4
+    names = list(g['tr_param_names'])
+    norms = dict(zip(names, g['tr_grad_norms']))
+    named = dict(model.named_parameters())
+    assert list(named) == names                     # same parameters, same order as the reference module
+    worst = 0.0
+    for n in names:
+        gr = named[n].grad.detach().cpu().numpy()
+        mine = np.linalg.norm(gr.ravel())
+        assert abs(mine - norms[n]) < GRAD_TOL * norms[n] + 1e-8, (n, mine, norms[n])
+        if 'tr_grad/' + n in g:
+            e = _grad_err(gr, g['tr_grad/' + n], max(norms[n], 1e-6)); worst = max(worst, e)
+            assert e < GRAD_TOL, (n, e)
+    bufs = dict(model.named_buffers())
+    for k in g:
+        if k.startswith('tr_bn/'):
+            assert rel_err(bufs[k[len('tr_bn/'):]].cpu().numpy(), g[k]) < 1e-5, k     # running statistics after the step
+    total = opt.step()
+    assert abs(float(total) - float(g['tr_total_grad_norm'])) < 1e-3 * float(g['tr_total_grad_norm'])
+    for k in g:
+        if k.startswith('tr_after_adam/'):
+            n = k[len('tr_after_adam/'):]
+            ref = g[k]; got = named[n].detach().cpu().numpy()
+            # Adam's first step moves every weight by ~lr*sign(g): compare the applied update
+            assert np.abs(got - ref).max() < 3e-5, (n, np.abs(got - ref).max())
+    # after the update the model still serves inference (the engine notices the new weights)
+    model.eval()
+    with torch.no_grad():
+        out = model(images=torch.from_numpy(frames).cuda().float() / 255., K=torch.from_numpy(K).cuda(), labels=labels_all[obj],
+                    TCO=torch.from_numpy(TCO).cuda(), n_iterations=1)
+    assert torch.isfinite(out['iteration=1']['TCO_output']).all()
+
+
+def test_training_gradients_vs_oracle_with_drop_connect(oracle, golden_train, golden_sd, mesh_table):
+    """seeded case with drop_connect masks and symmetric ground truths against the torch-CPU restatement"""
+    import train_case
+    from cosypose_amd import train_engine
+    c = train_case.build(oracle, golden_train, mesh_table)
+    B = c['x'].shape[0]
+    rs = np.random.RandomState(4)
+    drop_np = {i: (0.9, (rs.rand(B) < 0.7).astype(np.float32)) for i in (1, 4, 9, 20, 25)}
+    gt = np.concatenate([c['gt'], c['gt']], 1).copy()            # two possible ground truths, the second one perturbed
+    gt[:, 1, :3, 3] += 0.01
+    ref = oracle.TorchRef(golden_sd)
+    loss_o, pose_o, grads_o = ref.train_forward_backward(c['x'], gt, c['TCO_input'], c['K_crop'], c['points'],
+                                                         drop={i: (k, torch.from_numpy(m)) for i, (k, m) in drop_np.items()})
+    model, _, _ = _train_model(golden_sd)
+    model.train()
+    x8 = torch.zeros(B, 240, 320, 8, device='cuda')
+    x8[..., :6] = torch.from_numpy(c['x']).cuda().permute(0, 2, 3, 1)
+    drop = {i: torch.from_numpy(m / np.float32(k)).cuda() for i, (k, m) in drop_np.items()}
+    pose = train_engine.backbone_train(model, x8, drop)
+    loss = train_engine.loss_refiner_CO_disentangled(dev(gt), dev(c['TCO_input']), pose, dev(c['K_crop']), dev(c['points'])).mean()
+    loss.backward()
+    assert abs(loss.item() - loss_o) < 1e-4 * abs(loss_o)
+    assert rel_err(pose.detach().cpu().numpy(), pose_o) < 1e-4
+    for n, p in model.named_parameters():
+        go = grads_o[n]
+        scale = max(np.linalg.norm(go.ravel()), 1e-6)
+        assert _grad_err(p.grad.cpu().numpy(), go, scale) < GRAD_TOL, n
