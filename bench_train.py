@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Training-step timing (BASELINE configs[4], SURVEY 8d "Config 4"): 64 crops/GPU from 480x640 uint8 frames,
+240x320 crops, fp32 -- h_pose forward (train-mode BatchNorm, drop_connect), disentangled loss, backward, gradient
+all-reduce over RCCL, clip 0.5, Adam.  NOT the headline metric (bench.py is); prints one JSON line with the step time,
+its split and the all-reduce time.
+
+    python bench_train.py [--gpus N] [--steps K] [--warmup W] [--batch 64]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench_train.py --gpus N
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+from collections import defaultdict
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+
+class Meter:
+    def add(self, v):
+        pass
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--kernels', action='store_true', help='per-kernel table from torch.profiler to stderr')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from bench import SyntheticRenderer, build_model
+    from cosypose_amd import synthetic as syn, train_engine, pose_forward_loss as pfl
+    from cosypose_amd.mesh_db import BatchedMeshes
+    from cosypose_amd.distributed import init_distributed_mode
+
+    if not torch.cuda.is_available():
+        raise SystemExit('bench_train.py needs an MI355X (no CPU fallback)')
+    rank, world = init_distributed_mode('nccl')
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    B, n_obj, h, w, H, W = args.batch, 21, 480, 640, 240, 320
+    labels = np.array([f'obj_{i:06d}' for i in range(1, n_obj + 1)])
+    pts = syn.make_mesh_points(7, n_obj, 2600)
+    infos = {l: dict(label=l, n_points=2600, n_sym=1) for l in labels}
+    mesh_db = BatchedMeshes(infos, labels, torch.from_numpy(pts), torch.eye(4).reshape(1, 1, 4, 4).repeat(n_obj, 1, 1, 1)).float().cuda()
+    frames, K, TCO, obj = syn.make_training_batch(100 + rank, B, n_obj, h, w)
+    g = torch.Generator(device='cuda'); g.manual_seed(1 + rank)
+    renderer = SyntheticRenderer([torch.rand(B, 3, H, W, device='cuda', generator=g) for _ in range(3)])
+    model = build_model(1, mesh_db, (H, W), 'fp32', renderer).train()
+    # 2D boxes of the projected ground-truth models (what the dataset provides)
+    P = torch.from_numpy(pts[obj]).cuda()
+    Kc, Tc = torch.from_numpy(K).cuda(), torch.from_numpy(TCO).cuda()
+    cam = (Tc[:, :3, :3].unsqueeze(1) @ P.unsqueeze(-1)).squeeze(-1) + Tc[:, :3, 3].unsqueeze(1)
+    uv = (Kc.unsqueeze(1) @ cam.unsqueeze(-1)).squeeze(-1)
+    uv = uv[..., :2] / uv[..., 2:]
+    bboxes = torch.cat([uv.min(1)[0], uv.max(1)[0]], 1)
+    data = types.SimpleNamespace(images=torch.from_numpy(frames), K=torch.from_numpy(K), TCO=torch.from_numpy(TCO),
+                                 objects=[dict(name=l) for l in labels[obj]], bboxes=bboxes.cpu())
+    cfg = argparse.Namespace(n_points_loss=2600, loss_disentangled=True, n_pose_dims=9, init_method='v0')
+    opt = train_engine.FlatAdam(model, lr=3e-4, clip_grad_norm=0.5)
+    meters = defaultdict(Meter)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    split = defaultdict(float)
+
+    def step(timed):
+        e = [ev() for _ in range(5)]
+        opt.zero_grad()
+        e[0].record()
+        loss = pfl.h_pose(model=model, mesh_db=mesh_db, data=data, meters=meters, cfg=cfg, n_iterations=1, input_generator='fixed')
+        e[1].record()
+        loss.backward()
+        e[2].record()
+        train_engine.allreduce_gradients(opt.grad)
+        e[3].record()
+        opt.step()
+        e[4].record()
+        if timed:
+            torch.cuda.synchronize()
+            for k, a, b in (('forward_loss', 0, 1), ('backward', 1, 2), ('allreduce', 2, 3), ('clip_adam', 3, 4)):
+                split[k] += e[a].elapsed_time(e[b])
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step(False)
+    assert torch.isfinite(loss).all()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(False)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    for _ in range(min(args.steps, 3)):
+        step(True)
+    nsp = min(args.steps, 3)
+    if args.kernels and rank == 0:
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step(False); torch.cuda.synchronize()
+        ka = prof.key_averages()
+        print(ka.table(sort_by='cuda_time_total', row_limit=30, max_name_column_width=70), file=sys.stderr)
+        fam = defaultdict(float)
+        gemms = []
+        for e in ka:
+            t = getattr(e, 'self_device_time_total', None)
+            if t is None:
+                t = e.self_cuda_time_total
+            key = ('rocBLAS GEMM' if e.key.startswith('Cijk') else 'cosy HIP kernels' if 'cosy::' in e.key else
+                   'torch elementwise/reduce' if 'at::native' in e.key else 'copies' if 'Memcpy' in e.key or 'copyBuffer' in e.key else 'other')
+            fam[key] += t / 1e3
+            if e.key.startswith('Cijk'):
+                gemms.append((t / 1e3, e.count, e.key[:90]))
+        print('time by family (ms/step): ' + ', '.join(f'{k} {v:.2f}' for k, v in sorted(fam.items(), key=lambda kv: -kv[1])), file=sys.stderr)
+        for t, n, k in sorted(gemms, reverse=True)[:8]:
+            print(f'  gemm {t:8.2f} ms  x{n:3d}  {k}', file=sys.stderr)
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        print(json.dumps({
+            'metric': 'training step time (refiner, 240x320 crops, fp32)', 'value': round(ms, 2), 'unit': 'ms/step', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': False, 'scaling': 'weak', 'dtype': 'f32', 'data': 'synthetic',
+            'crops_per_s': round(world * B * args.steps / dt, 1),
+            'config': {'workload': f'BASELINE configs[4]: {B} crops/GPU from {h}x{w} uint8 frames, {H}x{W} crops, h_pose forward + disentangled '
+                                   f'loss + backward + gradient all-reduce ({opt.grad.numel() * 4 / 1e6:.1f} MB fp32) + clip 0.5 + Adam',
+                       'n_points_loss': 2600, 'drop_connect_rate': model.drop_connect_rate},
+            'split_ms': {k: round(v / nsp, 2) for k, v in split.items()},
+            'peak_memory_gb': round(torch.cuda.max_memory_allocated() / 1e9, 2),
+        }))
+
+
+if __name__ == '__main__':
+    main()

@@ -27,12 +27,13 @@ struct RedGeom { int cgroups, nslab, rows_per_slab; };
 RedGeom red_geom(long M, int C) {
     RedGeom g;
     g.cgroups = cdiv(C, 64);
-    long target = 4096 / g.cgroups;            // ~4096 workgroups in flight at most
-    if (target < 1) target = 1;
-    long rows = cdiv(M, target);
-    if (rows < 64) rows = 64;
-    g.rows_per_slab = (int)rows;
-    g.nslab = cdiv(M, rows);
+    long cap = 4096 / g.cgroups;               // up to ~4096 workgroups per reduction (16 waves/CU); the combine pass is parallel
+    if (cap < 8) cap = 8;
+    long nslab = cdiv(M, 128);
+    if (nslab > cap) nslab = cap;
+    if (nslab < 1) nslab = 1;
+    g.rows_per_slab = (int)cdiv(M, nslab);
+    g.nslab = cdiv(M, g.rows_per_slab);
     return g;
 }
 
@@ -70,13 +71,12 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
         }
     slab_write<2>(acc, lds, partial, slab, C, c);
 }
-__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ partial, int nslab, long M, int C, float eps,
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ sums /*[2][C]*/, long M, int C, float eps,
                                                              float momentum, float* __restrict__ mean, float* __restrict__ rstd,
                                                              float* __restrict__ running_mean, float* __restrict__ running_var) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    double s = 0., ss = 0.;
-    for (int k = 0; k < nslab; ++k) { s += partial[((size_t)k * 2 + 0) * C + c]; ss += partial[((size_t)k * 2 + 1) * C + c]; }
+    const double s = sums[c], ss = sums[C + c];
     const double m = s / (double)M;
     double var = ss / (double)M - m * m;
     if (var < 0.) var = 0.;
@@ -143,13 +143,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
     slab_write<2>(acc, lds, partial, slab, C, c);
 }
-__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restrict__ partial, int nslab, int C, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int accumulate) {
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ sums /*[2][C]: sum dy, sum dy*xhat*/, int C,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    double s = 0., ss = 0.;
-    for (int k = 0; k < nslab; ++k) { s += partial[((size_t)k * 2 + 0) * C + c]; ss += partial[((size_t)k * 2 + 1) * C + c]; }
-    if (accumulate) { dbeta[c] += (float)s; dgamma[c] += (float)ss; } else { dbeta[c] = (float)s; dgamma[c] = (float)ss; }
+    if (accumulate) { dbeta[c] += sums[c]; dgamma[c] += sums[C + c]; } else { dbeta[c] = sums[c]; dgamma[c] = sums[C + c]; }
 }
 // dx = gamma * rstd * (dy - sum(dy)/M - xhat * sum(dy*xhat)/M); sum_dy / sum_dyx are THIS call's sums (not accumulated grads)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ x,
@@ -262,30 +260,64 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
         }
     slab_write<KK>(acc, lds, partial, slab, C, c);
 }
-__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int nslab, long n, float* __restrict__ out) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    double s = 0.;
-    for (int k = 0; k < nslab; ++k) s += partial[(size_t)k * n + i];
-    out[i] = (float)s;
+// out[j] = sum over slabs of partial[slab*n + j]; lanes = 64 consecutive j, 16 waves stride over the slabs
+__global__ __launch_bounds__(1024) void combine_partials_kernel(const double* __restrict__ partial, int nslab, long n, double* __restrict__ out_d,
+                                                                float* __restrict__ out_f) {
+    __shared__ double lds[16 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long j = (long)blockIdx.x * 64 + lane;
+    double acc = 0.;
+    if (j < n) {
+        int k = wave;
+        for (; k + 48 < nslab; k += 64) {   // 4 loads in flight
+            const double a0 = partial[(size_t)k * n + j], a1 = partial[(size_t)(k + 16) * n + j];
+            const double a2 = partial[(size_t)(k + 32) * n + j], a3 = partial[(size_t)(k + 48) * n + j];
+            acc += (a0 + a1) + (a2 + a3);
+        }
+        for (; k < nslab; k += 16) acc += partial[(size_t)k * n + j];
+    }
+    lds[wave * 64 + lane] = acc;
+    __syncthreads();
+    if (wave == 0 && j < n) {
+        double t = 0.;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += lds[w * 64 + lane];
+        if (out_d) out_d[j] = t;
+        if (out_f) out_f[j] = (float)t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
 // squeeze-excite pieces, pooling, activations
 // ------------------------------------------------------------------------------------------
-// out[b][c] = scale * sum_p f(a[b][p][c] (, a2[b][p][c]));  MODE 0: a;  MODE 1: a * a2.  One workgroup per (b, 64 channels).
+// partial[(b*nchunk + chunk)][c] = sum over the chunk's pixels of f(a[b][p][c] (, a2[b][p][c]));  MODE 0: a;  MODE 1: a * a2.
+// One workgroup per (64 channels, sample, chunk of pixels); rows_reduce_final sums the chunks and scales.
 template <int MODE>
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ a, const float* __restrict__ a2, int HW, int C,
-                                                          float scale, float* __restrict__ out) {
+                                                          int rows_per_chunk, double* __restrict__ partial) {
+    __shared__ double lds[4 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, b = blockIdx.y, chunk = blockIdx.z, nchunk = gridDim.z;
+    const int p0 = chunk * rows_per_chunk, p1 = min(HW, p0 + rows_per_chunk);
+    double acc = 0.;
+    if (c < C)
+        for (int p = p0 + wave; p < p1; p += 4) {
+            const size_t o = ((size_t)b * HW + p) * C + c;
+            acc += MODE == 0 ? (double)a[o] : (double)a[o] * a2[o];
+        }
+    lds[wave * 64 + lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < C)
+        partial[((size_t)b * nchunk + chunk) * C + c] = ((lds[lane] + lds[64 + lane]) + lds[128 + lane]) + lds[192 + lane];
+}
+__global__ __launch_bounds__(256) void rows_reduce_final_kernel(const double* __restrict__ partial, int nchunk, int C, float scale,
+                                                                float* __restrict__ out) {
     __shared__ double lds[4 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane, b = blockIdx.y;
     double acc = 0.;
     if (c < C)
-        for (int p = wave; p < HW; p += 4) {
-            const size_t o = ((size_t)b * HW + p) * C + c;
-            acc += MODE == 0 ? (double)a[o] : (double)a[o] * a2[o];
-        }
+        for (int k = wave; k < nchunk; k += 4) acc += partial[((size_t)b * nchunk + k) * C + c];
     lds[wave * 64 + lane] = acc;
     __syncthreads();
     if (wave == 0 && c < C)
@@ -575,7 +607,11 @@ int cosy_bn_train_stats(const float* x, long M, int C, float eps, float momentum
     const RedGeom g = red_geom(M, C);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(g.cgroups, g.nslab), dim3(256), 0, s, x, M, C, g.rows_per_slab, (double*)workspace);
     COSY_CHECK_HIP(hipGetLastError());
-    LAUNCH1D(bn_stats_final_kernel, C, s, (const double*)workspace, g.nslab, M, C, eps, momentum, mean, rstd, running_mean, running_var);
+    double* sums = (double*)workspace + (size_t)g.nslab * 2 * C;
+    hipLaunchKernelGGL(combine_partials_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, (const double*)workspace, g.nslab, (long)2 * C, sums,
+                       (float*)nullptr);
+    COSY_CHECK_HIP(hipGetLastError());
+    LAUNCH1D(bn_stats_final_kernel, C, s, (const double*)sums, M, C, eps, momentum, mean, rstd, running_mean, running_var);
     return COSY_OK;
 }
 
@@ -599,8 +635,10 @@ int cosy_bn_train_backward(const float* dout, const float* x, const float* mean,
                        HW, g.rows_per_slab, (double*)workspace);
     COSY_CHECK_HIP(hipGetLastError());
     // this call's sums (needed by dx) into `sums`; the parameter gradients accumulate on request
-    LAUNCH1D(bn_bwd_final_kernel, C, s, (const double*)workspace, g.nslab, C, sums + C, sums, 0);
-    LAUNCH1D(bn_bwd_final_kernel, C, s, (const double*)workspace, g.nslab, C, dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(combine_partials_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, (const double*)workspace, g.nslab, (long)2 * C,
+                       (double*)nullptr, sums);
+    COSY_CHECK_HIP(hipGetLastError());
+    LAUNCH1D(bn_bwd_final_kernel, C, s, (const float*)sums, C, dgamma, dbeta, accumulate);
     LAUNCH1D(bn_bwd_apply_kernel, M * (C / 4), s, dout, x, mean, rstd, gamma, beta, sums, sums + C, M * (C / 4), C / 4, 1.f / (float)M, act,
              rowscale, HW, dx);
     return COSY_OK;
@@ -646,20 +684,41 @@ int cosy_dw_train_backward_weight(const float* x, const float* dy, int B, int H,
         hipLaunchKernelGGL(dw_bwd_weight_kernel<25>, dim3(g.cgroups, g.nslab), dim3(256), 0, s, x, dy, H, W, C, Ho, Wo, stride, lo, Mo,
                            g.rows_per_slab, (double*)workspace);
     COSY_CHECK_HIP(hipGetLastError());
-    LAUNCH1D(sum_partials_kernel, (long)k * k * C, s, (const double*)workspace, g.nslab, (long)k * k * C, dwt);
+    hipLaunchKernelGGL(combine_partials_kernel, dim3(cdiv((long)k * k * C, 64)), dim3(1024), 0, s, (const double*)workspace, g.nslab,
+                       (long)k * k * C, (double*)nullptr, dwt);
+    COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }
 
-int cosy_rows_mean(const float* a, int B, int HW, int C, float* out, cosy_stream_t stream) {
-    COSY_REQUIRE(a && out && B > 0 && HW > 0 && C > 0, "rows_mean: bad argument");
-    hipLaunchKernelGGL(rows_reduce_kernel<0>, dim3(cdiv(C, 64), B), dim3(256), 0, (hipStream_t)stream, a, (const float*)nullptr, HW, C,
+static int rows_chunks(int B, int HW, int C, int* rows_per_chunk) {
+    int cap = 1024 / (B * cdiv(C, 64));
+    if (cap < 1) cap = 1;
+    int n = cdiv(HW, 128);
+    if (n > cap) n = cap;
+    *rows_per_chunk = cdiv(HW, n);
+    return cdiv(HW, *rows_per_chunk);
+}
+int cosy_rows_mean(const float* a, int B, int HW, int C, float* out, void* workspace, cosy_stream_t stream) {
+    COSY_REQUIRE(a && out && workspace && B > 0 && HW > 0 && C > 0, "rows_mean: bad argument");
+    int rpc;
+    const int nchunk = rows_chunks(B, HW, C, &rpc);
+    hipLaunchKernelGGL(rows_reduce_kernel<0>, dim3(cdiv(C, 64), B, nchunk), dim3(256), 0, (hipStream_t)stream, a, (const float*)nullptr, HW, C,
+                       rpc, (double*)workspace);
+    COSY_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rows_reduce_final_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, nchunk, C,
                        1.f / (float)HW, out);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }
-int cosy_rows_dot(const float* a, const float* a2, int B, int HW, int C, float* out, cosy_stream_t stream) {
-    COSY_REQUIRE(a && a2 && out && B > 0 && HW > 0 && C > 0, "rows_dot: bad argument");
-    hipLaunchKernelGGL(rows_reduce_kernel<1>, dim3(cdiv(C, 64), B), dim3(256), 0, (hipStream_t)stream, a, a2, HW, C, 1.f, out);
+int cosy_rows_dot(const float* a, const float* a2, int B, int HW, int C, float* out, void* workspace, cosy_stream_t stream) {
+    COSY_REQUIRE(a && a2 && out && workspace && B > 0 && HW > 0 && C > 0, "rows_dot: bad argument");
+    int rpc;
+    const int nchunk = rows_chunks(B, HW, C, &rpc);
+    hipLaunchKernelGGL(rows_reduce_kernel<1>, dim3(cdiv(C, 64), B, nchunk), dim3(256), 0, (hipStream_t)stream, a, a2, HW, C, rpc,
+                       (double*)workspace);
+    COSY_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rows_reduce_final_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, nchunk, C,
+                       1.f, out);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }

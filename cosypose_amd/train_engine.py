@@ -84,13 +84,13 @@ def dw_backward(x, dy, wt, B, H, W, C, k, s):
 
 def rows_mean(a, B, HW, C):
     out = torch.empty(B, C, device=a.device)
-    check(lib().cosy_rows_mean(ptr(a), B, HW, C, ptr(out), stream()))
+    check(lib().cosy_rows_mean(ptr(a), B, HW, C, ptr(out), ptr(_workspace(a.device)), stream()))
     return out
 
 
 def rows_dot(a, a2, B, HW, C):
     out = torch.empty(B, C, device=a.device)
-    check(lib().cosy_rows_dot(ptr(a), ptr(a2), B, HW, C, ptr(out), stream()))
+    check(lib().cosy_rows_dot(ptr(a), ptr(a2), B, HW, C, ptr(out), ptr(_workspace(a.device)), stream()))
     return out
 
 

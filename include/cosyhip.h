@@ -202,8 +202,8 @@ int cosy_dw_train_backward_weight(const float* x, const float* dy, int B, int H,
                                   void* workspace, cosy_stream_t stream);
 /* per-sample reductions / broadcasts over the HW pixels of a (B,HW,C) activation: mean (adaptive_avg_pool2d),
  * sum of a*a2 (gradient of the squeeze-excite gate), a*g[b,c] (+ add[b,c]*add_scale), v[b,c]*scale broadcast */
-int cosy_rows_mean(const float* a, int B, int HW, int C, float* out, cosy_stream_t stream);
-int cosy_rows_dot(const float* a, const float* a2, int B, int HW, int C, float* out, cosy_stream_t stream);
+int cosy_rows_mean(const float* a, int B, int HW, int C, float* out, void* workspace, cosy_stream_t stream);
+int cosy_rows_dot(const float* a, const float* a2, int B, int HW, int C, float* out, void* workspace, cosy_stream_t stream);
 int cosy_rows_scale(const float* a, const float* g, const float* add, float add_scale, int B, int HW, int C, float* out,
                     cosy_stream_t stream);
 int cosy_rows_broadcast(const float* v, float scale, int B, int HW, int C, float* out, cosy_stream_t stream);

@@ -40,6 +40,11 @@ def _worker(rank, world, port, q):
     full = coll.gather_distributed(tmp_dir=None)
     ok &= list(full.infos['label']) == [f'o{i}' for i in range(D)] and torch.equal(full.poses, poses)
     ok &= full.boxes_crop[:, 0].tolist() == [0.0] * 6 + [1.0] * 5
+    # training: DDP's gradient averaging as one all-reduce of the flat gradient buffer
+    from cosypose_amd.train_engine import allreduce_gradients
+    gflat = torch.full((1000,), float(rank + 1))
+    allreduce_gradients(gflat)
+    ok &= bool(torch.allclose(gflat, torch.full((1000,), 1.5)))
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
