@@ -47,6 +47,8 @@ _SIGNATURES = {
     'cosy_dw_train_forward': ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _P], _I),
     'cosy_dw_train_backward_data': ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _P], _I),
     'cosy_dw_train_backward_weight': ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P], _I),
+    'cosy_wgrad_tall_supported': ([_L, _I, _I], _I),
+    'cosy_wgrad_tall': ([_P, _P, _L, _I, _I, _P, _P, _P], _I),
     'cosy_rows_mean': ([_P, _I, _I, _I, _P, _P, _P], _I),
     'cosy_rows_dot': ([_P, _P, _I, _I, _I, _P, _P, _P], _I),
     'cosy_rows_scale': ([_P, _P, _P, _F, _I, _I, _I, _P, _P], _I),

@@ -228,40 +228,124 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restric
     }
     ((f32x4*)dx)[i] = acc;
 }
-// dw[tap][c] = sum over output pixels of dy[p][c] * x[p_in(tap)][c]; lanes = channels, waves/slabs = output pixels
-template <int KK>
+// dw[tap][c] = sum over output pixels of dy[p][c] * x[p_in(tap)][c].  Lanes = channels; a unit of work is a run of 8
+// consecutive output pixels of one row: the K input rows under it are loaded once each (sliding window along x) and
+// feed all K*K tap accumulators (registers, static indices).  Waves / slabs stride over the units.
+template <int K, int S>
 __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy, int H, int W, int C,
-                                                            int Ho, int Wo, int s, int lo, long Mo, int rows_per_slab,
+                                                            int Ho, int Wo, int lo, long nunits, int units_per_slab,
                                                             double* __restrict__ partial) {
-    constexpr int K = KK == 9 ? 3 : 5;
+    constexpr int KK = K * K, RUN = 8, XS = (RUN - 1) * S + K;
     __shared__ double lds[4 * 64 * KK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane, slab = blockIdx.y;
-    const long r0 = (long)slab * rows_per_slab, r1 = min(Mo, r0 + rows_per_slab);
-    double acc[KK];
+    const long u0 = (long)slab * units_per_slab, u1 = min(nunits, u0 + units_per_slab);
+    const int runs = (Wo + RUN - 1) / RUN;
+    float acc[KK];
 #pragma unroll
-    for (int q = 0; q < KK; ++q) acc[q] = 0.;
+    for (int q = 0; q < KK; ++q) acc[q] = 0.f;
     if (c < C)
-        for (long r = r0 + wave; r < r1; r += 4) {
-            const int ox = (int)(r % Wo);
-            const long t = r / Wo;
+        for (long u = u0 + wave; u < u1; u += 4) {
+            const int run = (int)(u % runs);
+            const long t = u / runs;
             const int oy = (int)(t % Ho);
             const long b = t / Ho;
-            const float d = dy[r * C + c];
+            const int ox0 = run * RUN;
+            float d[RUN];
+#pragma unroll
+            for (int j = 0; j < RUN; ++j) d[j] = ox0 + j < Wo ? dy[((b * Ho + oy) * Wo + ox0 + j) * C + c] : 0.f;
+            const int ixb = ox0 * S - lo;
 #pragma unroll
             for (int ky = 0; ky < K; ++ky) {
-                const int iy = oy * s - lo + ky;
+                const int iy = oy * S - lo + ky;
+                if (iy < 0 || iy >= H) continue;
+                const float* xr = x + ((b * H + iy) * W) * C + c;
+                float xs[XS];
 #pragma unroll
-                for (int kx = 0; kx < K; ++kx) {
-                    const int ix = ox * s - lo + kx;
-                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) acc[ky * K + kx] += (double)d * x[((b * H + iy) * W + ix) * C + c];
+                for (int j = 0; j < XS; ++j) {
+                    const int ix = ixb + j;
+                    xs[j] = (ix >= 0 && ix < W) ? xr[(long)ix * C] : 0.f;
+                }
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                    for (int j = 0; j < RUN; ++j) acc[ky * K + kx] += d[j] * xs[j * S + kx];
+            }
+        }
+    double accd[KK];
+#pragma unroll
+    for (int q = 0; q < KK; ++q) accd[q] = acc[q];
+    slab_write<KK>(accd, lds, partial, slab, C, c);
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient of a 1x1 convolution over MANY rows and few channels (the high-resolution blocks):
+// dW[n][k] = sum_m dY[m][n] X[m][k], M ~ 10^5..10^6, N,K <= 192.  rocBLAS runs these tall-skinny products at a few
+// percent of the HBM rate; here every wave streams its rows once through v_mfma_f32_16x16x4_f32 (A = 4 rows of dY,
+// B = the same 4 rows of X) into TN x TK register tiles, workgroups write partial tiles, a combine pass adds them.
+// ------------------------------------------------------------------------------------------
+template <int TN, int TK>
+__global__ __launch_bounds__(256) void wgrad_tall_kernel(const float* __restrict__ dY, const float* __restrict__ X, long M, int N, int K,
+                                                         int rows_per_wave, float* __restrict__ partial) {
+    __shared__ float lds[4 * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int n_base = blockIdx.y * TN * 16;
+    const long r0 = ((long)blockIdx.x * 4 + wave) * rows_per_wave, r1 = min(M, r0 + rows_per_wave);
+    f32x4 acc[TN][TK];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TK; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long r = r0; r < r1; r += 8) {     // two 4-row MFMA steps per iteration: 2 x (TN + TK) loads in flight
+        float av[2][TN], bv[2][TK];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long row = r + h * 4 + kq;
+            const bool ok = row < r1;
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const int n = n_base + a * 16 + i;
+                av[h][a] = (ok && n < N) ? dY[row * N + n] : 0.f;
+            }
+#pragma unroll
+            for (int b = 0; b < TK; ++b) {
+                const int k = b * 16 + i;
+                bv[h][b] = (ok && k < K) ? X[row * K + k] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TK; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][a], bv[h][b], acc[a][b], 0, 0, 0);
+    }
+    // the 4 waves' tiles are added through LDS one tile at a time; wave 0 writes the workgroup's partial
+    float* out = partial + (size_t)blockIdx.x * N * K;
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TK; ++b) {
+            __syncthreads();
+            *(f32x4*)(lds + wave * 256 + lane * 4) = acc[a][b];
+            __syncthreads();
+            if (wave == 0) {
+                const f32x4 s0 = *(const f32x4*)(lds + lane * 4), s1 = *(const f32x4*)(lds + 256 + lane * 4);
+                const f32x4 s2 = *(const f32x4*)(lds + 512 + lane * 4), s3 = *(const f32x4*)(lds + 768 + lane * 4);
+                const int k = b * 16 + i;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n_base + a * 16 + 4 * kq + q;
+                    if (n < N && k < K) out[(size_t)n * K + k] = ((s0[q] + s1[q]) + s2[q]) + s3[q];
                 }
             }
         }
-    slab_write<KK>(acc, lds, partial, slab, C, c);
 }
+
 // out[j] = sum over slabs of partial[slab*n + j]; lanes = 64 consecutive j, 16 waves stride over the slabs
-__global__ __launch_bounds__(1024) void combine_partials_kernel(const double* __restrict__ partial, int nslab, long n, double* __restrict__ out_d,
+template <typename PT>
+__global__ __launch_bounds__(1024) void combine_partials_kernel(const PT* __restrict__ partial, int nslab, long n, double* __restrict__ out_d,
                                                                 float* __restrict__ out_f) {
     __shared__ double lds[16 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -608,7 +692,7 @@ int cosy_bn_train_stats(const float* x, long M, int C, float eps, float momentum
     hipLaunchKernelGGL(bn_stats_kernel, dim3(g.cgroups, g.nslab), dim3(256), 0, s, x, M, C, g.rows_per_slab, (double*)workspace);
     COSY_CHECK_HIP(hipGetLastError());
     double* sums = (double*)workspace + (size_t)g.nslab * 2 * C;
-    hipLaunchKernelGGL(combine_partials_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, (const double*)workspace, g.nslab, (long)2 * C, sums,
+    hipLaunchKernelGGL(combine_partials_kernel<double>, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, (const double*)workspace, g.nslab, (long)2 * C, sums,
                        (float*)nullptr);
     COSY_CHECK_HIP(hipGetLastError());
     LAUNCH1D(bn_stats_final_kernel, C, s, (const double*)sums, M, C, eps, momentum, mean, rstd, running_mean, running_var);
@@ -635,7 +719,7 @@ int cosy_bn_train_backward(const float* dout, const float* x, const float* mean,
                        HW, g.rows_per_slab, (double*)workspace);
     COSY_CHECK_HIP(hipGetLastError());
     // this call's sums (needed by dx) into `sums`; the parameter gradients accumulate on request
-    hipLaunchKernelGGL(combine_partials_kernel, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, (const double*)workspace, g.nslab, (long)2 * C,
+    hipLaunchKernelGGL(combine_partials_kernel<double>, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, (const double*)workspace, g.nslab, (long)2 * C,
                        (double*)nullptr, sums);
     COSY_CHECK_HIP(hipGetLastError());
     LAUNCH1D(bn_bwd_final_kernel, C, s, (const float*)sums, C, dgamma, dbeta, accumulate);
@@ -674,18 +758,52 @@ int cosy_dw_train_backward_weight(const float* x, const float* dy, int B, int H,
     COSY_REQUIRE(x && dy && dwt && workspace && (k == 3 || k == 5) && (stride == 1 || stride == 2), "dw_train_backward_weight: bad argument");
     const int lo = stride == 1 ? (k - 1) / 2 : (k - 2) / 2;
     const int Ho = stride == 1 ? H : (H + (k - 2) - k) / 2 + 1, Wo = stride == 1 ? W : (W + (k - 2) - k) / 2 + 1;
-    const long Mo = (long)B * Ho * Wo;
-    COSY_REQUIRE(Mo > 0, "dw_train_backward_weight: empty batch");
-    const RedGeom g = red_geom(Mo, C);
-    if (k == 3)
-        hipLaunchKernelGGL(dw_bwd_weight_kernel<9>, dim3(g.cgroups, g.nslab), dim3(256), 0, s, x, dy, H, W, C, Ho, Wo, stride, lo, Mo,
-                           g.rows_per_slab, (double*)workspace);
-    else
-        hipLaunchKernelGGL(dw_bwd_weight_kernel<25>, dim3(g.cgroups, g.nslab), dim3(256), 0, s, x, dy, H, W, C, Ho, Wo, stride, lo, Mo,
-                           g.rows_per_slab, (double*)workspace);
+    const long nunits = (long)B * Ho * cdiv(Wo, 8);
+    COSY_REQUIRE(nunits > 0, "dw_train_backward_weight: empty batch");
+    RedGeom g = red_geom(nunits * 4, C);     // a unit is 8 pixels: ask for slabs as if there were nunits*4 rows
+    const int ups = (int)cdiv(nunits, g.nslab);
+    g.nslab = cdiv(nunits, ups);
+    const dim3 grid(g.cgroups, g.nslab);
+#define DW_BW(KS, ST) hipLaunchKernelGGL((dw_bwd_weight_kernel<KS, ST>), grid, dim3(256), 0, s, x, dy, H, W, C, Ho, Wo, lo, nunits, ups, (double*)workspace)
+    if (k == 3 && stride == 1) DW_BW(3, 1);
+    else if (k == 3) DW_BW(3, 2);
+    else if (stride == 1) DW_BW(5, 1);
+    else DW_BW(5, 2);
+#undef DW_BW
     COSY_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(combine_partials_kernel, dim3(cdiv((long)k * k * C, 64)), dim3(1024), 0, s, (const double*)workspace, g.nslab,
+    hipLaunchKernelGGL(combine_partials_kernel<double>, dim3(cdiv((long)k * k * C, 64)), dim3(1024), 0, s, (const double*)workspace, g.nslab,
                        (long)k * k * C, (double*)nullptr, dwt);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+
+// dW (N,K) = dY^T (N,M) . X (M,K) for tall-skinny shapes; returns COSY_EINVAL (nothing launched) when the shape is not
+// one this kernel is built for -- the host then uses the library GEMM.
+int cosy_wgrad_tall_supported(long M, int N, int K) {
+    const int tk = cdiv(K, 16), tn = cdiv(N, 16);
+    const bool tk_ok = tk == 2 || tk == 3 || tk == 4 || tk == 9 || tk == 12;
+    return M >= 32768 && tk_ok && tn >= 2 && (size_t)1024 * N * K * sizeof(float) <= cosy_train_workspace_bytes();
+}
+int cosy_wgrad_tall(const float* dY, const float* X, long M, int N, int K, float* dW, void* workspace, cosy_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    COSY_REQUIRE(dY && X && dW && workspace, "wgrad_tall: null argument");
+    COSY_REQUIRE(cosy_wgrad_tall_supported(M, N, K), "wgrad_tall: shape M=%ld N=%d K=%d not supported", M, N, K);
+    const int tk = cdiv(K, 16), tn = cdiv(N, 16);
+    const int TN = (tn % 3 == 0 && tk <= 4) ? 3 : 2;      // n-tiles per workgroup; grid.y covers the rest
+    const int gy = cdiv(tn, TN);
+    int nwg = 1024;
+    int rpw = (int)cdiv(M, (long)nwg * 4);
+    rpw = cdiv(rpw, 8) * 8;
+    nwg = (int)cdiv(M, (long)rpw * 4);
+    const dim3 grid(nwg, gy);
+    float* partial = (float*)workspace;
+#define WG(A, B_) hipLaunchKernelGGL((wgrad_tall_kernel<A, B_>), grid, dim3(256), 0, s, dY, X, M, N, K, rpw, partial)
+    if (TN == 3) { if (tk == 2) WG(3, 2); else if (tk == 3) WG(3, 3); else WG(3, 4); }
+    else { if (tk == 2) WG(2, 2); else if (tk == 3) WG(2, 3); else if (tk == 4) WG(2, 4); else if (tk == 9) WG(2, 9); else WG(2, 12); }
+#undef WG
+    COSY_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(combine_partials_kernel<float>, dim3(cdiv((long)N * K, 64)), dim3(1024), 0, s, (const float*)partial, nwg, (long)N * K,
+                       (double*)nullptr, dW);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }

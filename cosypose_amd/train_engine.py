@@ -121,6 +121,18 @@ def act_backward(x, dy, kind):
 SWISH, SIGMOID = 0, 1
 
 
+def wgrad(dY, X):
+    """dW (N,K) = dY^T X for dY (M,N), X (M,K): the streaming MFMA kernel for the tall-skinny products of the
+    high-resolution blocks, the library GEMM otherwise."""
+    M, N = dY.shape
+    K = X.shape[1]
+    if lib().cosy_wgrad_tall_supported(M, N, K):
+        out = torch.empty(N, K, device=dY.device)
+        check(lib().cosy_wgrad_tall(ptr(dY), ptr(X), M, N, K, ptr(out), ptr(_workspace(dY.device)), stream()))
+        return out
+    return dY.t() @ X
+
+
 # ---------------------------------------------------------------------------------------------
 # the network as one autograd node
 # ---------------------------------------------------------------------------------------------
@@ -236,7 +248,7 @@ class _Net:
         da = rows_broadcast(dfeat, 1.0 / (H * W), B, H * W, arch.HEAD_C)
         draw = self._bn_b(tape, grads, 'backbone._bn1', da)
         wh = P['backbone._conv_head.weight']
-        grads['backbone._conv_head.weight'] = (draw.t() @ x_head).view_as(wh)
+        grads['backbone._conv_head.weight'] = wgrad(draw, x_head).view_as(wh)
         dx = draw @ wh.view(arch.HEAD_C, -1)
         for i in reversed(range(len(arch.B3_BLOCKS))):
             k, s, e, cin, cout = arch.B3_BLOCKS[i]
@@ -247,7 +259,7 @@ class _Net:
             dout = dx
             draw = self._bn_b(tape, grads, p + '_bn2', dout)
             wp = P[p + '_project_conv.weight']
-            grads[p + '_project_conv.weight'] = (draw.t() @ a2).view_as(wp)
+            grads[p + '_project_conv.weight'] = wgrad(draw, a2).view_as(wp)
             da2 = draw @ wp.view(cout, cmid)
             # squeeze-excite backward
             dg = rows_dot(da2, a1, B, HWo, cmid)
@@ -268,14 +280,14 @@ class _Net:
             if e != 1:
                 draw = self._bn_b(tape, grads, p + '_bn0', da0)
                 we = P[p + '_expand_conv.weight']
-                grads[p + '_expand_conv.weight'] = (draw.t() @ inp).view_as(we)
+                grads[p + '_expand_conv.weight'] = wgrad(draw, inp).view_as(we)
                 dinp = draw @ we.view(cmid, cin)
             else:
                 dinp = da0
             dx = dinp + dout if skip else dinp
         draw = self._bn_b(tape, grads, 'backbone._bn0', dx)
         cols = tape['stem']
-        grads['backbone._conv_stem.weight'] = (draw.t() @ cols).view(arch.STEM_C, 3, 3, 6).permute(0, 3, 1, 2).contiguous()
+        grads['backbone._conv_stem.weight'] = wgrad(draw, cols).view(arch.STEM_C, 3, 3, 6).permute(0, 3, 1, 2).contiguous()
         return grads
 
 

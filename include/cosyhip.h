@@ -200,6 +200,11 @@ int cosy_dw_train_backward_data(const float* dy, const float* wt, int B, int H, 
                                 cosy_stream_t stream);
 int cosy_dw_train_backward_weight(const float* x, const float* dy, int B, int H, int W, int C, int k, int stride, float* dwt,
                                   void* workspace, cosy_stream_t stream);
+/* weight gradient of a 1x1 convolution over many rows and few channels: dW (N,K) = dY^T (N,M) . X (M,K), dY (M,N), X (M,K)
+ * row-major.  cosy_wgrad_tall_supported says whether the MFMA streaming kernel is built for the shape (M >= 32768,
+ * K in 16-column tiles of 2,3,4,9 or 12); other shapes are plain library GEMMs on the host side. */
+int cosy_wgrad_tall_supported(long M, int N, int K);
+int cosy_wgrad_tall(const float* dY, const float* X, long M, int N, int K, float* dW, void* workspace, cosy_stream_t stream);
 /* per-sample reductions / broadcasts over the HW pixels of a (B,HW,C) activation: mean (adaptive_avg_pool2d),
  * sum of a*a2 (gradient of the squeeze-excite gate), a*g[b,c] (+ add[b,c]*add_scale), v[b,c]*scale broadcast */
 int cosy_rows_mean(const float* a, int B, int HW, int C, float* out, void* workspace, cosy_stream_t stream);
