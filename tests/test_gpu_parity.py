@@ -557,3 +557,90 @@ def test_training_gradients_vs_oracle_with_drop_connect(oracle, golden_train, go
         go = grads_o[n]
         scale = max(np.linalg.norm(go.ravel()), 1e-6)
         assert _grad_err(p.grad.cpu().numpy(), go, scale) < GRAD_TOL, n
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs[2] and configs[3] as parity cases (the bench line is configs[1])
+# ---------------------------------------------------------------------------------------------
+def _oracle_loop(oracle, golden_sd, images, K, im_ids, obj, TCO, mesh_table, seeds, hw):
+    """n iterations of the reference loop on the CPU oracle (torch-CPU backbone), per-object frames gathered as the
+    reference does (pose_predictor.py:41)."""
+    ref = oracle.TorchRef(golden_sd)
+    return oracle.pose_predictor_forward(images[im_ids], K[im_ids], obj, TCO, mesh_table, None,
+                                         lambda n, T, Kc: syn.make_renders(seeds + n, len(obj), *hw), n_iterations=4, render_size=hw,
+                                         backbone=ref.net_forward)
+
+
+def test_config2_refiner_only_fp16_tless_shape(model, oracle, golden_sd, mesh_table):
+    """configs[2]: refiner n_iter=4 from external coarse poses (n_coarse=0), 540x720 frames, fp16 storage; a rank's share
+    (12 of the 1024 crops) against the fp32 CPU oracle at the low-precision bound of test_refiner_loop_low_precision."""
+    import pandas as pd
+    from cosypose_amd import tensor_collection as tc
+    from cosypose_amd.pose_predictor import CoarseRefinePosePredictor
+    D, N, h, w, hw = 12, 3, 540, 720, (240, 320)
+    labels21 = model.mesh_db.labels
+    images, K = syn.make_frames(71, N, h, w), syn.make_K(N, h, w)
+    rs = np.random.RandomState(72)
+    obj, im = rs.randint(0, 21, D).astype(np.int32), np.sort(rs.randint(0, N, D)).astype(np.int32)
+    TCO = syn.make_TCO(73, D)
+    init = tc.PandasTensorCollection(infos=pd.DataFrame(dict(label=labels21[obj], batch_im_id=im)), poses=dev(TCO))
+    model.renderer = FakeRenderer(500)
+    model.compute_dtype = 'fp16'
+    try:
+        pred = CoarseRefinePosePredictor(coarse_model=None, refiner_model=model, bsz_objects=5)      # ragged chunks 5+5+2
+        final, allp = pred.get_predictions(dev(images), dev(K), data_TCO_init=init, n_coarse_iterations=0, n_refiner_iterations=4)
+    finally:
+        model.compute_dtype = 'fp32'
+    assert list(allp) == ['external_coarse'] + [f'refiner/iteration={i}' for i in range(1, 5)]
+    # the fake renderer is called once per (chunk, iteration): rebuild the same sequence per chunk for the oracle
+    want = np.zeros((D, 4, 4), np.float32)
+    call = 500
+    for s in range(0, D, 5):
+        e = min(s + 5, D)
+        ref = oracle.TorchRef(golden_sd)
+        out = oracle.pose_predictor_forward(images[im[s:e]], K[im[s:e]], obj[s:e], TCO[s:e], mesh_table, None,
+                                            lambda n, T, Kc, c=call, m=e - s: syn.make_renders(c + n, m, *hw), n_iterations=4,
+                                            render_size=hw, backbone=ref.net_forward)
+        want[s:e] = out['iteration=4']['TCO_output']
+        call += 4
+    assert rel_err(final.poses.cpu().numpy(), want) < 3e-3
+
+
+def test_config3_mixed_frame_sizes_skewed_shards(model, oracle, golden_sd, mesh_table):
+    """configs[3]: candidates from datasets with different frame sizes (640x480, 720x540, 1280x960) in skewed shares,
+    coarse 1 + refiner 1; every group must match the oracle, and the size-balanced assignment must even out the shares."""
+    import pandas as pd
+    from cosypose_amd import tensor_collection as tc
+    from cosypose_amd.pose_predictor import CoarseRefinePosePredictor
+    from cosypose_amd.distributed import balanced_assignment
+    labels21 = model.mesh_db.labels
+    pred = CoarseRefinePosePredictor(coarse_model=model, refiner_model=model, bsz_objects=4)
+    counts = []
+    for gi, ((h, w), D) in enumerate((((480, 640), 7), ((540, 720), 3), ((960, 1280), 2))):
+        images, K = syn.make_frames(80 + gi, 2, h, w), syn.make_K(2, h, w)
+        obj, im, boxes = syn.make_detections(90 + gi, D, 2, 21, h, w)
+        det = tc.PandasTensorCollection(infos=pd.DataFrame(dict(label=labels21[obj], batch_im_id=im, score=1.0)), bboxes=dev(boxes))
+        model.renderer = FakeRenderer(600 + 10 * gi)
+        final, allp = pred.get_predictions(dev(images), dev(K), detections=det, n_coarse_iterations=1, n_refiner_iterations=1)
+        assert len(final) == D and torch.isfinite(final.poses).all()
+        # oracle: coarse then refiner, chunked by 4 with the same renderer call order (all coarse chunks first)
+        TCO0 = oracle.tco_init_from_boxes(boxes, K[im], z=1.0)
+        call = 600 + 10 * gi
+        stage_in = TCO0
+        for stage in range(2):
+            outp = np.zeros((D, 4, 4), np.float32)
+            for s in range(0, D, 4):
+                e = min(s + 4, D)
+                ref = oracle.TorchRef(golden_sd)
+                o = oracle.pose_predictor_forward(images[im[s:e]], K[im[s:e]], obj[s:e], stage_in[s:e], mesh_table, None,
+                                                  lambda n, T, Kc, c=call, m=e - s: syn.make_renders(c, m, 240, 320), n_iterations=1,
+                                                  render_size=(240, 320), backbone=ref.net_forward)
+                outp[s:e] = o['iteration=1']['TCO_output']
+                call += 1
+            stage_in = outp
+        assert rel_err(final.poses.cpu().numpy(), stage_in) < 1e-4, (h, w)
+        counts.append(D)
+    # load-imbalanced shares [7,3,2] over 2 ranks: contiguous split is skewed, the balanced assignment is not
+    shares = balanced_assignment(np.array(counts), 2)
+    loads = sorted(int(sum(counts[i] for i in ids)) for ids in shares)
+    assert loads == [5, 7]
