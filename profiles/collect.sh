@@ -19,6 +19,7 @@ pass() { # name counters...
 pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+pass mfma MfmaUtil SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr TA_TOTAL_WAVEFRONTS_sum
 python profiles/summarize.py $OUT > $OUT/summary.txt 2>&1
 tail -60 $OUT/summary.txt

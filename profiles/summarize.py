@@ -56,6 +56,23 @@ def main(root):
                        write_bytes=1024 * sum(v['WRITE_SIZE']) / len(v['WRITE_SIZE']), launches=len(v['FETCH_SIZE']))
                for k, v in agg.items() if v['FETCH_SIZE'] and v['WRITE_SIZE'] and not k.startswith('__amd')}
     json.dump(traffic, open(f'{root}/pmc_traffic.json', 'w'), indent=1)
+    # matrix-core utilisation per kernel: rocprofv3's MfmaUtil (= sum SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * #SIMD), percent)
+    # and the MFMA FLOP rate from SQ_INSTS_VALU_MFMA_MOPS_BF16 * 512 over the kernel's mean duration
+    mf = defaultdict(lambda: defaultdict(list))
+    for (k, g), c in ctr.items():
+        for n in ('MfmaUtil', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_VALU_MFMA_MOPS_BF16'):
+            mf[k][n] += c.get(n, [])
+    rows = []
+    for k, v in mf.items():
+        if v['MfmaUtil'] and bykern[k][1] and sum(v['SQ_INSTS_VALU_MFMA_MOPS_BF16']) > 0:
+            t_us = bykern[k][0] / bykern[k][1]
+            mops = sum(v['SQ_INSTS_VALU_MFMA_MOPS_BF16']) / len(v['SQ_INSTS_VALU_MFMA_MOPS_BF16'])
+            rows.append((sum(v['MfmaUtil']) / len(v['MfmaUtil']), mops * 512 / (t_us * 1e-6) / 1e12, t_us, k))
+    if rows:
+        print('== matrix-core utilisation per kernel (PMC pass `mfma`): MfmaUtil %, MFMA TFLOP/s issued, avg us')
+        for u, tf, t_us, k in sorted(rows, reverse=True):
+            print(f'{u:6.1f}%  {tf:8.1f} TFLOP/s  {t_us:8.1f} us  {k}')
+        print()
     print(f'== per-kernel time (rocprofv3 --kernel-trace), total {total / 1e3:.2f} ms')
     for k, (t, n) in sorted(bykern.items(), key=lambda kv: -kv[1][0])[:25]:
         print(f'{100 * t / total:5.1f}%  n={n:5d}  avg {t / n:9.1f} us  {k}')
