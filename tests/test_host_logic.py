@@ -122,3 +122,37 @@ def test_sharding():
     parts = balanced_assignment(costs, 8)
     loads = [costs[p].sum() for p in parts]
     assert sorted(np.concatenate(parts).tolist()) == list(range(50)) and max(loads) - min(loads) <= 4
+
+
+def test_detection_and_bop_csv_formats(tmp_path):
+    """detector output contract (detector.py:19-72) and the BOP csv round trip (run_custom_scenario.py:26-58)"""
+    import pandas as pd
+    from cosypose_amd import io_formats, tensor_collection as tc
+    from cosypose_amd import synthetic as syn
+    per_image = [dict(boxes=np.array([[10, 20, 110, 220], [5, 5, 50, 60], [30, 40, 90, 100]], np.float32),
+                      labels=np.array(['obj_000002', 'obj_000005', 'obj_000002']), scores=np.array([0.9, 0.2, 0.95])),
+                 dict(boxes=np.zeros((0, 4), np.float32), labels=np.array([]), scores=np.array([])),
+                 dict(boxes=np.array([[1, 2, 3, 4]], np.float32), labels=np.array(['obj_000007']), scores=np.array([0.5]))]
+    det = io_formats.make_detections(per_image, device='cpu')
+    assert list(det.infos.columns) == ['batch_im_id', 'label', 'score'] and det.bboxes.shape == (4, 4)
+    assert det.infos['batch_im_id'].tolist() == [0, 0, 0, 2]
+    det = io_formats.make_detections(per_image, device='cpu', detection_th=0.3)
+    assert det.infos['label'].tolist() == ['obj_000002', 'obj_000002', 'obj_000007']
+    det = io_formats.make_detections(per_image, device='cpu', detection_th=0.3, one_instance_per_class=True)
+    assert sorted(zip(det.infos['label'], det.infos['score'])) == [('obj_000002', 0.95), ('obj_000007', 0.5)]
+    assert det.bboxes[det.infos['label'].tolist().index('obj_000002')].tolist() == [30, 40, 90, 100]
+    assert len(io_formats.make_detections([dict(boxes=np.zeros((0, 4)), labels=[], scores=[])], device='cpu')) == 0
+    # refined poses -> BOP csv (t in mm, row-major R) -> candidates
+    poses = torch.from_numpy(syn.make_TCO(5, 3))
+    infos = pd.DataFrame(dict(label=['obj_000002', 'obj_000007', 'obj_000021'], score=[0.9, 0.5, 0.25], scene_id=[48, 48, 49], view_id=[1, 1, 733]))
+    preds = tc.PandasTensorCollection(infos=infos, poses=poses)
+    path = tmp_path / 'bop.csv'
+    io_formats.tc_to_csv(preds, path)
+    lines = path.read_text().split('\n')
+    assert lines[0] == 'scene_id,im_id,obj_id,score,R,t,time' and len(lines) == 4
+    f = lines[1].split(',')
+    assert f[:3] == ['48', '1', '2'] and len(f[4].split(' ')) == 9 and len(f[5].split(' ')) == 3
+    assert abs(float(f[5].split(' ')[2]) - 1e3 * float(poses[0, 2, 3])) < 1e-3        # millimetres
+    back = io_formats.read_csv_candidates(path)
+    assert back.infos['label'].tolist() == infos['label'].tolist() and back.infos['view_id'].tolist() == [1, 1, 733]
+    assert torch.allclose(back.poses, poses, atol=1e-6)
