@@ -99,6 +99,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='do not record per-kernel HIP events in the timed region')
     ap.add_argument('--layers', action='store_true', help='print the per-launch table to stderr')
+    ap.add_argument('--renderer', default='pregenerated', choices=['pregenerated', 'hip'],
+                    help="renderer.render source: pre-generated device images (default: the reference's renderer is outside the "
+                         "path) or the on-device HIP rasteriser (SURVEY 8f-1) rendering every crop in every iteration")
     args = ap.parse_args()
 
     import torch
@@ -133,6 +136,10 @@ def main():
     g = torch.Generator(device='cuda'); g.manual_seed(seed)
     renders = [torch.rand(min(D, args.bsz_objects), 3, H, W, device='cuda', generator=g) for _ in range(5)]
     renderer = SyntheticRenderer(renders)
+    if args.renderer == 'hip':
+        from cosypose_amd.rasterizer import RenderMeshes, HipBatchRenderer
+        mv, mf, mc = syn.make_render_meshes(7, n_obj, n_lat=48, n_lon=64)        # 6,016 triangles per object
+        renderer = HipBatchRenderer(RenderMeshes(labels, mv, mf, mc).cuda())
     coarse = build_model(0, mesh_db, (H, W), args.dtype, renderer)
     refiner = build_model(1, mesh_db, (H, W), args.dtype, renderer)
     predictor = CoarseRefinePosePredictor(coarse_model=coarse, refiner_model=refiner, bsz_objects=args.bsz_objects)
@@ -236,7 +243,9 @@ def main():
             'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[1]: {D} detections/GPU over {n_frames} frames {h}x{w}, {n_obj} objects, '
-                                   f'coarse {n_coarse} + refiner {n_refine} iterations, {H}x{W} crops, synthetic on-device renders',
+                                   f'coarse {n_coarse} + refiner {n_refine} iterations, {H}x{W} crops, ' +
+                                   ('synthetic on-device renders' if args.renderer == 'pregenerated' else
+                                    'renders by the on-device HIP rasteriser (6k-triangle meshes) inside the loop'),
                        'pose_iterations_per_step_per_gpu': iters_per_step, 'bsz_objects': args.bsz_objects,
                        'parallelism': f'candidate-sharded x{world}, 1 all-gather of refined poses per step'},
             'roofline': roofline,

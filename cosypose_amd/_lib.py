@@ -39,6 +39,8 @@ _SIGNATURES = {
     'cosy_loss_co_symmetric': ([_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P], _I),
     'cosy_loss_refiner_disentangled': ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P], _I),
     'cosy_dists_add': ([_P, _P, _P, _P, _I, _I, _I, _P, _P], _I),
+    'cosy_render_scratch_bytes': ([_I, _I, _I, _I], _c.c_size_t),
+    'cosy_render_meshes': ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P], _I),
     'cosy_train_workspace_bytes': ([], _c.c_size_t),
     'cosy_crop_pack_to': ([_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     'cosy_bn_train_stats': ([_P, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P], _I),

@@ -136,3 +136,42 @@ def make_training_batch(seed, B, n_obj=21, h=480, w=640):
     TCO = make_TCO(seed + 1, B)
     obj = np.random.RandomState(seed + 2).randint(0, n_obj, B).astype(np.int32)
     return frames, K, TCO, obj
+
+
+def make_render_meshes(seed, n_obj, n_lat=24, n_lon=32):
+    """Closed triangle meshes for the rasteriser: bumpy ellipsoids with the half-extents make_mesh_points(seed, ...) draws
+    (so that geometry points and render meshes describe the same objects) and smooth vertex colours.
+    -> verts list [(V,3)], faces list [(F,3) int32], colors list [(V,3)]"""
+    rs = np.random.RandomState(seed)
+    ext = rs.uniform(0.03, 0.12, (n_obj, 1, 3))
+    rs = np.random.RandomState(seed + 1000)
+    lat = np.linspace(0, np.pi, n_lat + 1)[1:-1]
+    lon = np.linspace(0, 2 * np.pi, n_lon, endpoint=False)
+    verts_l, faces_l, colors_l = [], [], []
+    ring = lambda i: 1 + i * n_lon
+    faces = []
+    for j in range(n_lon):
+        faces.append((0, ring(0) + j, ring(0) + (j + 1) % n_lon))
+    for i in range(len(lat) - 1):
+        for j in range(n_lon):
+            a, b = ring(i) + j, ring(i) + (j + 1) % n_lon
+            c, d = ring(i + 1) + j, ring(i + 1) + (j + 1) % n_lon
+            faces += [(a, c, b), (b, c, d)]
+    south = 1 + len(lat) * n_lon
+    for j in range(n_lon):
+        faces.append((south, ring(len(lat) - 1) + (j + 1) % n_lon, ring(len(lat) - 1) + j))
+    faces = np.asarray(faces, np.int32)
+    for o in range(n_obj):
+        dirs = [np.array([0, 0, 1.0])]
+        for t in lat:
+            for p in lon:
+                dirs.append(np.array([np.sin(t) * np.cos(p), np.sin(t) * np.sin(p), np.cos(t)]))
+        dirs.append(np.array([0, 0, -1.0]))
+        dirs = np.asarray(dirs)
+        f = rs.uniform(1, 3, 3); ph = rs.uniform(0, 6.28, 3)
+        bump = 1 + 0.15 * np.sin(f[0] * dirs[:, 0] * 3 + ph[0]) * np.cos(f[1] * dirs[:, 1] * 3 + ph[1]) + 0.1 * np.sin(f[2] * dirs[:, 2] * 4 + ph[2])
+        verts_l.append((dirs * bump[:, None] * ext[o]).astype(np.float32))
+        base = rs.uniform(0.2, 0.9, 3)
+        colors_l.append(np.clip(base + 0.3 * dirs * rs.uniform(-1, 1, 3), 0, 1).astype(np.float32))
+        faces_l.append(faces)
+    return verts_l, faces_l, colors_l

@@ -228,6 +228,17 @@ int cosy_grad_norm_clip(const float* grads, long n, float max_norm, float* norm_
 int cosy_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, const float* norm_and_coef, cosy_stream_t stream);
 
+/* ---- on-device mesh rasteriser behind renderer.render (interface of BulletBatchRenderer.render,
+ * cosypose/rendering/bullet_batch_renderer.py:46-90; camera model of simulator/camera.py:9-33).  verts / colors
+ * (n_obj,V,3), faces (n_obj,F,3) int32 (padded), n_faces (n_obj); per crop obj_id, TCO (B,4,4), K (B,3,3) ->
+ * rgb (B,3,H,W) in [0,1] (black background, non-finite poses -> black) and optional depth (B,H,W) in metres.
+ * Shading = vertex colour x (ambient + diffuse |n.l|), l = light direction in the camera frame (PyBullet's OpenGL shading
+ * is third-party: pixel values parity-unpinned).  `scratch`: cosy_render_scratch_bytes(B,V,H,W) bytes. */
+size_t cosy_render_scratch_bytes(int B, int V, int H, int W);
+int cosy_render_meshes(const float* verts, const float* colors, const int* faces, const int* n_faces, const int* obj_id,
+                       const float* TCO, const float* K, int B, int V, int F, int H, int W, float ambient, float diffuse,
+                       float light_x, float light_y, float light_z, float* rgb, float* depth, void* scratch, cosy_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -644,3 +644,75 @@ def test_config3_mixed_frame_sizes_skewed_shards(model, oracle, golden_sd, mesh_
     shares = balanced_assignment(np.array(counts), 2)
     loads = sorted(int(sum(counts[i] for i in ids)) for ids in shares)
     assert loads == [5, 7]
+
+
+# ---------------------------------------------------------------------------------------------
+# on-device mesh rasteriser behind renderer.render
+# ---------------------------------------------------------------------------------------------
+def _render_setup(n_obj=5):
+    from cosypose_amd.rasterizer import RenderMeshes, HipBatchRenderer
+    labels = np.array([f'obj_{i:06d}' for i in range(1, n_obj + 1)])
+    v, f, c = syn.make_render_meshes(7, n_obj)
+    meshes = RenderMeshes(labels, v, f, c).cuda()
+    return labels, (v, f, c), meshes, HipBatchRenderer(meshes)
+
+
+def test_rasteriser_vs_cpu_twin_and_geometry(oracle):
+    labels, (v, f, c), meshes, renderer = _render_setup()
+    B, H, W = 6, 240, 320
+    obj = np.array([0, 1, 2, 3, 4, 2], np.int32)
+    TCO = syn.make_TCO(11, B, z_range=(0.5, 1.0), xy=0.05)
+    K = np.tile(np.array([[520., 0, 158.3], [0, 515., 121.7], [0, 0, 1]], np.float32), (B, 1, 1))
+    TCO[5, 0, 0] = np.nan                                          # non-finite pose -> black image (bullet_batch_renderer.py:25-36)
+    rgb, depth = renderer.render([dict(name=labels[o]) for o in obj], dev(TCO), dev(K), resolution=(H, W), render_depth=True)
+    rgb, depth = rgb.cpu().numpy(), depth.cpu().numpy()
+    assert rgb.shape == (B, 3, H, W) and rgb.min() >= 0 and rgb.max() <= 1
+    r_o, d_o, zb = oracle.rasterize(meshes.verts.cpu().numpy(), meshes.colors.cpu().numpy(), meshes.faces.cpu().numpy(),
+                                    meshes.n_faces.cpu().numpy(), obj, TCO, K, H, W)
+    assert np.array_equal(depth, d_o)                               # same winning face and depth in every pixel
+    assert np.abs(rgb - r_o).max() < 1e-6
+    assert (rgb[5] == 0).all() and (depth[5] == 0).all()
+    for b in range(5):
+        mask = depth[b] > 0
+        assert 500 < mask.sum() < H * W
+        # the silhouette's bounding box is the bounding box of the projected vertices (within a pixel)
+        P = (TCO[b, :3, :3] @ v[obj[b]].T).T + TCO[b, :3, 3]
+        u = K[b, 0, 0] * P[:, 0] / P[:, 2] + K[b, 0, 2]; vv = K[b, 1, 1] * P[:, 1] / P[:, 2] + K[b, 1, 2]
+        ys, xs = np.where(mask)
+        for got, want in ((xs.min(), max(u.min(), 0)), (xs.max() + 1, min(u.max(), W)), (ys.min(), max(vv.min(), 0)), (ys.max() + 1, min(vv.max(), H))):
+            assert abs(got - want) <= 1.5, (b, got, want)
+        # depth of the visible surface lies between the nearest and farthest vertex
+        assert depth[b][mask].min() >= P[:, 2].min() - 1e-6 and depth[b][mask].max() <= P[:, 2].max() + 1e-6
+    # batch invariance / determinism
+    again = renderer.render([dict(name=labels[o]) for o in obj[:2]], dev(TCO[:2]), dev(K[:2]), resolution=(H, W)).cpu().numpy()
+    assert np.array_equal(again, rgb[:2])
+
+
+def test_refinement_loop_with_on_device_renderer(golden_sd):
+    """coarse 1 + refiner 2 with the HIP rasteriser plugged in as model.renderer: the whole loop stays on the GPU"""
+    import pandas as pd
+    from cosypose_amd import tensor_collection as tc
+    from cosypose_amd.mesh_db import BatchedMeshes
+    from cosypose_amd.pose_models_cfg import create_model_pose, check_update_config
+    from cosypose_amd.pose_predictor import CoarseRefinePosePredictor
+    labels, (v, f, c), meshes, renderer = _render_setup(5)
+    pts = np.stack([vv[np.random.RandomState(0).choice(len(vv), 2500 if len(vv) >= 2500 else len(vv), replace=len(vv) < 2500)] for vv in v])
+    if pts.shape[1] < 2500:
+        pts = np.concatenate([pts, pts[:, np.random.RandomState(1).randint(0, pts.shape[1], 2500 - pts.shape[1])]], 1)
+    mesh_db = BatchedMeshes({l: dict(label=l, n_sym=1) for l in labels}, labels, torch.from_numpy(pts), torch.eye(4).reshape(1, 1, 4, 4).repeat(5, 1, 1, 1)).float().cuda()
+    cfg = check_update_config(argparse.Namespace(backbone_str='efficientnet-b3', n_pose_dims=9))
+    m = create_model_pose(cfg, renderer, mesh_db)
+    m.load_state_dict({k: torch.from_numpy(vv) for k, vv in golden_sd.items()}, strict=False)
+    m.cfg = cfg
+    m = m.cuda().eval()
+    images, K = dev(syn.make_frames(3, 2, 480, 640)), dev(syn.make_K(2, 480, 640))
+    obj, im, boxes = syn.make_detections(5, 7, 2, 5, 480, 640)
+    det = tc.PandasTensorCollection(infos=pd.DataFrame(dict(label=labels[obj], batch_im_id=im, score=1.0)), bboxes=dev(boxes))
+    pred = CoarseRefinePosePredictor(coarse_model=m, refiner_model=m, bsz_objects=4)
+    final, allp = pred.get_predictions(images, K, detections=det, n_coarse_iterations=1, n_refiner_iterations=2)
+    assert len(final) == 7 and torch.isfinite(final.poses).all()
+    # the render of the last iteration shows the object inside the crop (the crop camera is centred on the object)
+    it = allp['refiner/iteration=2']
+    rgb = renderer.render([dict(name=l) for l in it.infos['label']], it.poses_input, it.K_crop, resolution=(240, 320))
+    cover = (rgb.sum(1) > 0).float().mean((1, 2))
+    assert (cover > 0.05).all() and (cover < 0.9).all()
