@@ -154,7 +154,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         b.skip = (b.d.s == 1 && b.d.cin == b.d.cout);  // id_skip, efficientnet.py:94
         b.n_tiles = dw_num_tiles(b.cmid, b.Ho, b.Wo, b.d.k);
         // selected blocks (default 2-5 and 8): expand + depthwise fused, the expanded tensor stays in LDS
-        b.fused = n->fuse && b.d.e != 1 && ((n->fuse_mask >> i) & 1) && fuse_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype);
+        b.fused = n->fuse && b.d.e != 1 && ((n->fuse_mask >> i) & 1) && fuse_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
         b.exp_wp_fused = nullptr;
         if (b.d.e != 1) {
             mk_pw(b.exp, p, b.d.cin, b.cmid, p + (size_t)b.cmid * b.d.cin);
@@ -291,7 +291,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
             f.D = Dbuf; f.partial = w.partial; f.zeros = n->zeros;
             f.B = Bc; f.H = b.H; f.W = b.W; f.Cin = b.d.cin; f.Cmid = b.cmid; f.Ho = b.Ho; f.Wo = b.Wo; f.k = b.d.k; f.s = b.d.s; f.pad_lo = b.pad_lo;
             if ((rc = launch_mbconv_front(f, n->dtype, s))) return rc;
-            fuse_kernel_name(b.d.cin, b.d.k, b.d.s, n->dtype, kn, sizeof(kn));
+            fuse_kernel_name(b.d.cin, b.d.k, b.d.s, n->dtype, b.H, b.W, kn, sizeof(kn));
             if ((rc = mark(kn, i, ((double)Bc * b.H * b.W * b.d.cin + (double)Bc * b.Ho * b.Wo * b.cmid + (double)b.d.cin * b.cmid) * esz_d,
                            2.0 * Bc * b.H * b.W * b.d.cin * b.cmid + 2.0 * Bc * b.Ho * b.Wo * b.cmid * b.d.k * b.d.k))) return rc;
         } else {
@@ -427,10 +427,10 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
         n->chunk = c <= 0 ? max_batch : c;
         const char* fv = getenv("COSY_FUSE");
         n->fuse = fv ? atoi(fv) : 1;
-        // measured per block (256^2, bf16): fused wins for blocks 2-5 and 8; it loses for the k=5 stride-1 blocks 6/7
-        // (halo recompute x1.9) and is not built for Cin > 64 (blocks 9+)
+        // measured per block (256^2, bf16): the tiled kernel wins for blocks 2-5 and 8 and loses for the k=5 stride-1 blocks
+        // 6/7 (halo recompute x1.9); blocks 19-25 (8x8 maps) run the whole-image kernel (mbconv_small_kernel)
         const char* fm = getenv("COSY_FUSE_MASK");
-        n->fuse_mask = fm ? (unsigned)strtoul(fm, nullptr, 0) : 0x13cu;
+        n->fuse_mask = fm ? (unsigned)strtoul(fm, nullptr, 0) : 0x3f8013cu;
         const char* sv = getenv("COSY_STREAMS");
         n->nstreams = (sv ? atoi(sv) : 1) == 2 && max_batch >= 32 ? 2 : 1;   // measured: 2 streams x half batches is ~10 % slower
     }

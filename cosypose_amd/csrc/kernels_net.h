@@ -28,7 +28,7 @@ struct PwArgs {
 };
 int launch_pw_gemm(const PwArgs& a, PwCfg cfg, int dtype, hipStream_t s);
 void pw_kernel_name(const PwArgs& a, PwCfg c, int dtype, char* buf, size_t n);
-void fuse_kernel_name(int Cin, int k, int s, int dtype, char* buf, size_t n);
+void fuse_kernel_name(int Cin, int k, int s, int dtype, int H, int W, char* buf, size_t n);
 
 struct DwArgs {
     const void* in;      // (B,H,W,C)
@@ -55,7 +55,7 @@ struct FuseArgs {
     const void* zeros;
     int B, H, W, Cin, Cmid, Ho, Wo, k, s, pad_lo;
 };
-bool fuse_supported(int Cin, int Cmid, int k, int s, int dtype);
+bool fuse_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W);
 int fuse_num_tiles(int Cin, int Ho, int Wo, int k, int s, int dtype);
 int launch_mbconv_front(const FuseArgs& a, int dtype, hipStream_t s);
 

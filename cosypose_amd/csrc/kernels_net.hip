@@ -580,8 +580,13 @@ void pw_kernel_name(const PwArgs& a, PwCfg c, int dtype, char* buf, size_t n) {
         snprintf(buf, n, "pw_gemm_kernel<%s, %d, %d>", tname(dtype), c.NI, c.WN);
     }
 }
-void fuse_kernel_name(int Cin, int k, int s, int dtype, char* buf, size_t n) {
+void fuse_kernel_name(int Cin, int k, int s, int dtype, int H, int W, char* buf, size_t n) {
     const int esz = dtype == COSY_F32 ? 4 : 2;
+    if (cdiv(Cin, esz == 2 ? 32 : 16) > 2) {   // the whole-image kernel of the small maps
+        const int mbr = cdiv(H * W, 16), mpw = cdiv(mbr, (mbr <= 4 ? 256 : 512) / 64);
+        snprintf(buf, n, "mbconv_small_kernel<%s, %d, %d, %d, %d, %d>", tname(dtype), k, s, s == 1 ? 4 : 2, cdiv(Cin, 32), mpw);
+        return;
+    }
     const int et32 = esz == 4 ? 1 : fuse_et_f32();
     snprintf(buf, n, "mbconv_front_kernel<%s, %s, %d, %d, %d, %d>", tname(dtype), et32 ? "float" : tname(dtype), k, s, s == 1 ? 4 : 2,
              cdiv(Cin, esz == 2 ? 32 : 16));
@@ -591,6 +596,25 @@ int launch_pw_gemm(const PwArgs& a, PwCfg cfg, int dtype, hipStream_t s) {
     if (a.M == 0) return COSY_OK;
     COSY_REQUIRE(a.K % 8 == 0 && a.N % 8 == 0, "pw_gemm: K=%d and N=%d must be multiples of 8", a.K, a.N);
     return COSY_DISPATCH_T(dtype, launch_pw_t<T>(a, cfg, dtype, s));
+}
+
+// Fixed-order (deterministic) reduction of per-thread squeeze sums parked in LDS as red[thread][CPT]: output (g, e) =
+// sum over the threads t = g, g + NG, ... < stride of red[t][e].  Spread over up to 4 threads per output (each sums
+// every 4th contribution, two xor-shuffles combine them) instead of one thread walking all of them: the serial walk
+// (32 dependent LDS reads) sat on the critical path of every chunk while the other waves waited at the next barrier.
+__device__ __forceinline__ void reduce_squeeze_sums(const float* red, int stride, int NG, int CPT, int tid, int nthr, float* out) {
+    const int outputs = NG * CPT;
+    int parts = 4;
+    while (outputs * parts > nthr) parts >>= 1;
+    const int o = tid / parts, part = tid - o * parts;
+    float sacc = 0.f;
+    if (o < outputs) {
+        const int g = o / CPT, e = o - g * CPT;
+        for (int t = g + part * NG; t < stride; t += NG * parts) sacc += red[t * CPT + e];
+    }
+    if (parts == 4) { sacc += __shfl_xor(sacc, 1); sacc += __shfl_xor(sacc, 2); }
+    else if (parts == 2) sacc += __shfl_xor(sacc, 1);
+    if (o < outputs && part == 0) out[o] = sacc;
 }
 
 // ==========================================================================================
@@ -774,12 +798,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwKArgs a) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) red[tid * 8 + c] = sum[c];
     __syncthreads();
-    if (tid < CGB * 8) {
-        const int g = tid >> 3, ch = tid & 7;
-        float s = 0.f;
-        for (int t = g; t < stride; t += CGB) s += red[t * 8 + ch];
-        a.partial[((size_t)b * a.n_tiles + tile_id) * a.C + c0 + g * 8 + ch] = s;
-    }
+    reduce_squeeze_sums(red, stride, CGB, 8, tid, nthr, a.partial + ((size_t)b * a.n_tiles + tile_id) * a.C + c0);
 }
 
 template <typename T>
@@ -818,6 +837,11 @@ int launch_dwconv(const DwArgs& a, int dtype, hipStream_t s) {
 //   3. depthwise from Et exactly as dwconv_kernel (sliding window over rows), BN+SiLU, NHWC store, squeeze sums.
 // Cost: the expansion is recomputed on the halo (x1.2-1.4), on MFMA units that are otherwise idle here.
 // ==========================================================================================
+// Bytes per pixel row of the LDS tile of expanded activations: +16 keeps the expand epilogue's 16-byte writes (16 pixels
+// per instruction, one pitch apart) conflict-free.  Measured alternative: pitches that make the depthwise READS
+// contiguous (192 / 224 B) were slower (b2 562 -> 735 us, b3 343 -> 358 us) although SQ_LDS_BANK_CONFLICT reads 0.56-0.69
+// of busy cycles for these kernels.
+constexpr int et_pitch(int elem_size, int stride) { (void)stride; return 48 * elem_size + 16; }
 struct FusePlan { int TH, TW, THin, TWin, MB, kbn, threads, ntx, nty, et_f32; size_t lds; };
 static int fuse_et_f32() { static const int v = getenv("COSY_FUSE_ET32") ? atoi(getenv("COSY_FUSE_ET32")) : 1; return v; }
 static FusePlan fuse_plan(int Cin, int Ho, int Wo, int k, int s, int esz) {
@@ -833,17 +857,23 @@ static FusePlan fuse_plan(int Cin, int Ho, int Wo, int k, int s, int esz) {
     p.kbn = cdiv(Cin, esz == 2 ? 32 : 16);
     const int cpt = 16 / ees, units = (48 / cpt) * p.TW * (p.TH / R);
     p.threads = ((units < 384 ? units : 384) + 63) / 64 * 64;
-    p.lds = (size_t)p.MB * p.kbn * 1024 + (size_t)p.MB * 16 * (48 * ees + 16) + (size_t)k * k * 48 * 4 + (size_t)p.threads * 8 * 4;
+    p.lds = (size_t)p.MB * p.kbn * 1024 + (size_t)p.MB * 16 * et_pitch(ees, s) + (size_t)k * k * 48 * 4 + (size_t)p.threads * 8 * 4;
     p.ntx = cdiv(Wo, p.TW); p.nty = cdiv(Ho, p.TH);
     return p;
 }
 int fuse_num_tiles(int Cin, int Ho, int Wo, int k, int s, int dtype) {
+    if (cdiv(Cin, dtype == COSY_F32 ? 16 : 32) > 2) return 1;   // the whole-image kernel of the small maps
     FusePlan p = fuse_plan(Cin, Ho, Wo, k, s, dtype == COSY_F32 ? 4 : 2);
     return p.ntx * p.nty;
 }
-bool fuse_supported(int Cin, int Cmid, int k, int s, int dtype) {
+static bool fuse_use_small(int Cin, int Cmid, int H, int W, int Ho, int Wo, int k, int s, int dtype);
+static int conv_out(int in, int k, int s) { return s == 1 ? in : (in - 2) / 2 + 1; }   // static same padding (image_size 300)
+// H, W = the block's input map (0 = unknown: only the tiled kernel is considered)
+bool fuse_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W) {
     const int kbn = cdiv(Cin, dtype == COSY_F32 ? 16 : 32);
-    return Cmid % 48 == 0 && kbn <= 2 && (k == 3 || k == 5) && (s == 1 || s == 2);
+    const bool tiled = Cmid % 48 == 0 && kbn <= 2 && (k == 3 || k == 5) && (s == 1 || s == 2);
+    if (tiled || H <= 0) return tiled;
+    return fuse_use_small(Cin, Cmid, H, W, conv_out(H, k, s), conv_out(W, k, s), k, s, dtype);
 }
 
 struct FuseKArgs {
@@ -859,7 +889,7 @@ __global__ __launch_bounds__(384) void mbconv_front_kernel(FuseKArgs a) {
     using raw_t = typename DT<T>::raw_t;
     constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
     constexpr int NI = 3, CC = 48;
-    constexpr int PITCH = CC * (int)sizeof(ET) + 16;  // bytes per Et pixel row (+16: conflict-free 16-byte writes)
+    constexpr int PITCH = et_pitch((int)sizeof(ET), S);  // bytes per Et pixel row: conflict-free depthwise reads
     constexpr int CPT = 16 / (int)sizeof(ET);         // channels per depthwise thread (one 16-byte Et read)
     constexpr int NG = CC / CPT;                      // channel groups per chunk
     constexpr int NROW = (R - 1) * S + KS;
@@ -1008,12 +1038,7 @@ __global__ __launch_bounds__(384) void mbconv_front_kernel(FuseKArgs a) {
 #pragma unroll
         for (int c = 0; c < CPT; ++c) red[tid * CPT + c] = sum[c];
         __syncthreads();
-        if (tid < CC) {   // fixed-order (deterministic) reduction over the threads that share a channel group
-            const int g = tid / CPT, e = tid % CPT;
-            float s = 0.f;
-            for (int t = g; t < stride; t += NG) s += red[t * CPT + e];
-            a.partial[((size_t)b * a.n_tiles + tile_id) * a.Cmid + ch * CC + tid] = s;
-        }
+        reduce_squeeze_sums(red, stride, NG, CPT, tid, nthr, a.partial + ((size_t)b * a.n_tiles + tile_id) * a.Cmid + ch * CC);
         // next chunk: its Et writes happen after this barrier's readers are done (all Et reads precede the barrier above);
         // `red` is rewritten only after the next chunk's first barrier.
     }
@@ -1044,9 +1069,269 @@ static int launch_fuse_t(const FuseArgs& a, hipStream_t s) {
     if (p.kbn == 1) return p.et_f32 ? launch_fuse_k<T, float, 1>(a, p, k, s) : launch_fuse_k<T, T, 1>(a, p, k, s);
     return p.et_f32 ? launch_fuse_k<T, float, 2>(a, p, k, s) : launch_fuse_k<T, T, 2>(a, p, k, s);
 }
+
+// ------------------------------------------------------------------------------------------
+// Whole-image variant for the SMALL maps of the late blocks (H*W <= 320 pixels, Cin up to 384): the same fusion
+// (expand 1x1 -> BN -> SiLU -> depthwise -> BN -> SiLU -> squeeze sums, the 6x expanded tensor never leaves the CU),
+// organised differently because here the map is one tile and the input has many channels:
+//   * a workgroup owns (sample, a run of 48-channel chunks); there is no halo to recompute;
+//   * the block INPUT lives in REGISTERS for the whole kernel: every wave keeps the MFMA B fragments of its MPW
+//     16-pixel blocks for all KBN k-blocks (KBN*4 VGPRs each), loaded once from global;
+//   * the chunk's expand weights (3*KBN fragment blocks) are DMA'd into one LDS buffer while the previous chunk's
+//     depthwise phase runs (they are dead during that phase: a single buffer suffices);
+//   * Et holds the zero-padded expanded image in fp32; only real pixels are ever written, so the halo is zeroed once;
+//   * squeeze sums are complete per (sample, chunk): partial has n_tiles = 1.
+// ------------------------------------------------------------------------------------------
+struct FuseSKArgs {
+    const void* X; const void* Wp; const float* s0; const float* b0; const float* dww; const float* s1; const float* b1;
+    void* D; float* partial; const void* zeros;
+    int H, W, NP, Cin, Cmid, Ho, Wo, lo, THin, TWin, nkb_total, MBr, ncg, cpw, dbg;
+    unsigned rcp_w;   // ceil(2^16 / W): p / W == (p * rcp_w) >> 16 for p < MBr*16 (checked on the host)
+};
+
+template <typename T, int KS, int S, int R, int KBN, int MPW>
+__global__ __launch_bounds__(512) void mbconv_small_kernel(FuseSKArgs a) {
+    using raw_t = typename DT<T>::raw_t;
+    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
+    constexpr int NI = 3, CC = 48, PITCH = et_pitch(4, S), CPT = 4, NG = CC / CPT;
+    constexpr int NROW = (R - 1) * S + KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int TWin = a.TWin, npos = a.THin * a.TWin;
+    // per-chunk parameters [s0 48][b0 48][s1 48][b1 48][taps KS*KS x 48] fp32, double buffered: they are prefetched by DMA
+    // one chunk ahead (fetching them with ordinary loads at the top of a chunk exposes ~2 us of latency per chunk)
+    constexpr int PU = 4 * (CC / 4) + KS * KS * (CC / 4);      // 16-byte units per parameter block
+    constexpr int PJ = (PU + 63) / 64, PBYTES = PJ * 1024;
+    char* Et = smem;
+    char* Wl = Et + (size_t)npos * PITCH;
+    char* Pl = Wl + NI * KBN * 1024;
+    float* red = (float*)(Pl + 2 * PBYTES);
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthr >> 6;
+    const int b = blockIdx.x / a.ncg, cg = blockIdx.x - b * a.ncg;
+    const int nchunks = a.Cmid / CC;
+    const int ch0 = cg * a.cpw, ch1 = min(nchunks, ch0 + a.cpw);
+    const int prow = lane & 15, kg = lane >> 4;
+
+    auto issue_w = [&](int ch) {
+        for (int blk = wave; blk < NI * KBN; blk += nwaves) {
+            const int ni = blk / KBN, kb = blk - ni * KBN;
+            const T* src = (const T*)a.Wp + ((size_t)(ch * NI + ni) * a.nkb_total + kb) * 64 * EPL + lane * EPL;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(Wl + (size_t)blk * 1024), 16, 0, 0);
+        }
+        // parameters of the chunk: PJ more DMA instructions, spread over the waves
+        for (int j = wave; j < PJ; j += nwaves) {
+            const int u = j * 64 + lane;
+            const float* src = (const float*)a.zeros;
+            if (u < PU) {
+                const int arr = u / (CC / 4), q = u - arr * (CC / 4);
+                const float* base = arr == 0 ? a.s0 : arr == 1 ? a.b0 : arr == 2 ? a.s1 : arr == 3 ? a.b1 : a.dww + (size_t)(arr - 4) * a.Cmid;
+                src = base + ch * CC + q * 4;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(Pl + (size_t)(ch & 1) * PBYTES + (size_t)j * 1024), 16, 0, 0);
+        }
+    };
+    issue_w(ch0);
+    // the block input of this sample -> registers (fragment layout: lane = (pixel row of the 16-block, k-group))
+    raw_t xf[MPW][KBN];
+    {
+        const T* __restrict__ X = (const T*)a.X + (size_t)b * a.NP * a.Cin;
+#pragma unroll
+        for (int mi = 0; mi < MPW; ++mi) {
+            const int p = (wave + mi * nwaves) * 16 + prow;
+#pragma unroll
+            for (int kb = 0; kb < KBN; ++kb) {
+                const int k = kb * KB + kg * EPL;
+                const bool ok = p < a.NP && k < a.Cin;
+                xf[mi][kb] = *(const raw_t*)(ok ? (const void*)(X + (size_t)p * a.Cin + k) : a.zeros);
+            }
+        }
+    }
+    // zero the padded expanded image once (the halo is never written again)
+    for (int i = tid; i < npos * (PITCH / 16); i += nthr) *(f32x4*)(Et + (size_t)i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nyq = (a.Ho + R - 1) / R;
+    const int units = NG * a.Wo * nyq;           // <= threads: every thread owns at most ONE (4-channel, column, R rows) unit
+    const int stride = (nthr / NG) * NG;
+    const int cq = tid % NG;
+    const bool has_unit = tid < units && !(a.dbg & 1);
+    const int uq = tid / NG, ux = uq % a.Wo, uyq = uq / a.Wo;
+    // Global stores count in vmcnt on this ISA and retire in order with the loads: a wait for the NEXT chunk's DMA issued
+    // after this chunk's output stores would also wait for the stores' acknowledgements (~2-3 us per chunk, measured).
+    // So per chunk: [barrier] expand -> [barrier] issue DMA(ch+1) -> depthwise COMPUTE -> wait DMA -> output stores.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // W(ch0) / params(ch0) / the input fragments have landed
+    __syncthreads();
+    for (int ch = ch0; ch < ch1; ++ch) {
+        const float* P = (const float*)(Pl + (size_t)(ch & 1) * PBYTES);
+        const float* wl = P + 4 * CC;
+        // ---- expansion on the matrix cores -> Et (real pixels only)
+        {
+            const int n0 = kg * 4 * NI;
+            float sc[NI * 4], bi[NI * 4];
+#pragma unroll
+            for (int q = 0; q < NI; ++q) { load4(P + n0 + q * 4, sc + q * 4); load4(P + CC + n0 + q * 4, bi + q * 4); }
+#pragma unroll
+            for (int mi = 0; mi < MPW; ++mi) {
+                const int mb = wave + mi * nwaves;
+                if (mb < a.MBr && !(a.dbg & 2)) {
+                    f32x4 acc[NI];
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) acc[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < KBN; ++kb)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            const raw_t wf = *(const raw_t*)(Wl + (size_t)(ni * KBN + kb) * 1024 + lane * 16);
+                            mma(acc[ni], wf, xf[mi][kb]);
+                        }
+                    const int p = mb * 16 + prow;
+                    if (p < a.NP) {
+                        const int y = (int)(((unsigned)p * a.rcp_w) >> 16), x = p - y * a.W;
+                        float v12[NI * 4];
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float v = acc[ni][r] * sc[ni * 4 + r] + bi[ni * 4 + r];
+                                v12[ni * 4 + r] = v * sigmoid_t<T>(v);
+                            }
+                        float* dst = (float*)(Et + (size_t)((y + a.lo) * TWin + x + a.lo) * PITCH) + kg * 4 * NI;
+                        store4(dst, v12); store4(dst + 4, v12 + 4); store4(dst + 8, v12 + 8);
+                    }
+                }
+            }
+        }
+        __syncthreads();                       // Et complete; the weight buffer is free
+        if (ch + 1 < ch1 && !(a.dbg & 4)) issue_w(ch + 1);     // lands while the depthwise phase computes
+        // ---- depthwise from Et: compute first, store after the DMA wait
+        float sum[CPT], yv[R][CPT];
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) sum[c] = 0.f;
+        if (has_unit) {
+            float sc[CPT], bi[CPT];
+            load4(P + 2 * CC + cq * CPT, sc); load4(P + 3 * CC + cq * CPT, bi);
+            float acc[R][CPT];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) acc[r][c] = 0.f;
+#pragma unroll 1
+            for (int kx = 0; kx < KS; ++kx) {
+                float wc[KS][CPT];
+#pragma unroll
+                for (int ky = 0; ky < KS; ++ky) load4(wl + (ky * KS + kx) * CC + cq * CPT, wc[ky]);
+                const char* col = Et + ((size_t)(uyq * R * S) * TWin + ux * S + kx) * PITCH + cq * 16;
+#pragma unroll
+                for (int rr = 0; rr < NROW; ++rr) {
+                    float v[CPT];
+                    load4((const float*)(col + (size_t)rr * TWin * PITCH), v);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int ky = rr - r * S;
+                        if (ky >= 0 && ky < KS) {
+#pragma unroll
+                            for (int c = 0; c < CPT; ++c) acc[r][c] += wc[ky][c] * v[c];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) {
+                    float v = acc[r][c] * sc[c] + bi[c];
+                    v = v * sigmoid_t<T>(v);
+                    yv[r][c] = v;
+                    if (uyq * R + r < a.Ho) sum[c] += v;
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) red[tid * CPT + c] = sum[c];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // DMA(ch+1) landed (issued before any store of this chunk)
+        if (has_unit) {
+            T* __restrict__ out = (T*)a.D + (size_t)b * a.Ho * a.Wo * a.Cmid + ch * CC + cq * CPT;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int oy = uyq * R + r;
+                if (oy < a.Ho) store4(out + ((size_t)oy * a.Wo + ux) * a.Cmid, yv[r]);
+            }
+        }
+        __syncthreads();   // red complete; everybody's DMA(ch+1) landed; all Et / parameter reads of this chunk are done
+        reduce_squeeze_sums(red, stride, NG, CPT, tid, nthr, a.partial + (size_t)b * a.Cmid + ch * CC);
+    }
+}
+
+struct FuseSmallPlan { int kbn, MBr, mpw, threads, THin, TWin, ncg, cpw; size_t lds; bool ok; };
+static FuseSmallPlan fuse_small_plan(int Cin, int Cmid, int H, int W, int Ho, int Wo, int k, int s, int esz) {
+    FuseSmallPlan p{};
+    const int R = s == 1 ? 4 : 2;
+    p.kbn = cdiv(Cin, 32);
+    p.MBr = cdiv(H * W, 16);
+    p.threads = p.MBr <= 4 ? 256 : 512;
+    p.mpw = cdiv(p.MBr, p.threads / 64);
+    const int nyq = cdiv(Ho, R);
+    p.THin = (nyq * R - 1) * s + k;
+    if (p.THin < H + k - 1) p.THin = H + k - 1;
+    p.TWin = (Wo - 1) * s + k;
+    if (p.TWin < W + k - 1) p.TWin = W + k - 1;
+    const int pj = (4 * 12 + k * k * 12 + 63) / 64;     // parameter block, see the kernel
+    p.lds = (size_t)p.THin * p.TWin * et_pitch(4, s) + (size_t)3 * p.kbn * 1024 + (size_t)2 * pj * 1024 + (size_t)p.threads * 4 * 4;
+    const int nchunks = Cmid / 48;
+    static const int cpw_target = getenv("COSY_SMALL_CPW") ? atoi(getenv("COSY_SMALL_CPW")) : 15;
+    p.cpw = nchunks <= cpw_target ? nchunks : cdiv(nchunks, cdiv(nchunks, cpw_target));   // ~15 chunks per workgroup (measured 3..29)
+    p.ncg = cdiv(nchunks, p.cpw);
+    // built for the 8x8 (7x10) maps of blocks 19-25: stride 1, one 16-pixel block per wave, 232 or 384 input channels.
+    // (On the 16x16 maps the input registers + a 400-pixel fp32 tile leave one workgroup per CU: not built.)
+    p.ok = esz == 2 && Cmid % 48 == 0 && (p.kbn == 8 || p.kbn == 12) && p.mpw == 1 && p.lds <= 80 * 1024 && (k == 3 || k == 5) && s == 1 &&
+           12 * Wo * cdiv(Ho, 4) <= p.threads;
+    return p;
+}
+static int fuse_small_enabled() { static const int v = getenv("COSY_FUSE_SMALL") ? atoi(getenv("COSY_FUSE_SMALL")) : 1; return v; }
+
+template <typename T, int KS, int KBN>
+static int launch_fuse_small_m(const FuseSmallPlan& p, const FuseSKArgs& k, int B, hipStream_t s) {
+    const dim3 grid((unsigned)(B * k.ncg)), block(p.threads);
+    static bool attr_set = false;
+    if (!attr_set) {
+        COSY_CHECK_HIP(hipFuncSetAttribute((const void*)mbconv_small_kernel<T, KS, 1, 4, KBN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((mbconv_small_kernel<T, KS, 1, 4, KBN, 1>), grid, block, p.lds, s, k);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+template <typename T>
+static int launch_fuse_small_t(const FuseArgs& a, hipStream_t s) {
+    const FuseSmallPlan p = fuse_small_plan(a.Cin, a.Cmid, a.H, a.W, a.Ho, a.Wo, a.k, a.s, sizeof(T));
+    FuseSKArgs k;
+    k.X = a.X; k.Wp = a.Wp; k.s0 = a.s0; k.b0 = a.b0; k.dww = a.dww; k.s1 = a.s1; k.b1 = a.b1; k.D = a.D; k.partial = a.partial;
+    k.zeros = a.zeros; k.H = a.H; k.W = a.W; k.NP = a.H * a.W; k.Cin = a.Cin; k.Cmid = a.Cmid; k.Ho = a.Ho; k.Wo = a.Wo; k.lo = a.pad_lo;
+    k.THin = p.THin; k.TWin = p.TWin; k.nkb_total = pw_nkb_total(a.Cin, COSY_BF16); k.MBr = p.MBr; k.ncg = p.ncg; k.cpw = p.cpw;
+    k.rcp_w = (65536u + a.W - 1) / a.W;
+    static const int dbg = getenv("COSY_SMALL_DBG") ? atoi(getenv("COSY_SMALL_DBG")) : 0;   // timing experiments only
+    k.dbg = dbg;
+    for (int q = 0; q < p.MBr * 16; ++q)
+        if ((int)(((unsigned)q * k.rcp_w) >> 16) != q / a.W) { set_error("mbconv_small: reciprocal division inexact"); return COSY_EINVAL; }
+    if constexpr (sizeof(T) == 2) {
+        if (a.k == 3 && p.kbn == 8) return launch_fuse_small_m<T, 3, 8>(p, k, a.B, s);
+        if (a.k == 3 && p.kbn == 12) return launch_fuse_small_m<T, 3, 12>(p, k, a.B, s);
+        if (a.k == 5 && p.kbn == 8) return launch_fuse_small_m<T, 5, 8>(p, k, a.B, s);
+        if (a.k == 5 && p.kbn == 12) return launch_fuse_small_m<T, 5, 12>(p, k, a.B, s);
+    }
+    set_error("mbconv_small: unsupported k=%d s=%d k-blocks=%d", a.k, a.s, p.kbn);
+    return COSY_EINVAL;
+}
+static bool fuse_use_small(int Cin, int Cmid, int H, int W, int Ho, int Wo, int k, int s, int dtype) {
+    if (!fuse_small_enabled() || dtype == COSY_F32 || cdiv(Cin, 32) <= 2) return false;
+    return fuse_small_plan(Cin, Cmid, H, W, Ho, Wo, k, s, 2).ok;
+}
+
 int launch_mbconv_front(const FuseArgs& a, int dtype, hipStream_t s) {
     if (a.B == 0) return COSY_OK;
-    COSY_REQUIRE(fuse_supported(a.Cin, a.Cmid, a.k, a.s, dtype), "mbconv_front: unsupported shape Cin=%d Cmid=%d", a.Cin, a.Cmid);
+    if (fuse_use_small(a.Cin, a.Cmid, a.H, a.W, a.Ho, a.Wo, a.k, a.s, dtype)) return COSY_DISPATCH_T(dtype, launch_fuse_small_t<T>(a, s));
+    COSY_REQUIRE(fuse_supported(a.Cin, a.Cmid, a.k, a.s, dtype, 0, 0), "mbconv_front: unsupported shape Cin=%d Cmid=%d", a.Cin, a.Cmid);
     return COSY_DISPATCH_T(dtype, launch_fuse_t<T>(a, s));
 }
 

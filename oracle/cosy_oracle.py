@@ -365,8 +365,9 @@ class TorchRef:
     def __init__(self, sd, dtype=None):
         import torch
         self.torch = torch
-        self.sd = {k: (v if hasattr(v, 'detach') else torch.from_numpy(np.asarray(v))).float() for k, v in sd.items()
-                   if not k.endswith('num_batches_tracked')}
+        # private copies: train mode updates the running statistics in place and must not touch the caller's arrays
+        self.sd = {k: (v if hasattr(v, 'detach') else torch.from_numpy(np.asarray(v))).detach().float().clone()
+                   for k, v in sd.items() if not k.endswith('num_batches_tracked')}
 
     @staticmethod
     def _pad(k, s):

@@ -586,6 +586,7 @@ def test_config2_refiner_only_fp16_tless_shape(model, oracle, golden_sd, mesh_ta
     init = tc.PandasTensorCollection(infos=pd.DataFrame(dict(label=labels21[obj], batch_im_id=im)), poses=dev(TCO))
     model.renderer = FakeRenderer(500)
     model.compute_dtype = 'fp16'
+    model.render_size = hw            # the module-scoped model may have been left at another crop size by earlier tests
     try:
         pred = CoarseRefinePosePredictor(coarse_model=None, refiner_model=model, bsz_objects=5)      # ragged chunks 5+5+2
         final, allp = pred.get_predictions(dev(images), dev(K), data_TCO_init=init, n_coarse_iterations=0, n_refiner_iterations=4)
@@ -603,7 +604,7 @@ def test_config2_refiner_only_fp16_tless_shape(model, oracle, golden_sd, mesh_ta
                                             render_size=hw, backbone=ref.net_forward)
         want[s:e] = out['iteration=4']['TCO_output']
         call += 4
-    assert rel_err(final.poses.cpu().numpy(), want) < 3e-3
+    assert rel_err(final.poses.cpu().numpy(), want) < 5e-4       # measured 1.9e-5 (fp16 storage, fp32 accumulation)
 
 
 def test_config3_mixed_frame_sizes_skewed_shards(model, oracle, golden_sd, mesh_table):
@@ -614,6 +615,7 @@ def test_config3_mixed_frame_sizes_skewed_shards(model, oracle, golden_sd, mesh_
     from cosypose_amd.pose_predictor import CoarseRefinePosePredictor
     from cosypose_amd.distributed import balanced_assignment
     labels21 = model.mesh_db.labels
+    model.render_size, model.compute_dtype = (240, 320), 'fp32'
     pred = CoarseRefinePosePredictor(coarse_model=model, refiner_model=model, bsz_objects=4)
     counts = []
     for gi, ((h, w), D) in enumerate((((480, 640), 7), ((540, 720), 3), ((960, 1280), 2))):
