@@ -879,7 +879,7 @@ bool fuse_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W) {
 struct FuseKArgs {
     const void* X; const void* Wp; const float* s0; const float* b0; const float* dww; const float* s1; const float* b1;
     void* D; float* partial; const void* zeros;
-    int H, W, Cin, Cmid, Ho, Wo, lo, TH, TW, THin, TWin, MB, ntx, n_tiles, nkb_total;
+    int H, W, Cin, Cmid, Ho, Wo, lo, TH, TW, THin, TWin, MB, ntx, n_tiles, nkb_total, dbg;
     unsigned rcp_tw;   // ceil(2^16 / TWin): p / TWin == (p * rcp_tw) >> 16 for the tile's pixel range (checked on the host)
 };
 
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(384) void mbconv_front_kernel(FuseKArgs a) {
             float sc[NI * 4], bi[NI * 4];
 #pragma unroll
             for (int q = 0; q < NI; ++q) { load4(a.s0 + n0 + q * 4, sc + q * 4); load4(a.b0 + n0 + q * 4, bi + q * 4); }
-            for (int mb = wave; mb < MB; mb += nwaves) {
+            for (int mb = wave; mb < ((a.dbg & 2) ? 0 : MB); mb += nwaves) {
                 f32x4 acc[NI];
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -978,7 +978,7 @@ __global__ __launch_bounds__(384) void mbconv_front_kernel(FuseKArgs a) {
         float sum[CPT];
 #pragma unroll
         for (int c = 0; c < CPT; ++c) sum[c] = 0.f;
-        if (tid < stride) {
+        if (tid < stride && !(a.dbg & 1)) {
             const int c0 = ch * CC + cq * CPT;
             float sc[CPT], bi[CPT];
 #pragma unroll
@@ -1064,6 +1064,8 @@ static int launch_fuse_t(const FuseArgs& a, hipStream_t s) {
     k.TH = p.TH; k.TW = p.TW; k.THin = p.THin; k.TWin = p.TWin; k.MB = p.MB; k.ntx = p.ntx; k.n_tiles = p.ntx * p.nty;
     k.nkb_total = pw_nkb_total(a.Cin, sizeof(T) == 4 ? COSY_F32 : COSY_BF16);   // k-block geometry depends on the element size only
     k.rcp_tw = (65536u + p.TWin - 1) / p.TWin;
+    static const int dbg = getenv("COSY_FUSE_DBG") ? atoi(getenv("COSY_FUSE_DBG")) : 0;   // phase knock-out, timing experiments only
+    k.dbg = dbg;
     for (int q = 0; q < p.MB * 16; ++q)
         if ((int)(((unsigned)q * k.rcp_tw) >> 16) != q / p.TWin) { set_error("mbconv_front: reciprocal division inexact"); return COSY_EINVAL; }
     if (p.kbn == 1) return p.et_f32 ? launch_fuse_k<T, float, 1>(a, p, k, s) : launch_fuse_k<T, T, 1>(a, p, k, s);
