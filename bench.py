@@ -111,14 +111,14 @@ def main():
     from cosypose_amd import tensor_collection as tc
     from cosypose_amd.mesh_db import BatchedMeshes
     from cosypose_amd.pose_predictor import CoarseRefinePosePredictor
-    from cosypose_amd.distributed import init_distributed_mode, all_gather_rows
+    from cosypose_amd.distributed import init_distributed_mode, all_gather_rows, local_device_index
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
     rank, world = init_distributed_mode('nccl')
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
-    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    torch.cuda.set_device(local_device_index())
     H, W = (int(v) for v in args.crop.split('x'))
     h, w = (512, 512) if H == W else (480, 640)   # square frames for square crops
     D, n_frames, n_obj = args.detections, 16, 21

@@ -40,14 +40,14 @@ def main():
     from bench import SyntheticRenderer, build_model
     from cosypose_amd import synthetic as syn, train_engine, pose_forward_loss as pfl
     from cosypose_amd.mesh_db import BatchedMeshes
-    from cosypose_amd.distributed import init_distributed_mode
+    from cosypose_amd.distributed import init_distributed_mode, local_device_index
 
     if not torch.cuda.is_available():
         raise SystemExit('bench_train.py needs an MI355X (no CPU fallback)')
     rank, world = init_distributed_mode('nccl')
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    torch.cuda.set_device(local_device_index())
     B, n_obj, h, w, H, W = args.batch, 21, 480, 640, 240, 320
     labels = np.array([f'obj_{i:06d}' for i in range(1, n_obj + 1)])
     pts = syn.make_mesh_points(7, n_obj, 2600)

@@ -25,16 +25,25 @@ def get_world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def local_device_index():
+    """The GPU this rank binds: LOCAL_RANK, wrapped over the visible devices (so that a rehearsal with more ranks than
+    GPUs -- COSY_DIST_BACKEND=gloo, all ranks on one device -- exercises the same code path as the real launch)."""
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    return int(os.environ.get('LOCAL_RANK', '0')) % n if n else 0
+
+
 def init_distributed_mode(backend=None):
     """torchrun-style env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).  One visible GPU per rank:
-    the rank binds LOCAL_RANK's device (reference: cosypose/utils/distributed.py:55-69 uses SLURM vars + file store)."""
+    the rank binds LOCAL_RANK's device (reference: cosypose/utils/distributed.py:55-69 uses SLURM vars + file store).
+    COSY_DIST_BACKEND overrides the backend (RCCL refuses two ranks on one GPU; gloo does not)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world <= 1 or dist.is_initialized():
         return get_rank(), get_world_size()
+    backend = os.environ.get('COSY_DIST_BACKEND', backend)
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-    if backend == 'nccl':
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_device_index())
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     dist.init_process_group(backend=backend, init_method='env://')
     return get_rank(), get_world_size()
