@@ -114,8 +114,8 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         if (fill) { hipError_t e = hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) *herr = e; }
         return d;
     };
-    auto mk_pw = [&](PwLayer& L, const float* w, int K, int N, const float* bn) {
-        L.K = K; L.N = N; L.cfg = pw_choose_cfg(N);
+    auto mk_pw = [&](PwLayer& L, const float* w, int K, int N, const float* bn, int HW, bool gated) {
+        L.K = K; L.N = N; L.cfg = n->esz == 2 ? pw_choose_cfg_late(K, N, HW, gated) : pw_choose_cfg(N);
         const size_t ne = pw_packed_elems(K, N, L.cfg, n->dtype);
         L.Wp = bump.take(ne * n->esz);
         const int npad = cdiv(N, pw_bn(L.cfg)) * pw_bn(L.cfg);
@@ -157,7 +157,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         b.fused = n->fuse && b.d.e != 1 && ((n->fuse_mask >> i) & 1) && fuse_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
         b.exp_wp_fused = nullptr;
         if (b.d.e != 1) {
-            mk_pw(b.exp, p, b.d.cin, b.cmid, p + (size_t)b.cmid * b.d.cin);
+            mk_pw(b.exp, p, b.d.cin, b.cmid, p + (size_t)b.cmid * b.d.cin, b.H * b.W, false);
             if (b.fused) {
                 const PwCfg c48{3, 1};
                 const size_t ne = pw_packed_elems(b.d.cin, b.cmid, c48, n->dtype);
@@ -197,12 +197,12 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
             p += b.cmid;
             b.se_wr = up_f32(wr); b.se_br = up_f32(br); b.se_we = up_f32(we); b.se_be = up_f32(be);
         }
-        mk_pw(b.proj, p, b.cmid, b.d.cout, p + (size_t)b.d.cout * b.cmid);
+        mk_pw(b.proj, p, b.cmid, b.d.cout, p + (size_t)b.d.cout * b.cmid, b.Ho * b.Wo, true);
         p += (size_t)b.d.cout * b.cmid + 4 * b.d.cout;
         h = b.Ho; w_ = b.Wo;
     }
     n->Hf = h; n->Wf = w_;
-    mk_pw(n->head, p, HEAD_IN, HEAD_C, p + (size_t)HEAD_C * HEAD_IN);
+    mk_pw(n->head, p, HEAD_IN, HEAD_C, p + (size_t)HEAD_C * HEAD_IN, n->Hf * n->Wf, false);
     p += (size_t)HEAD_C * HEAD_IN + 4 * HEAD_C;
     {
         std::vector<float> fw(N_POSE * HEAD_C, 0.f), fb(N_POSE, 0.f);

@@ -9,6 +9,7 @@ struct PwCfg { int NI, WN; };
 static inline int pw_bn(PwCfg c) { return 16 * c.NI * c.WN; }
 static inline int pw_bm(PwCfg c) { return 64 * (4 / c.WN); }
 PwCfg pw_choose_cfg(int N);
+PwCfg pw_choose_cfg_late(int K, int N, int HW, bool gated);
 int pw_kb(int dtype);                     // k elements per fragment block: 32 (bf16) / 16 (f32)
 size_t pw_packed_elems(int K, int N, PwCfg c, int dtype);
 // host-side packing of a (N,K) fp32 weight into the kernel's fragment-block order (dst has elem size of dtype)

@@ -104,6 +104,19 @@ PwCfg pw_choose_cfg(int N) {
     }
     return best;
 }
+// Tile choice for the late layers (2-byte types).  Phase knock-out timing (COSY_PW_DBG) showed these GEMMs bound by the
+// L2 -> LDS DMA stream, not by MFMA or HBM: with everything but the DMA ring and its barriers removed a late GEMM still
+// takes 2/3 of its time.  Per launch the ring moves NT * M*K (activation rows, once per n-tile) + MT * Npad*K (weights,
+// once per m-tile) elements, so a tile that covers N in ONE pass saves a whole pass over the activations -- as long as it
+// keeps two workgroups per CU.  Measured (256 crops): N = 136 with BN = 160 (NI5,WN2) instead of 2 x 96: 72 -> 55 us
+// (b14-17 project), 51 -> 41 us (b13).  Wider tiles lose: BN = 256 (NI8,WN2; 84 KB of LDS, one workgroup per CU) 58 -> 86
+// us, 256 x 128 (NI8,WN1) 66 -> 107 us, 2 x 192 for N = 384 61 -> 70 us.
+PwCfg pw_choose_cfg_late(int K, int N, int HW, bool gated) {
+    (void)gated;
+    static const int wide = getenv("COSY_PW_WIDE") ? atoi(getenv("COSY_PW_WIDE")) : 1;
+    if (wide && K >= 96 && HW >= 64 && N > 128 && N <= 160) return PwCfg{5, 2};
+    return pw_choose_cfg(N);
+}
 int pw_kb(int dtype) { return dtype == COSY_F32 ? 16 : 32; }
 static inline uint16_t f32_to_f16_host(float f) { _Float16 h = (_Float16)(f > 65504.f ? 65504.f : (f < -65504.f ? -65504.f : f)); uint16_t u; memcpy(&u, &h, 2); return u; }
 static int pw_nkb_total(int K, int dtype) { int n = cdiv(K, pw_kb(dtype)); return (n + 1) & ~1; }
@@ -143,6 +156,7 @@ struct PwKArgs {
     int M, K, N, HW, silu, MT, NT, nkb_total, nkb_valid;
     const void* zeros;
     int nsamp, rowgate;   // DMA kernel gate: samples under one m-tile; 1 = gate the activation fragments per row
+    int dbg;              // phase knock-out for timing experiments (COSY_PW_DBG): 1 no epilogue math, 2 no stores, 4 no MFMA, 8 no gate
 };
 
 template <typename T, int NI, int WN>
@@ -394,7 +408,8 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwKArgs a) {
         for (int ni = 0; ni < NI; ++ni) fw[ni] = *(const raw_t*)(st + (NA + wn * NI + ni) * 1024 + lane * 16);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) fa[mi] = *(const raw_t*)(st + (wm * MI + mi) * 1024 + lane * 16);
-        if (GATE && a.rowgate) {
+        if (GATE && (a.dbg & 8)) {
+        } else if (GATE && a.rowgate) {
             // maps whose pixel count is not a multiple of 64 (240x320 input): a wave's rows straddle samples, so the
             // gate multiplies the ACTIVATION fragments, each lane with the gate row of its own pixel's sample
 #pragma unroll
@@ -438,10 +453,12 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwKArgs a) {
                 from_f32(fw[ni], f);
             }
         }
+        if (!(a.dbg & 4)) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], fw[ni], fa[mi]);
+                for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], fw[ni], fa[mi]);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -465,10 +482,11 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwKArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = acc[mi][ni][r] * sc[ni][r] + bi[ni][r];
-                if (a.silu) v = v * sigmoid_t<T>(v);
+                if (a.silu && !(a.dbg & 1)) v = v * sigmoid_t<T>(v);
                 y[ni * 4 + r] = v;
             }
         const size_t o = (size_t)m * N + nl;
+        if (a.dbg & 2) { if (y[0] == 12345.678f) out[o] = (T)y[1]; continue; }
         if (res) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
@@ -496,6 +514,8 @@ static int launch_pw_dma_mi(PwKArgs k, hipStream_t s) {
     constexpr int WM = 4 / WN, NB = MI * WM + NI * WN;
     k.MT = cdiv(k.M, 16 * MI * WM);
     const int grid = cdiv(k.MT, 8) * 8 * k.NT;
+    static const int dbg = getenv("COSY_PW_DBG") ? atoi(getenv("COSY_PW_DBG")) : 0;
+    k.dbg = dbg;
     k.rowgate = GATE && (k.HW % 64 != 0);
     k.nsamp = k.rowgate ? pw_gate_nsamp(16 * MI * WM, k.HW) : 2;
     const size_t lds = (size_t)NS * NB * 1024 + 1024 + (GATE ? (size_t)k.nsamp * k.nkb_total * DT<T>::KB * 4 : 0);
@@ -538,6 +558,9 @@ static int launch_pw_dma(const PwKArgs& k, PwCfg c, int grid, hipStream_t s) {
     if (c.NI == 3 && c.WN == 2) return launch_pw_dma_cfg<T, 3, 2, GATE>(k, grid, s);
     if (c.NI == 3 && c.WN == 1) return launch_pw_dma_cfg<T, 3, 1, GATE>(k, grid, s);
     if (c.NI == 2 && c.WN == 1) return launch_pw_dma_cfg<T, 2, 1, GATE>(k, grid, s);
+    if constexpr (sizeof(T) == 2) {   // wide tiles of the late layers (pw_choose_cfg_late)
+        if (c.NI == 5 && c.WN == 2) return launch_pw_dma_cfg<T, 5, 2, GATE>(k, grid, s);
+    }
     set_error("pw_gemm_dma: unsupported tile config NI=%d WN=%d", c.NI, c.WN);
     return COSY_EINVAL;
 }
@@ -550,7 +573,7 @@ static int launch_pw_t(const PwArgs& a, PwCfg c, int dtype, hipStream_t s) {
     k.MT = cdiv(a.M, pw_bm(c)); k.NT = cdiv(a.N, pw_bn(c));
     k.nkb_total = pw_nkb_total(a.K, dtype); k.nkb_valid = cdiv(a.K, pw_kb(dtype));
     const int grid = cdiv(k.MT, 8) * 8 * k.NT;
-    k.zeros = a.zeros;
+    k.zeros = a.zeros; k.dbg = 0; k.nsamp = 2; k.rowgate = 0;
     if (pw_use_dma(a)) return a.gate ? launch_pw_dma<T, true>(k, c, grid, s) : launch_pw_dma<T, false>(k, c, grid, s);
     if (c.NI == 4 && c.WN == 2) hipLaunchKernelGGL((pw_gemm_kernel<T, 4, 2>), dim3(grid), dim3(256), 0, s, k);
     else if (c.NI == 3 && c.WN == 2) hipLaunchKernelGGL((pw_gemm_kernel<T, 3, 2>), dim3(grid), dim3(256), 0, s, k);
