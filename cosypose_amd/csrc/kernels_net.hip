@@ -110,7 +110,8 @@ PwCfg pw_choose_cfg(int N) {
 // once per m-tile) elements, so a tile that covers N in ONE pass saves a whole pass over the activations -- as long as it
 // keeps two workgroups per CU.  Measured (256 crops): N = 136 with BN = 160 (NI5,WN2) instead of 2 x 96: 72 -> 55 us
 // (b14-17 project), 51 -> 41 us (b13).  Wider tiles lose: BN = 256 (NI8,WN2; 84 KB of LDS, one workgroup per CU) 58 -> 86
-// us, 256 x 128 (NI8,WN1) 66 -> 107 us, 2 x 192 for N = 384 61 -> 70 us.
+// us (82 us with a 2-stage ring that restores two workgroups per CU), 256 x 128 (NI8,WN1) 66 -> 107 us, 2 x 192 for N = 384
+// 61 -> 70 us.
 PwCfg pw_choose_cfg_late(int K, int N, int HW, bool gated) {
     (void)gated;
     static const int wide = getenv("COSY_PW_WIDE") ? atoi(getenv("COSY_PW_WIDE")) : 1;
