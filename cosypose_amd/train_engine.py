@@ -342,8 +342,9 @@ class _DisentangledLossFn(torch.autograd.Function):
         out9, gt, TCO_input, K_crop, points = ctx.saved
         B, S, Pn = gt.shape[0], gt.shape[1], points.shape[1]
         d = torch.empty(B, 9, device=out9.device)
+        dl = dloss.contiguous().float()       # held in a name: a temporary inside ptr() could be recycled before the launch
         check(lib().cosy_loss_refiner_disentangled_backward(ptr(gt), ptr(TCO_input), ptr(out9), ptr(K_crop), ptr(points), None, B, S, Pn,
-                                                            ptr(dloss.contiguous().float()), ptr(d), stream()))
+                                                            ptr(dl), ptr(d), stream()))
         return d, None, None, None, None
 
 

@@ -718,3 +718,34 @@ def test_refinement_loop_with_on_device_renderer(golden_sd):
     rgb = renderer.render([dict(name=l) for l in it.infos['label']], it.poses_input, it.K_crop, resolution=(240, 320))
     cover = (rgb.sum(1) > 0).float().mean((1, 2))
     assert (cover > 0.05).all() and (cover < 0.9).all()
+
+
+def test_crop_pack_all_window_paths(oracle):
+    """the fused crop + pack kernel against the roi_align oracle on boxes that exercise its three gather paths: 4x4 window
+    (bins < 2.6 px), 6x6 window (bins up to ~5 px), per-sample loop (huge boxes), plus out-of-frame and NaN boxes"""
+    from cosypose_amd._lib import lib, check, ptr, stream, COSY_F32
+    N, h, w, H, W = 2, 120, 160, 48, 64
+    frames = syn.make_frames(17, N, h, w)
+    boxes = np.array([[10.3, 5.2, 74.3, 53.2],          # bin 1.0: 4x4 path
+                      [0, 0, 160, 120],                  # bin 2.5
+                      [-40, -30, 200, 150],              # bin 3.75: 6x6 path, partly outside
+                      [-300, -200, 500, 400],            # bin 12.5: sample loop
+                      [150.2, 110.1, 150.9, 110.4],      # degenerate (roi clamped to 1 px)
+                      [400, 300, 500, 380],              # entirely outside -> zeros
+                      [np.nan, 0, 50, 50]], np.float32)
+    B = len(boxes)
+    im = np.array([0, 1, 0, 1, 0, 1, 0], np.int32)
+    renders = syn.make_renders(4, B, H, W)
+    frames4 = torch.empty(N, h, w, 4, device='cuda')
+    frames_d = dev(frames)
+    check(lib().cosy_frames_to_nhwc4(ptr(frames_d), ptr(frames4), N, h, w, stream()))
+    x8 = torch.full((B, H, W, 8), -7.0, device='cuda')
+    im_d, boxes_d, renders_d = dev(im, torch.int32), dev(boxes), dev(renders)     # keep the device buffers alive across the call
+    check(lib().cosy_crop_pack_to(ptr(x8), COSY_F32, ptr(frames4), ptr(im_d), ptr(boxes_d), ptr(renders_d), B, N, h, w, H, W, stream()))
+    got = x8.cpu().numpy()
+    rois = np.concatenate([im[:, None].astype(np.float32), boxes], 1)
+    want = oracle.roi_align(frames, rois[:6], (H, W), 4)
+    np.testing.assert_allclose(got[:6, :, :, :3].transpose(0, 3, 1, 2), want, rtol=0, atol=2e-6)
+    assert (got[5, :, :, :3] == 0).all() and (got[6, :, :, :3] == 0).all()          # outside / NaN box: no valid sample
+    assert np.array_equal(got[..., 3:6].transpose(0, 3, 1, 2), renders)              # render channels copied exactly
+    assert (got[..., 6:] == 0).all()                                                 # the two padding channels
