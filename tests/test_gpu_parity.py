@@ -749,3 +749,46 @@ def test_crop_pack_all_window_paths(oracle):
     assert (got[5, :, :, :3] == 0).all() and (got[6, :, :, :3] == 0).all()          # outside / NaN box: no valid sample
     assert np.array_equal(got[..., 3:6].transpose(0, 3, 1, 2), renders)              # render channels copied exactly
     assert (got[..., 6:] == 0).all()                                                 # the two padding channels
+
+
+def test_training_reference_loop_unchanged_and_deterministic(golden_train, golden_sd):
+    """the reference's own loop (train_pose.py:317-331: zero_grad / h / backward / clip_grad_norm_ / torch.optim.Adam.step)
+    runs unchanged on a cosypose_amd model and lands on the same weights as the fused FlatAdam path after 2 steps;
+    two identical runs are bit-identical (deterministic reductions, no atomics)."""
+    import argparse, types
+    from collections import defaultdict
+    from cosypose_amd import pose_forward_loss as pfl, train_engine
+    B = 4
+    frames, K, TCO, obj = syn.make_training_batch(61, B)
+    cfg = argparse.Namespace(n_points_loss=600, loss_disentangled=True, n_pose_dims=9, init_method='v0')
+
+    class M:
+        def add(self, v): pass
+
+    def run(kind):
+        model, mesh_db, labels_all = _train_model(golden_sd)
+        model.train(); model.drop_connect_rate = 0.0
+        data = types.SimpleNamespace(images=torch.from_numpy(frames), K=torch.from_numpy(K), TCO=torch.from_numpy(TCO),
+                                     objects=[dict(name=l) for l in labels_all[obj]], bboxes=torch.from_numpy(golden_train['tr_bboxes']))
+        opt = train_engine.FlatAdam(model, lr=3e-4, clip_grad_norm=0.5) if kind == 'flat' else torch.optim.Adam(model.parameters(), lr=3e-4)
+        losses = []
+        for step in range(2):
+            opt.zero_grad()
+            np.random.seed(123 + step)
+            loss = pfl.h_pose(model=model, mesh_db=mesh_db, data=data, meters=defaultdict(M), cfg=cfg, n_iterations=1, input_generator='fixed')
+            loss.backward()
+            if kind != 'flat':
+                torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=0.5, norm_type=2)
+            opt.step()
+            losses.append(loss.item())
+        return losses, {n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters()}
+
+    l_ref, p_ref = run('torch')
+    l_flat, p_flat = run('flat')
+    l_flat2, p_flat2 = run('flat')
+    assert l_flat == l_flat2 and all(np.array_equal(p_flat[n], p_flat2[n]) for n in p_flat)      # deterministic
+    assert abs(l_ref[0] - float(golden_train['tr_loss'])) < 1e-4 * abs(l_ref[0]) and l_ref[1] != l_ref[0]
+    assert np.allclose(l_ref, l_flat, rtol=1e-5)
+    for n in p_ref:
+        # Adam's early steps move each weight by ~lr regardless of the gradient scale: compare the applied updates
+        assert np.abs(p_ref[n] - p_flat[n]).max() < 5e-5, n
