@@ -663,7 +663,8 @@ static DwPlan dw_plan(int C, int Ho, int Wo, int k, int s, int esz) {
     p.TH = Ho <= 4 ? 4 : 8;
     p.THin = (p.TH - 1) * s + k; p.TWin = (p.TW - 1) * s + k;
     const int cg = C / 8;
-    const size_t lim = esz == 2 ? 40 * 1024 : 60 * 1024;
+    static const int lim_kb = getenv("COSY_DW_LDS_KB") ? atoi(getenv("COSY_DW_LDS_KB")) : 40;
+    const size_t lim = esz == 2 ? (size_t)lim_kb * 1024 : 60 * 1024;
     p.CGB = 1;
     for (int d = 1; d <= 16 && d <= cg; ++d) {
         if (cg % d) continue;
@@ -683,7 +684,7 @@ int dw_num_tiles(int C, int Ho, int Wo, int k) { DwPlan p = dw_plan(C, Ho, Wo, k
 
 struct DwKArgs {
     const void* in; const float* w; const float* scale; const float* bias; void* out; float* partial;
-    int H, W, C, Ho, Wo, lo, CGB, TH, TW, THin, TWin, ntx, n_tiles, n_chunks, n_jobs;
+    int H, W, C, Ho, Wo, lo, CGB, TH, TW, THin, TWin, ntx, n_tiles, n_chunks, n_jobs, dbg;
     const void* zeros;  // >= 16 zero bytes in global memory
 };
 
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwKArgs a) {
             ok[j] = ix >= 0 && ix < a.W;
             goff[j] = ix * a.C + q * (16 / (int)sizeof(T));
         }
-        for (int yy = wave; yy < THin; yy += nwaves) {
+        for (int yy = wave; yy < ((a.dbg & 2) ? 0 : THin); yy += nwaves) {
             const int iy = iy0 + yy;
             const bool yok = iy >= 0 && iy < a.H;
             const T* rowp = in + (size_t)iy * a.W * a.C;
@@ -765,7 +766,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwKArgs a) {
     float sum[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) sum[c] = 0.f;
-    if (tid < stride) {
+    if (tid < stride && !(a.dbg & 1)) {
         const int cg = tid % CGB;
         float sc[8], bi[8];
         load8(a.scale + c0 + cg * 8, sc);
@@ -833,6 +834,8 @@ static int launch_dw_t(const DwArgs& a, hipStream_t s) {
     k.H = a.H; k.W = a.W; k.C = a.C; k.Ho = a.Ho; k.Wo = a.Wo; k.lo = a.pad_lo;
     k.CGB = p.CGB; k.TH = p.TH; k.TW = p.TW; k.THin = p.THin; k.TWin = p.TWin; k.ntx = p.ntx; k.n_tiles = p.ntx * p.nty;
     k.n_chunks = p.n_chunks; k.n_jobs = k.n_tiles * a.B; k.zeros = a.zeros;
+    static const int dbg = getenv("COSY_DW_DBG") ? atoi(getenv("COSY_DW_DBG")) : 0;   // phase knock-out, timing experiments only
+    k.dbg = dbg;
     dim3 grid((unsigned)cdiv(k.n_jobs, 8) * 8 * p.n_chunks), block(p.threads);
     if (a.k == 3 && a.s == 1) hipLaunchKernelGGL((dwconv_kernel<T, 3, 1>), grid, block, p.lds, s, k);
     else if (a.k == 3 && a.s == 2) hipLaunchKernelGGL((dwconv_kernel<T, 3, 2>), grid, block, p.lds, s, k);
@@ -881,6 +884,10 @@ static FusePlan fuse_plan(int Cin, int Ho, int Wo, int k, int s, int esz) {
     p.kbn = cdiv(Cin, esz == 2 ? 32 : 16);
     const int cpt = 16 / ees, units = (48 / cpt) * p.TW * (p.TH / R);
     p.threads = ((units < 384 ? units : 384) + 63) / 64 * 64;
+    {   // enough waves for the expand phase too: at most 2 sixteen-pixel blocks per wave (COSY_FUSE_MBW, experiments)
+        static const int mbw = getenv("COSY_FUSE_MBW") ? atoi(getenv("COSY_FUSE_MBW")) : 0;
+        if (mbw > 0) { int t = cdiv(p.MB, mbw) * 64; if (t > 384) t = 384; if (t > p.threads) p.threads = t; }
+    }
     p.lds = (size_t)p.MB * p.kbn * 1024 + (size_t)p.MB * 16 * et_pitch(ees, s) + (size_t)k * k * 48 * 4 + (size_t)p.threads * 8 * 4;
     p.ntx = cdiv(Wo, p.TW); p.nty = cdiv(Ho, p.TH);
     return p;
