@@ -157,12 +157,11 @@ def make_drop_connect_scales(B, device, rate=DROP_CONNECT_RATE, generator=None):
     if not rate:
         return out
     n = len(arch.B3_BLOCKS)
-    for i, (k, s, e, cin, cout) in enumerate(arch.B3_BLOCKS):
-        r = rate * float(i) / n
-        if s == 1 and cin == cout and r:
-            keep = 1.0 - r
-            rnd = keep + torch.rand(B, device=device, generator=generator)
-            out[i] = (torch.floor(rnd) / keep).contiguous()
+    ids = [i for i, (k, s, e, cin, cout) in enumerate(arch.B3_BLOCKS) if s == 1 and cin == cout and rate * float(i) / n]
+    keep = torch.tensor([1.0 - rate * float(i) / n for i in ids], device=device).unsqueeze(1)
+    scales = torch.floor(keep + torch.rand(len(ids), B, device=device, generator=generator)) / keep      # all blocks at once
+    for j, i in enumerate(ids):
+        out[i] = scales[j]
     return out
 
 
@@ -176,9 +175,6 @@ class _Net:
     def _bn_f(self, tape, name, raw, M, C, act, rowscale=None, HW=1, res=None):
         rm, rv = self.buf.get(name + '.running_mean'), self.buf.get(name + '.running_var')
         mean, rstd = bn_stats(raw, M, C, rm, rv)
-        nb = self.buf.get(name + '.num_batches_tracked')
-        if nb is not None:
-            nb += 1
         tape[name] = (raw, mean, rstd, M, C, act, rowscale, HW)
         return bn_apply(raw, mean, rstd, self.P[name + '.weight'], self.P[name + '.bias'], M, C, act, rowscale, HW, res)
 
@@ -236,6 +232,9 @@ class _Net:
         feat = rows_mean(a, B, H * W, arch.HEAD_C)
         pose = torch.addmm(P['pose_fc.bias'], feat, P['pose_fc.weight'].t())
         tape['head'] = (x, feat, B, H, W)
+        nbt = [v for k, v in self.buf.items() if k.endswith('num_batches_tracked')]
+        if nbt:
+            torch._foreach_add_(nbt, 1)      # every BatchNorm saw one more batch: one launch for all 79 counters
         return pose, tape
 
     def backward(self, tape, dpose):
@@ -281,10 +280,10 @@ class _Net:
                 draw = self._bn_b(tape, grads, p + '_bn0', da0)
                 we = P[p + '_expand_conv.weight']
                 grads[p + '_expand_conv.weight'] = wgrad(draw, inp).view_as(we)
-                dinp = draw @ we.view(cmid, cin)
+                # the skip connection's gradient rides on the GEMM (C = dout + draw W) instead of a separate add
+                dx = torch.addmm(dout, draw, we.view(cmid, cin)) if skip else draw @ we.view(cmid, cin)
             else:
-                dinp = da0
-            dx = dinp + dout if skip else dinp
+                dx = da0 + dout if skip else da0
         draw = self._bn_b(tape, grads, 'backbone._bn0', dx)
         cols = tape['stem']
         grads['backbone._conv_stem.weight'] = wgrad(draw, cols).view(arch.STEM_C, 3, 3, 6).permute(0, 3, 1, 2).contiguous()
