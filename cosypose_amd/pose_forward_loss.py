@@ -37,52 +37,46 @@ def add_noise(TCO, euler_deg_std=(15, 15, 15), trans_std=(0.01, 0.01, 0.05)):
     return TCO_out
 
 
-def h_pose(model, mesh_db, data, meters, cfg, n_iterations=1, input_generator='fixed'):
-    batch_size, _, h, w = data.images.shape
+def _initial_poses(input_generator, cfg, TCO_possible_gt, bboxes, points, K):
+    """TCO_init of the training batch for the reference's three input generators (pose_forward_loss.py:32-43)."""
+    if input_generator == 'fixed':
+        return lib3d.TCO_init_from_boxes(z_range=(1.0, 1.0), boxes=bboxes, K=K)
+    if input_generator == 'gt+noise':
+        return add_noise(TCO_possible_gt[:, 0], euler_deg_std=[15, 15, 15], trans_std=[0.01, 0.01, 0.05])
+    if input_generator == 'fixed+trans_noise':
+        assert cfg.init_method == 'z-up+auto-depth'
+        rows = torch.arange(bboxes.shape[0], dtype=torch.int32, device=bboxes.device)      # points are already per sample
+        TCO_init = lib3d.TCO_init_from_boxes_zup_autodepth(bboxes, points, rows, K)
+        return add_noise(TCO_init, euler_deg_std=[0, 0, 0], trans_std=[0.01, 0.01, 0.05])
+    raise ValueError('Unknown input generator', input_generator)
 
+
+def h_pose(model, mesh_db, data, meters, cfg, n_iterations=1, input_generator='fixed'):
+    if not (cfg.loss_disentangled and cfg.n_pose_dims == 9):
+        raise ValueError('only the disentangled loss on 9-d pose outputs is built (cfg.loss_disentangled, n_pose_dims=9)')
+    # batch -> device (uint8 frames to [0,1] floats as in the reference)
     images = cast(data.images).float() / 255.
-    K = cast(data.K).float()
-    TCO_gt = cast(data.TCO).float()
+    K, TCO_gt, bboxes = cast(data.K).float(), cast(data.TCO).float(), cast(data.bboxes).float()
     labels = np.array([obj['name'] for obj in data.objects])
-    bboxes = cast(data.bboxes).float()
 
     meshes = mesh_db.select(labels)
-    points = meshes.sample_points(cfg.n_points_loss, deterministic=False)
-    TCO_possible_gt = TCO_gt.unsqueeze(1) @ meshes.symmetries
+    points = meshes.sample_points(cfg.n_points_loss, deterministic=False)      # global numpy RNG, as in the reference
+    TCO_possible_gt = TCO_gt.unsqueeze(1) @ meshes.symmetries                  # every symmetric copy of the ground truth
+    TCO_init = _initial_poses(input_generator, cfg, TCO_possible_gt, bboxes, points, K)
 
-    if input_generator == 'fixed':
-        TCO_init = lib3d.TCO_init_from_boxes(z_range=(1.0, 1.0), boxes=bboxes, K=K)
-    elif input_generator == 'gt+noise':
-        TCO_init = add_noise(TCO_possible_gt[:, 0], euler_deg_std=[15, 15, 15], trans_std=[0.01, 0.01, 0.05])
-    elif input_generator == 'fixed+trans_noise':
-        assert cfg.init_method == 'z-up+auto-depth'
-        TCO_init = lib3d.TCO_init_from_boxes_zup_autodepth(bboxes, points, torch.arange(batch_size, dtype=torch.int32, device=bboxes.device), K)
-        TCO_init = add_noise(TCO_init, euler_deg_std=[0, 0, 0], trans_std=[0.01, 0.01, 0.05])
-    else:
-        raise ValueError('Unknown input generator', input_generator)
-
-    module = model.module if hasattr(model, 'module') else model
+    module = model.module if hasattr(model, 'module') else model               # DistributedDataParallel wrapper or bare module
     outputs = module(images=images, K=K, labels=labels, TCO=TCO_init, n_iterations=n_iterations)
 
-    losses_TCO_iter = []
-    for n in range(n_iterations):
-        iter_outputs = outputs[f'iteration={n+1}']
-        K_crop = iter_outputs['K_crop']
-        TCO_input = iter_outputs['TCO_input']
-        model_outputs = iter_outputs['model_outputs']
+    per_iteration = []
+    for n in range(1, n_iterations + 1):
+        it = outputs[f'iteration={n}']
+        loss_n = train_engine.loss_refiner_CO_disentangled(TCO_possible_gt=TCO_possible_gt, TCO_input=it['TCO_input'],
+                                                           refiner_outputs=it['model_outputs']['pose'], K_crop=it['K_crop'],
+                                                           points=points)
+        meters[f'loss_TCO-iter={n}'].add(loss_n.mean().item())
+        per_iteration.append(loss_n)
 
-        if cfg.loss_disentangled and cfg.n_pose_dims == 9:
-            loss_TCO_iter = train_engine.loss_refiner_CO_disentangled(
-                TCO_possible_gt=TCO_possible_gt, TCO_input=TCO_input, refiner_outputs=model_outputs['pose'],
-                K_crop=K_crop, points=points)
-        else:
-            raise ValueError('only the disentangled loss on 9-d pose outputs is built (cfg.loss_disentangled, n_pose_dims=9)')
-
-        meters[f'loss_TCO-iter={n+1}'].add(loss_TCO_iter.mean().item())
-        losses_TCO_iter.append(loss_TCO_iter)
-
-    loss_TCO = torch.cat(losses_TCO_iter).mean()
-    loss = loss_TCO
-    meters['loss_TCO'].add(loss_TCO.item())
+    loss = torch.cat(per_iteration).mean()
+    meters['loss_TCO'].add(loss.item())
     meters['loss_total'].add(loss.item())
     return loss
