@@ -792,3 +792,50 @@ def test_training_reference_loop_unchanged_and_deterministic(golden_train, golde
     for n in p_ref:
         # Adam's early steps move each weight by ~lr regardless of the gradient scale: compare the applied updates
         assert np.abs(p_ref[n] - p_flat[n]).max() < 5e-5, n
+
+
+def test_distance_and_render_ops_at_full_size():
+    """BASELINE-size inputs (2048 candidates, 2600 loss points, 256 renders) through size-independent properties: batch
+    invariance and permutation equivariance, bit for bit (fixed-order reductions, order-independent z-buffer)."""
+    from cosypose_amd import symmetric_distances as sd, distances
+    from cosypose_amd.mesh_db import BatchedMeshes
+    rs = np.random.RandomState(31)
+    n_obj, P, S, B = 30, 2600, 6, 2048
+    pts = (rs.uniform(-1, 1, (n_obj, P, 3)) * 0.1).astype(np.float32)
+    n_sym = rs.randint(1, S + 1, n_obj)
+    sym = np.tile(np.eye(4, dtype=np.float32), (n_obj, S, 1, 1))
+    for o in range(n_obj):
+        for k in range(1, n_sym[o]):
+            a = 2 * np.pi * k / n_sym[o]
+            sym[o, k, :3, :3] = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+    labels = np.array([f'o{i}' for i in range(n_obj)])
+    db = BatchedMeshes({l: dict(label=l, n_sym=int(n_sym[i])) for i, l in enumerate(labels)}, labels, torch.from_numpy(pts),
+                       torch.from_numpy(sym)).float().cuda()
+    obj = rs.randint(0, n_obj, B)
+    T2 = syn_poses(rs, B); T1 = T2.copy(); T1[:, :3, 3] += (rs.randn(B, 3) * 2e-3).astype(np.float32)
+    perm = rs.permutation(B)
+    for fn in (sd.symmetric_distance_batched, sd.symmetric_distance_batched_fast):
+        d, S12 = fn(dev(T1), dev(T2), labels[obj], db)
+        dp, S12p = fn(dev(T1[perm]), dev(T2[perm]), labels[obj[perm]], db)
+        d64, _ = fn(dev(T1[:64]), dev(T2[:64]), labels[obj[:64]], db)
+        assert torch.equal(dp, d[torch.from_numpy(perm).cuda()]) and torch.equal(S12p, S12[torch.from_numpy(perm).cuda()])
+        assert torch.equal(d64, d[:64]) and torch.isfinite(d).all() and (d > 0).all()
+    Bp = 64
+    pts_b = dev(pts[obj[:Bp]])
+    s = distances.dists_add_symmetric(dev(T1[:Bp]), dev(T2[:Bp]), pts_b)
+    s8 = distances.dists_add_symmetric(dev(T1[:8]), dev(T2[:8]), pts_b[:8])
+    a = distances.dists_add(dev(T1[:Bp]), dev(T2[:Bp]), pts_b)
+    assert torch.equal(s8, s[:8])
+    assert (s.norm(dim=-1) <= a.norm(dim=-1) + 1e-7).all()          # the nearest predicted point is never farther than the matched one
+    # rasteriser: 256 crops of 256x256, twice and in a different batch composition
+    labels_r, _, meshes, renderer = _render_setup(5)
+    Br = 256
+    objr = rs.randint(0, 5, Br)
+    TCO = syn.make_TCO(77, Br, z_range=(0.5, 1.0), xy=0.05)
+    K = np.tile(np.array([[520., 0, 127.3], [0, 515., 128.2], [0, 0, 1]], np.float32), (Br, 1, 1))
+    infos = [dict(name=labels_r[o]) for o in objr]
+    r1 = renderer.render(infos, dev(TCO), dev(K), resolution=(256, 256))
+    r2 = renderer.render(infos, dev(TCO), dev(K), resolution=(256, 256))
+    r3 = renderer.render(infos[100:140], dev(TCO[100:140]), dev(K[100:140]), resolution=(256, 256))
+    assert torch.equal(r1, r2) and torch.equal(r3, r1[100:140]) and r1.shape == (Br, 3, 256, 256)
+    assert ((r1.sum(1) > 0).float().mean((1, 2)) > 0.01).all()
