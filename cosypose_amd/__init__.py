@@ -16,4 +16,10 @@ def __getattr__(name):  # lazy: importing the package must not require torch.cud
     if name == 'BatchedMeshes':
         from .mesh_db import BatchedMeshes
         return BatchedMeshes
+    if name in ('HipBatchRenderer', 'RenderMeshes'):
+        from . import rasterizer
+        return getattr(rasterizer, name)
+    if name == 'h_pose':
+        from .pose_forward_loss import h_pose
+        return h_pose
     raise AttributeError(name)
