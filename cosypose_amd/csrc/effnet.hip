@@ -536,13 +536,17 @@ int cosy_frames_to_nhwc4(const float* images, float* out, int N, int h, int w, c
 
 int cosy_crop_pack(cosy_net_t* n, const float* images, const int* im_id, const float* boxes_crop, const float* renders, int B,
                    int N, int h, int w, cosy_stream_t stream) {
-    COSY_REQUIRE(n && images && boxes_crop && renders, "crop_pack: null argument");
+    COSY_REQUIRE(n, "crop_pack: null net");
+    if (B == 0) return COSY_OK;   // an empty batch carries null data pointers (an empty device tensor has none)
+    COSY_REQUIRE(images && boxes_crop && renders, "crop_pack: null argument");
     COSY_REQUIRE(B >= 0 && B <= n->maxB, "crop_pack: batch %d exceeds max_batch %d", B, n->maxB);
     return launch_crop_pack(n->X, n->dtype, images, im_id, boxes_crop, renders, B, N, h, w, n->H, n->W, (hipStream_t)stream);
 }
 
 int cosy_effnet_b3_forward(cosy_net_t* n, int B, float* feat, float* pose9, float* taps, cosy_stream_t stream) {
-    COSY_REQUIRE(n && pose9, "forward: null argument");
+    COSY_REQUIRE(n, "forward: null net");
+    if (B == 0) return COSY_OK;
+    COSY_REQUIRE(pose9, "forward: null argument");
     COSY_REQUIRE(B >= 0 && B <= n->maxB, "forward: batch %d exceeds max_batch %d", B, n->maxB);
     return net_forward_top(n, B, feat, pose9, taps, (hipStream_t)stream);
 }
@@ -559,6 +563,7 @@ int cosy_effnet_b3_features_nchw(cosy_net_t* n, int B, float* out, cosy_stream_t
 int cosy_crop_geometry(const float* pts_table, const int* obj_id, const float* K, const int* im_id, const float* TCO, int B, int P,
                        float z_min, int im_h, int im_w, int out_h, int out_w, float lamb, float* boxes_rend, float* boxes_crop,
                        float* K_crop, cosy_stream_t stream) {
+    if (B == 0) return COSY_OK;
     COSY_REQUIRE(pts_table && obj_id && K && TCO && boxes_rend && boxes_crop && K_crop, "crop_geometry: null argument");
     COSY_REQUIRE(B >= 0 && P >= 1, "crop_geometry: bad sizes B=%d P=%d", B, P);
     return launch_crop_geometry(pts_table, obj_id, K, im_id, TCO, B, P, z_min, im_h, im_w, out_h, out_w, lamb, boxes_rend,
@@ -567,22 +572,26 @@ int cosy_crop_geometry(const float* pts_table, const int* obj_id, const float* K
 
 int cosy_roi_align(const float* images, const int* im_id, const float* boxes, int B, int N, int C, int h, int w, int out_h,
                    int out_w, int sampling_ratio, float* out, cosy_stream_t stream) {
+    if (B == 0) return COSY_OK;
     COSY_REQUIRE(images && boxes && out, "roi_align: null argument");
     return launch_roi_align(images, im_id, boxes, B, N, C, h, w, out_h, out_w, sampling_ratio, out, (hipStream_t)stream);
 }
 
 int cosy_pose_update(const float* TCO_in, const float* K_crop, const float* pose9, int B, float* TCO_out, cosy_stream_t stream) {
+    if (B == 0) return COSY_OK;
     COSY_REQUIRE(TCO_in && K_crop && pose9 && TCO_out, "pose_update: null argument");
     return launch_pose_update(TCO_in, K_crop, pose9, B, TCO_out, (hipStream_t)stream);
 }
 
 int cosy_tco_init_from_boxes(const float* boxes, const float* K, const int* im_id, int B, float z, float* TCO, cosy_stream_t stream) {
+    if (B == 0) return COSY_OK;
     COSY_REQUIRE(boxes && K && TCO, "tco_init_from_boxes: null argument");
     return launch_tco_init_from_boxes(boxes, K, im_id, B, z, TCO, (hipStream_t)stream);
 }
 
 int cosy_tco_init_zup_autodepth(const float* boxes, const float* pts_table, const int* obj_id, const float* K, const int* im_id,
                                 int B, int P, float* TCO, cosy_stream_t stream) {
+    if (B == 0) return COSY_OK;
     COSY_REQUIRE(boxes && pts_table && obj_id && K && TCO, "tco_init_zup_autodepth: null argument");
     return launch_tco_init_zup(boxes, pts_table, obj_id, K, im_id, B, P, TCO, (hipStream_t)stream);
 }

@@ -64,8 +64,11 @@ def h_pose(model, mesh_db, data, meters, cfg, n_iterations=1, input_generator='f
     TCO_possible_gt = TCO_gt.unsqueeze(1) @ meshes.symmetries                  # every symmetric copy of the ground truth
     TCO_init = _initial_poses(input_generator, cfg, TCO_possible_gt, bboxes, points, K)
 
-    module = model.module if hasattr(model, 'module') else model               # DistributedDataParallel wrapper or bare module
-    outputs = module(images=images, K=K, labels=labels, TCO=TCO_init, n_iterations=n_iterations)
+    # Through the wrapper when the model is DistributedDataParallel (as train_pose.py:246 wraps it): DDP.forward is what
+    # arms the reducer for this backward -- calling model.module directly would skip the gradient all-reduce and the
+    # buffer broadcast without any error.  The network is ONE autograd node whose inputs are the leaf parameters, so the
+    # reducer's per-parameter hooks fire as usual.
+    outputs = model(images=images, K=K, labels=labels, TCO=TCO_init, n_iterations=n_iterations)
 
     per_iteration = []
     for n in range(1, n_iterations + 1):

@@ -1,5 +1,5 @@
-"""N>1 path on CPU: world_size-2 gloo processes exercise the sharding + single-collective
-gather used by bench.py / gather_distributed (RCCL on the GPU box, gloo here)."""
+"""N>1 path on CPU: gloo processes exercise the sharding + single-collective gather used by bench.py,
+gather_distributed and get_predictions_sharded (RCCL on the GPU box, gloo here)."""
 import os
 import sys
 import pathlib
@@ -12,6 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 REPO = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
 
 
 def _free_port():
@@ -19,45 +20,176 @@ def _free_port():
     return p
 
 
+class FakePredictor:
+    """CPU stand-in with CoarseRefinePosePredictor.get_predictions' contract: every candidate's outputs depend only on
+    its own box / label / frame (as on the device), so sharded == single-process bit for bit."""
+
+    def _iter(self, infos, start, images, K, n):
+        from cosypose_amd import tensor_collection as tc
+        im = torch.as_tensor(infos['batch_im_id'].values.astype(np.int64))
+        lab = torch.as_tensor([float(int(l[1:])) for l in infos['label']], dtype=torch.float32)
+        frame = images[im].reshape(len(im), -1).mean(1) if len(im) else torch.zeros(0)
+        outs = {}
+        cur = start
+        for i in range(1, n + 1):
+            upd = cur.clone()
+            upd[:, :3, 3] += (0.01 * i * (lab + frame) + K[im][:, 0, 0] * 1e-4).unsqueeze(1)
+            k_crop = K[im] * (1.0 + 0.1 * i)
+            boxes = torch.stack([lab, frame, lab * i, frame + i], 1)
+            outs[f'iteration={i}'] = tc.PandasTensorCollection(infos, poses=upd, poses_input=cur, K_crop=k_crop, boxes_rend=boxes,
+                                                               boxes_crop=boxes * 2)
+            cur = upd
+        return outs
+
+    def get_predictions(self, images, K, detections=None, data_TCO_init=None, n_coarse_iterations=1, n_refiner_iterations=1):
+        preds = {}
+        if data_TCO_init is None:
+            infos = detections.infos
+            start = torch.eye(4).repeat(len(infos), 1, 1)
+            if len(infos):
+                start[:, :2, 3] = detections.bboxes[:, :2] * 1e-3
+            out = self._iter(infos, start, images, K, n_coarse_iterations)
+            for k, v in out.items():
+                preds[f'coarse/{k}'] = v
+            cur = out[f'iteration={n_coarse_iterations}']
+        else:
+            cur = preds['external_coarse'] = data_TCO_init
+        if n_refiner_iterations:
+            out = self._iter(cur.infos, cur.poses, images, K, n_refiner_iterations)
+            for k, v in out.items():
+                preds[f'refiner/{k}'] = v
+            cur = out[f'iteration={n_refiner_iterations}']
+        return cur, preds
+
+
+def _global_table(D=37, n_frames=5):
+    import pandas as pd
+    from cosypose_amd import tensor_collection as tc
+    rs = np.random.RandomState(3)
+    infos = pd.DataFrame(dict(label=[f'o{rs.randint(1, 9)}' for _ in range(D)], batch_im_id=rs.randint(0, n_frames, D), score=rs.rand(D)))
+    boxes = torch.as_tensor(rs.rand(D, 4).astype(np.float32) * 100)
+    images = torch.as_tensor(rs.rand(n_frames, 3, 8, 8).astype(np.float32))
+    K = torch.as_tensor(rs.rand(n_frames, 3, 3).astype(np.float32) * 100)
+    return tc.PandasTensorCollection(infos, bboxes=boxes), images, K
+
+
+def _same(a, b):
+    return sorted(a) == sorted(b) and all(
+        a[k].infos.equals(b[k].infos) and sorted(a[k].tensors) == sorted(b[k].tensors) and
+        all(torch.equal(a[k].tensors[f], b[k].tensors[f]) for f in a[k].tensors)
+        for k in a)
+
+
+def _drop_external(d):
+    return {k: v for k, v in d.items() if k != 'external_coarse'}
+
+
 def _worker(rank, world, port, q):
+    try:
+        _worker_body(rank, world, port, q)
+    except Exception:
+        import traceback
+        traceback.print_exc()
+        q.put((rank, False))
+        raise
+
+
+def _worker_body(rank, world, port, q):
     sys.path.insert(0, str(REPO))
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     import pandas as pd
-    from cosypose_amd.distributed import init_distributed_mode, shard_range, all_gather_rows, get_rank, get_world_size
+    from cosypose_amd.distributed import (init_distributed_mode, shard_range, all_gather_rows, get_rank, get_world_size,
+                                          get_predictions_sharded)
     from cosypose_amd import tensor_collection as tc
     init_distributed_mode('gloo')
     assert (get_rank(), get_world_size()) == (rank, world)
-    D = 11                                               # ragged: 6 + 5
+    D = 4 * world + 3                                    # ragged
     poses = torch.arange(D * 16, dtype=torch.float32).reshape(D, 4, 4)
     s, e = shard_range(D)
-    got = all_gather_rows(poses[s:e], max_rows=6)        # one collective, bound known a priori
+    bound = -(-D // world)
+    got = all_gather_rows(poses[s:e], max_rows=bound)    # one collective, bound known a priori
     ok = torch.equal(got, poses)
-    skew = poses[:3] if rank == 0 else poses[3:]         # load-imbalanced shares, bound agreed on the fly
+    skew = poses[:3] if rank == 0 else (poses[3:] if rank == world - 1 else poses[:0])   # load-imbalanced, empty middle ranks
     ok &= torch.equal(all_gather_rows(skew), poses)
-    ok &= all_gather_rows(poses[:0] if rank == 0 else poses).shape[0] == D   # an empty rank
+    # dtypes survive exactly: int64 beyond 2**24 / 2**53, float64, bool
+    big = torch.tensor([2 ** 40 + 1 + rank, -(2 ** 55) - rank], dtype=torch.int64)
+    ok &= all_gather_rows(big).tolist() == [v for r in range(world) for v in (2 ** 40 + 1 + r, -(2 ** 55) - r)]
+    ok &= all_gather_rows(torch.tensor([[1.0 + 2.0 ** -40 * (rank + 1)]], dtype=torch.float64)).dtype == torch.float64
+    ok &= all_gather_rows(torch.tensor([rank % 2 == 0])).tolist() == [r % 2 == 0 for r in range(world)]
+    # collection gather incl. an int tensor and a rank that produced nothing (tc.concatenate([]) has no tensors at all)
     infos = pd.DataFrame(dict(label=[f'o{i}' for i in range(s, e)], batch_im_id=list(range(s, e))))
-    coll = tc.PandasTensorCollection(infos, poses=poses[s:e], boxes_crop=torch.ones(e - s, 4) * rank)
+    coll = tc.PandasTensorCollection(infos, poses=poses[s:e], boxes_crop=torch.ones(e - s, 4) * rank,
+                                     ids=torch.arange(s, e, dtype=torch.int64) + 2 ** 33)
+    if rank == 1:
+        coll = tc.concatenate([])
     full = coll.gather_distributed(tmp_dir=None)
-    ok &= list(full.infos['label']) == [f'o{i}' for i in range(D)] and torch.equal(full.poses, poses)
-    ok &= full.boxes_crop[:, 0].tolist() == [0.0] * 6 + [1.0] * 5
+    s1, e1 = shard_range(D, 1, world)
+    keep = [i for i in range(D) if not (s1 <= i < e1)]
+    ok &= list(full.infos['label']) == [f'o{i}' for i in keep] and torch.equal(full.poses, poses[keep])
+    ok &= full.ids.dtype == torch.int64 and full.ids.tolist() == [i + 2 ** 33 for i in keep]
+    # the sharded driver: every rank passes the global table and receives the full result == single process, bit for bit
+    det, images, K = _global_table()
+    pred = FakePredictor()
+    ref_final, ref = pred.get_predictions(images, K, detections=det, n_coarse_iterations=1, n_refiner_iterations=4)
+    skewed = [len(det) - 3 * (world - 1)] + [3] * (world - 1)
+    for kw in (dict(balance='contiguous'), dict(balance='cost', costs=np.arange(len(det)) % 7 + 1.0), dict(balance='counts', counts=skewed)):
+        final, out = get_predictions_sharded(pred, images, K, detections=det, n_coarse_iterations=1, n_refiner_iterations=4, **kw)
+        ok &= _same(out, ref) and torch.equal(final.poses, ref_final.poses)
+    # refiner-only from given poses (configs[2]) and the zero-detection call
+    init = tc.PandasTensorCollection(det.infos, poses=ref['coarse/iteration=1'].poses)
+    final, out = get_predictions_sharded(pred, images, K, data_TCO_init=init, n_coarse_iterations=0, n_refiner_iterations=2)
+    r2 = pred.get_predictions(images, K, data_TCO_init=init, n_coarse_iterations=0, n_refiner_iterations=2)[1]
+    ok &= _same(_drop_external(out), _drop_external(r2))
+    final, out = get_predictions_sharded(pred, images, K, detections=det[np.zeros(0, np.int64)], n_refiner_iterations=1)
+    ok &= len(final) == 0
     # training (SURVEY 8a-13 / 8e): DDP's gradient averaging as one all-reduce of the flat gradient buffer
     from cosypose_amd.train_engine import allreduce_gradients
     gflat = torch.full((1000,), float(rank + 1))
     allreduce_gradients(gflat)
-    ok &= bool(torch.allclose(gflat, torch.full((1000,), 1.5)))
+    ok &= bool(torch.allclose(gflat, torch.full((1000,), (world + 1) / 2)))
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gather_gloo():
+@pytest.mark.parametrize('world', [2, 4])
+def test_gather_and_sharded_predictor_gloo(world):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(2))
+    res = sorted(q.get(timeout=180) for _ in range(world))
     for p in procs:
         p.join(60)
-    assert res == [(0, True), (1, True)]
+    assert res == [(r, True) for r in range(world)]
+
+
+def test_plan_shards_and_simulated_ranks():
+    """Partition rules + the pack / reorder logic with the collective replaced by an in-process concat of all ranks' rows."""
+    from cosypose_amd.distributed import plan_shards, get_predictions_sharded, run_shard, RowPacker
+    assert [len(p) for p in plan_shards(11, 4)] == [3, 3, 3, 2]
+    skew = [512, 384, 320, 256, 224, 160, 128, 64]
+    assert [len(p) for p in plan_shards(2048, 8, 'counts', counts=skew)] == skew
+    costs = np.array([9, 1, 1, 1, 8, 1, 1, 2.0])
+    plan = plan_shards(8, 2, 'cost', costs=costs)
+    assert sorted(np.concatenate(plan).tolist()) == list(range(8)) and abs(costs[plan[0]].sum() - costs[plan[1]].sum()) <= 2
+    det, images, K = _global_table()
+    pred = FakePredictor()
+    _, ref = pred.get_predictions(images, K, detections=det, n_coarse_iterations=1, n_refiner_iterations=2)
+    world = 5
+    fields = ('poses', 'poses_input', 'K_crop', 'boxes_rend', 'boxes_crop')
+    keys = ['coarse/iteration=1', 'refiner/iteration=1', 'refiner/iteration=2']
+    for kw in (dict(balance='contiguous'), dict(balance='cost', costs=np.arange(len(det)) % 5 + 1.0)):
+        plan = plan_shards(len(det), world, kw['balance'], costs=kw.get('costs'))
+        rows_of = []
+        for r in range(world):      # what every rank would contribute
+            _, p = run_shard(pred, images, K, det, plan[r], n_coarse_iterations=1, n_refiner_iterations=2)
+            packer = RowPacker([(f'{k}|{f}', tuple(p[k].tensors[f].shape[1:]), torch.float32) for k in keys for f in fields])
+            rows_of.append(packer.pack({f'{k}|{f}': p[k].tensors[f] for k in keys for f in fields}, len(plan[r]), 'cpu'))
+        gather = lambda local, counts: torch.cat(rows_of)
+        for r in (0, world - 1):
+            _, out = get_predictions_sharded(pred, images, K, detections=det, n_coarse_iterations=1, n_refiner_iterations=2, rank=r,
+                                             world_size=world, gather_rows=gather, **kw)
+            assert _same(out, ref)
