@@ -87,10 +87,13 @@ def lib():
     """Load the shared library (once).  Raises if it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
-            raise CosyHipError(f'{LIB} not found: build it with `python -m cosypose_amd.build` '
+        path = LIB
+        if os.environ.get('COSY_TUNE_LIB'):       # experiments only: the -DCOSY_TUNE build that reads COSY_* knobs
+            from .build import TUNE_LIB as path
+        if not os.path.exists(path):
+            raise CosyHipError(f'{path} not found: build it with `python -m cosypose_amd.build` '
                                '(or __graft_entry__.build()); cosypose_amd has no CPU / eager fallback')
-        l = ctypes.CDLL(LIB)
+        l = ctypes.CDLL(path)
         for name, (args, res) in _SIGNATURES.items():
             fn = getattr(l, name)
             fn.argtypes = args

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libcosyhip.so')
 SOURCES = ['kernels_geom.hip', 'kernels_dist.hip', 'kernels_raster.hip', 'kernels_train.hip', 'kernels_net.hip',
-           'effnet.hip']
+           'kernels_mbconv.hip', 'kernels_wave.hip', 'effnet.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
@@ -22,35 +22,40 @@ def _headers():
     return hs + [os.path.join(HERE, '..', 'include', 'cosyhip.h')]
 
 
-def _obj(src):
-    return os.path.join(LIBDIR, os.path.splitext(src)[0] + '.o')
+TUNE_LIB = os.path.join(LIBDIR, 'libcosyhip_tune.so')   # -DCOSY_TUNE build: env knobs + phase knock-outs, experiments only
 
 
-def _stale_sources(force):
+def _obj(src, tune=False):
+    return os.path.join(LIBDIR, os.path.splitext(src)[0] + ('.tune.o' if tune else '.o'))
+
+
+def _stale_sources(force, tune=False):
     hdr_t = max(os.path.getmtime(h) for h in _headers())
     out = []
     for s in SOURCES:
-        src, obj = os.path.join(CSRC, s), _obj(s)
+        src, obj = os.path.join(CSRC, s), _obj(s, tune)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
             out.append(s)
     return out
 
 
-def build(force=False, verbose=False, extra_flags=()):
+def build(force=False, verbose=False, tune=False):
+    """The shipping library, or with tune=True the experiment build (reads COSY_* environment knobs)."""
     os.makedirs(LIBDIR, exist_ok=True)
-    stale = _stale_sources(force)
-    if not stale and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(_obj(s)) for s in SOURCES):
+    stale = _stale_sources(force, tune)
+    LIB = TUNE_LIB if tune else globals()['LIB']
+    if not stale and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(_obj(s, tune)) for s in SOURCES):
         return LIB
 
     def compile_one(s):
-        cmd = [HIPCC] + FLAGS + list(extra_flags) + ['-c', os.path.join(CSRC, s), '-o', _obj(s)]
+        cmd = [HIPCC] + FLAGS + (['-DCOSY_TUNE'] if tune else []) + ['-c', os.path.join(CSRC, s), '-o', _obj(s, tune)]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
 
     with ThreadPoolExecutor(max_workers=min(len(stale), os.cpu_count() or 1) or 1) as ex:
         list(ex.map(compile_one, stale))
-    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + [_obj(s) for s in SOURCES]
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + [_obj(s, tune) for s in SOURCES]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -59,4 +64,4 @@ def build(force=False, verbose=False, extra_flags=()):
 
 if __name__ == '__main__':
     import sys
-    print(build(force='--force' in sys.argv, verbose=True))
+    print(build(force='--force' in sys.argv, verbose=True, tune='--tune' in sys.argv))

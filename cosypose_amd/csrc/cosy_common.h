@@ -28,6 +28,17 @@ void set_error(const char* fmt, ...);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Tuning / phase knock-out knobs exist only in the -DCOSY_TUNE build (lib/libcosyhip_tune.so: experiments, timing only --
+// results may be meaningless).  The shipping library reads no environment variable and compiles no knock-out branch.
+#ifdef COSY_TUNE
+#include <stdlib.h>
+static inline int tune_int(const char* name, int dflt) { const char* v = getenv(name); return v ? (int)strtol(v, nullptr, 0) : dflt; }
+#define COSY_DBG(expr) (expr)
+#else
+static inline int tune_int(const char*, int dflt) { return dflt; }
+#define COSY_DBG(expr) 0
+#endif
+
 typedef __bf16 bf16_t;
 typedef _Float16 f16_t;
 typedef float f32x4 __attribute__((ext_vector_type(4)));

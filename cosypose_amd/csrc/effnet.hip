@@ -56,7 +56,7 @@ static long param_count() {
 
 struct PwLayer { int K = 0, N = 0; PwCfg cfg{4, 2}; void* Wp = nullptr; float* scale = nullptr; float* bias = nullptr; };
 struct Block {
-    BlkDef d; int cmid, cse, H, W, Ho, Wo, pad_lo, n_tiles; bool skip, fused;
+    BlkDef d; int cmid, cse, H, W, Ho, Wo, pad_lo, n_tiles; bool skip, fused, rows, wave;
     PwLayer exp, proj;
     void* exp_wp_fused;   // expand weights packed in 48-channel tiles for mbconv_front_kernel
     float *dw_w, *dw_scale, *dw_bias, *se_wr, *se_br, *se_we, *se_be;
@@ -73,6 +73,8 @@ struct cosy_net {
     void* X;
     int chunk, fuse;
     unsigned fuse_mask;   // bit i: MBConv block i runs the fused expand+depthwise front kernel
+    unsigned rows_mask;   // bit i: ... in its row-streaming form (mbconv_rows_kernel) where the shape allows
+    unsigned wave_mask;   // bit i: ... in its wave-autonomous form (mbconv_wave_kernel) where the shape allows (wins over rows)
     // activation workspaces: ws[0] holds max_batch samples; ws[1] (half size) serves the second half-batch when the
     // forward is split over two internal streams so that VALU-bound and MFMA/bandwidth-bound kernels co-reside
     struct WS { void *act[2], *E, *D, *Hd, *actc[2], *Ec, *Dc; float *partial, *gate, *featbuf; } ws[2];
@@ -155,11 +157,15 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         b.n_tiles = dw_num_tiles(b.cmid, b.Ho, b.Wo, b.d.k);
         // selected blocks (default 2-5 and 8): expand + depthwise fused, the expanded tensor stays in LDS
         b.fused = n->fuse && b.d.e != 1 && ((n->fuse_mask >> i) & 1) && fuse_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
+        b.rows = n->fuse && b.d.e != 1 && ((n->rows_mask >> i) & 1) && rows_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W, b.Ho, b.Wo);
+        b.wave = n->fuse && b.d.e != 1 && ((n->wave_mask >> i) & 1) && wave_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
+        if (b.wave) b.rows = false;
+        if (b.rows || b.wave) b.fused = true;
         b.exp_wp_fused = nullptr;
         if (b.d.e != 1) {
             mk_pw(b.exp, p, b.d.cin, b.cmid, p + (size_t)b.cmid * b.d.cin, b.H * b.W, false);
             if (b.fused) {
-                const PwCfg c48{3, 1};
+                const PwCfg c48 = b.wave ? PwCfg{1, 1} : PwCfg{3, 1};   // 16-channel tiles for the wave kernel, 48 otherwise
                 const size_t ne = pw_packed_elems(b.d.cin, b.cmid, c48, n->dtype);
                 b.exp_wp_fused = bump.take(ne * n->esz);
                 if (fill) {
@@ -168,7 +174,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
                     hipError_t e2 = hipMemcpy(b.exp_wp_fused, tmp.data(), tmp.size(), hipMemcpyHostToDevice);
                     if (e2 != hipSuccess) *herr = e2;
                 }
-                b.n_tiles = fuse_num_tiles(b.d.cin, b.Ho, b.Wo, b.d.k, b.d.s, n->dtype);
+                b.n_tiles = b.wave ? wave_max_tiles() : b.rows ? 1 : fuse_num_tiles(b.d.cin, b.Ho, b.Wo, b.d.k, b.d.s, n->dtype);
             }
             p += (size_t)b.cmid * b.d.cin + 4 * b.cmid;
         }
@@ -285,13 +291,16 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
     auto run_block = [&](int i, const void* in, void* out, int Bc, void* Ebuf, void* Dbuf) -> int {
         const Block& b = n->blk[i];
         const void* src = in;
+        int se_tiles = b.n_tiles;     // partial-sum tiles per sample the front kernel writes (the wave kernel decides per launch)
         if (b.fused) {
             FuseArgs f{};
             f.X = in; f.Wp = b.exp_wp_fused; f.s0 = b.exp.scale; f.b0 = b.exp.bias; f.dww = b.dw_w; f.s1 = b.dw_scale; f.b1 = b.dw_bias;
             f.D = Dbuf; f.partial = w.partial; f.zeros = n->zeros;
             f.B = Bc; f.H = b.H; f.W = b.W; f.Cin = b.d.cin; f.Cmid = b.cmid; f.Ho = b.Ho; f.Wo = b.Wo; f.k = b.d.k; f.s = b.d.s; f.pad_lo = b.pad_lo;
-            if ((rc = launch_mbconv_front(f, n->dtype, s))) return rc;
-            fuse_kernel_name(b.d.cin, b.d.k, b.d.s, n->dtype, b.H, b.W, kn, sizeof(kn));
+            if ((rc = b.wave ? launch_mbconv_wave(f, n->dtype, &se_tiles, s) : b.rows ? launch_mbconv_rows(f, n->dtype, s) : launch_mbconv_front(f, n->dtype, s))) return rc;
+            if (b.wave) wave_kernel_name(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W, kn, sizeof(kn));
+            else if (b.rows) rows_kernel_name(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W, b.Ho, b.Wo, kn, sizeof(kn));
+            else fuse_kernel_name(b.d.cin, b.d.k, b.d.s, n->dtype, b.H, b.W, kn, sizeof(kn));
             if ((rc = mark(kn, i, ((double)Bc * b.H * b.W * b.d.cin + (double)Bc * b.Ho * b.Wo * b.cmid + (double)b.d.cin * b.cmid) * esz_d,
                            2.0 * Bc * b.H * b.W * b.d.cin * b.cmid + 2.0 * Bc * b.Ho * b.Wo * b.cmid * b.d.k * b.d.k))) return rc;
         } else {
@@ -312,11 +321,16 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         if ((rc = mark(kn, i, ((double)Bc * b.H * b.W * b.cmid + (double)Bc * b.Ho * b.Wo * b.cmid) * esz_d + (double)Bc * b.n_tiles * b.cmid * 4,
                        2.0 * Bc * b.Ho * b.Wo * b.cmid * b.d.k * b.d.k))) return rc;
         }
+#ifdef COSY_TUNE
+        if (taps && tune_int("COSY_TAP_D", -1) == i) {       // experiment: probe the depthwise output of block i into tap slot 0
+            if ((rc = launch_taps(Dbuf, Bc, b.Ho * b.Wo, b.cmid, n->dtype, taps, 0, s))) return rc;
+        }
+#endif
         SeArgs se{};
-        se.partial = w.partial; se.n_tiles = b.n_tiles; se.w_red = b.se_wr; se.b_red = b.se_br; se.w_exp = b.se_we; se.b_exp = b.se_be;
+        se.partial = w.partial; se.n_tiles = se_tiles; se.w_red = b.se_wr; se.b_red = b.se_br; se.w_exp = b.se_we; se.b_exp = b.se_be;
         se.gate = w.gate; se.B = Bc; se.C = b.cmid; se.Cse = b.cse; se.HW = b.Ho * b.Wo;
         if ((rc = launch_se(se, s))) return rc;
-        if ((rc = mark("se_kernel", i, (double)Bc * b.n_tiles * b.cmid * 4 + (double)Bc * b.cmid * 4 + 2.0 * b.cse * b.cmid * 4,
+        if ((rc = mark("se_kernel", i, (double)Bc * se_tiles * b.cmid * 4 + (double)Bc * b.cmid * 4 + 2.0 * b.cse * b.cmid * 4,
                        4.0 * Bc * b.cse * b.cmid))) return rc;
         PwArgs a{};
         a.A = Dbuf; a.Wp = b.proj.Wp; a.out = out; a.scale = b.proj.scale; a.bias = b.proj.bias;
@@ -421,18 +435,16 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
     if (!n) { set_error("create: host allocation failed"); return COSY_ENOMEM; }
     n->dtype = dtype; n->H = H; n->W = W; n->maxB = max_batch; n->esz = dtype == COSY_F32 ? 4 : 2;
     n->Hs = out_dim(H, 3, 2); n->Ws = out_dim(W, 3, 2);
-    {   // early-segment chunk (samples); COSY_EARLY_CHUNK overrides, 0 = whole batch
-        const char* ev = getenv("COSY_EARLY_CHUNK");
-        int c = ev ? atoi(ev) : 0;   // measured: chunking is slower (kernels are issue-bound, not HBM-bound)
+    {   // schedule knobs: fixed in the shipping build, env-overridable only under -DCOSY_TUNE (cosy_common.h)
+        const int c = tune_int("COSY_EARLY_CHUNK", 0);   // measured: chunking the early segment is slower (kernels are issue-bound)
         n->chunk = c <= 0 ? max_batch : c;
-        const char* fv = getenv("COSY_FUSE");
-        n->fuse = fv ? atoi(fv) : 1;
+        n->fuse = tune_int("COSY_FUSE", 1);
         // measured per block (256^2, bf16): the tiled kernel wins for blocks 2-5 and 8 and loses for the k=5 stride-1 blocks
         // 6/7 (halo recompute x1.9); blocks 19-25 (8x8 maps) run the whole-image kernel (mbconv_small_kernel)
-        const char* fm = getenv("COSY_FUSE_MASK");
-        n->fuse_mask = fm ? (unsigned)strtoul(fm, nullptr, 0) : 0x3f8013cu;
-        const char* sv = getenv("COSY_STREAMS");
-        n->nstreams = (sv ? atoi(sv) : 1) == 2 && max_batch >= 32 ? 2 : 1;   // measured: 2 streams x half batches is ~10 % slower
+        n->fuse_mask = (unsigned)tune_int("COSY_FUSE_MASK", 0x3f8013c);
+        n->rows_mask = (unsigned)tune_int("COSY_ROWS_MASK", 0x1fc);     // blocks 2-8: the maps that are >= 32 pixels wide
+        n->wave_mask = (unsigned)tune_int("COSY_WAVE_MASK", 0x3fffc);   // blocks 2-17: maps 16..128 pixels wide, stride per shape table
+        n->nstreams = tune_int("COSY_STREAMS", 1) == 2 && max_batch >= 32 ? 2 : 1;   // measured: 2 streams x half batches is ~10 % slower
     }
     hipError_t herr = hipSuccess;
     Bump wb;

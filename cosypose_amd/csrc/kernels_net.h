@@ -59,6 +59,16 @@ struct FuseArgs {
 bool fuse_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W);
 int fuse_num_tiles(int Cin, int Ho, int Wo, int k, int s, int dtype);
 int launch_mbconv_front(const FuseArgs& a, int dtype, hipStream_t s);
+// row-streaming variant for the high-resolution blocks (kernels_mbconv.hip): same arguments, partial has ONE tile per sample
+bool rows_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W, int Ho, int Wo);
+void rows_kernel_name(int Cin, int Cmid, int k, int s, int dtype, int H, int W, int Ho, int Wo, char* buf, size_t n);
+int launch_mbconv_rows(const FuseArgs& a, int dtype, hipStream_t s);
+// wave-autonomous variant (kernels_wave.hip): expanded rows in registers, no LDS ring / barriers; expand weights packed with
+// PwCfg{1,1} (16-channel tiles, natural row order); partial has ONE tile per sample
+bool wave_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W);
+void wave_kernel_name(int Cin, int Cmid, int k, int s, int dtype, int H, int W, char* buf, size_t n);
+int wave_max_tiles();   // upper bound of the row bands (partial-sum tiles per sample) a launch may use
+int launch_mbconv_wave(const FuseArgs& a, int dtype, int* n_tiles_out, hipStream_t s);
 
 struct SeArgs {
     const float* partial;  // (B, n_tiles, C)

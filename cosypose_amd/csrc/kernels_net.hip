@@ -49,7 +49,7 @@ PwCfg pw_choose_cfg(int N) {
 // 61 -> 70 us.
 PwCfg pw_choose_cfg_late(int K, int N, int HW, bool gated) {
     (void)gated;
-    static const int wide = getenv("COSY_PW_WIDE") ? atoi(getenv("COSY_PW_WIDE")) : 1;
+    static const int wide = tune_int("COSY_PW_WIDE", 1);
     if (wide && K >= 96 && HW >= 64 && N > 128 && N <= 160) return PwCfg{5, 2};
     return pw_choose_cfg(N);
 }
@@ -92,7 +92,6 @@ struct PwKArgs {
     int M, K, N, HW, silu, MT, NT, nkb_total, nkb_valid;
     const void* zeros;
     int nsamp, rowgate;   // DMA kernel gate: samples under one m-tile; 1 = gate the activation fragments per row
-    int dbg;              // phase knock-out for timing experiments (COSY_PW_DBG): 1 no epilogue math, 2 no stores, 4 no MFMA, 8 no gate
 };
 
 template <typename T, int NI, int WN>
@@ -344,8 +343,7 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwKArgs a) {
         for (int ni = 0; ni < NI; ++ni) fw[ni] = *(const raw_t*)(st + (NA + wn * NI + ni) * 1024 + lane * 16);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) fa[mi] = *(const raw_t*)(st + (wm * MI + mi) * 1024 + lane * 16);
-        if (GATE && (a.dbg & 8)) {
-        } else if (GATE && a.rowgate) {
+        if (GATE && a.rowgate) {
             // maps whose pixel count is not a multiple of 64 (240x320 input): a wave's rows straddle samples, so the
             // gate multiplies the ACTIVATION fragments, each lane with the gate row of its own pixel's sample
 #pragma unroll
@@ -389,12 +387,10 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwKArgs a) {
                 from_f32(fw[ni], f);
             }
         }
-        if (!(a.dbg & 4)) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], fw[ni], fa[mi]);
-        }
+            for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], fw[ni], fa[mi]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -418,11 +414,10 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwKArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = acc[mi][ni][r] * sc[ni][r] + bi[ni][r];
-                if (a.silu && !(a.dbg & 1)) v = v * sigmoid_t<T>(v);
+                if (a.silu) v = v * sigmoid_t<T>(v);
                 y[ni * 4 + r] = v;
             }
         const size_t o = (size_t)m * N + nl;
-        if (a.dbg & 2) { if (y[0] == 12345.678f) out[o] = (T)y[1]; continue; }
         if (res) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
@@ -450,8 +445,6 @@ static int launch_pw_dma_mi(PwKArgs k, hipStream_t s) {
     constexpr int WM = 4 / WN, NB = MI * WM + NI * WN;
     k.MT = cdiv(k.M, 16 * MI * WM);
     const int grid = cdiv(k.MT, 8) * 8 * k.NT;
-    static const int dbg = getenv("COSY_PW_DBG") ? atoi(getenv("COSY_PW_DBG")) : 0;
-    k.dbg = dbg;
     k.rowgate = GATE && (k.HW % 64 != 0);
     k.nsamp = k.rowgate ? pw_gate_nsamp(16 * MI * WM, k.HW) : 2;
     const size_t lds = (size_t)NS * NB * 1024 + 1024 + (GATE ? (size_t)k.nsamp * k.nkb_total * DT<T>::KB * 4 : 0);
@@ -467,7 +460,7 @@ static int launch_pw_dma_mi(PwKArgs k, hipStream_t s) {
 }
 // MI = 16-row blocks per wave: 4 (64 rows) by default; 2 halves the accumulators (-> more resident workgroups)
 static int pw_mi(const PwKArgs& k) {
-    static const int mi = getenv("COSY_PW_MI") ? atoi(getenv("COSY_PW_MI")) : 4;
+    static const int mi = tune_int("COSY_PW_MI", 4);
     return (mi == 2 && k.nkb_valid > 2 && (!k.gate || k.HW % 64 == 0)) ? 2 : 4;
 }
 template <typename T, int NI, int WN, bool GATE, int NS>
@@ -484,7 +477,7 @@ static int launch_pw_dma_cfg(const PwKArgs& k, int grid, hipStream_t s) {
     // short k-loops (<= 2 k-blocks: the streaming 1x1 convs of the high-resolution blocks) need no deep ring:
     // 2 stages keep the LDS footprint small so that more workgroups are resident per CU
     if (k.nkb_valid <= 2) return launch_pw_dma_ns<T, NI, WN, GATE, 2>(k, grid, s);
-    static const int deep = getenv("COSY_PW_NS") ? atoi(getenv("COSY_PW_NS")) : 3;
+    static const int deep = tune_int("COSY_PW_NS", 3);
     if (deep >= 4 && k.nkb_valid >= 8) return launch_pw_dma_ns<T, NI, WN, GATE, 4>(k, grid, s);
     return launch_pw_dma_ns<T, NI, WN, GATE, 3>(k, grid, s);
 }
@@ -509,7 +502,7 @@ static int launch_pw_t(const PwArgs& a, PwCfg c, int dtype, hipStream_t s) {
     k.MT = cdiv(a.M, pw_bm(c)); k.NT = cdiv(a.N, pw_bn(c));
     k.nkb_total = pw_nkb_total(a.K, dtype); k.nkb_valid = cdiv(a.K, pw_kb(dtype));
     const int grid = cdiv(k.MT, 8) * 8 * k.NT;
-    k.zeros = a.zeros; k.dbg = 0; k.nsamp = 2; k.rowgate = 0;
+    k.zeros = a.zeros; k.nsamp = 2; k.rowgate = 0;
     if (pw_use_dma(a)) return a.gate ? launch_pw_dma<T, true>(k, c, grid, s) : launch_pw_dma<T, false>(k, c, grid, s);
     if (c.NI == 4 && c.WN == 2) hipLaunchKernelGGL((pw_gemm_kernel<T, 4, 2>), dim3(grid), dim3(256), 0, s, k);
     else if (c.NI == 3 && c.WN == 2) hipLaunchKernelGGL((pw_gemm_kernel<T, 3, 2>), dim3(grid), dim3(256), 0, s, k);
@@ -522,7 +515,7 @@ static int launch_pw_t(const PwArgs& a, PwCfg c, int dtype, hipStream_t s) {
 
 static const char* tname(int dtype) { return dtype == COSY_F32 ? "float" : dtype == COSY_BF16 ? "__bf16" : "_Float16"; }
 static bool pw_use_dma(const PwArgs& a) {
-    static const int use_dma = getenv("COSY_PW_DMA") ? atoi(getenv("COSY_PW_DMA")) : 1;
+    static const int use_dma = tune_int("COSY_PW_DMA", 1);
     // gate rows of every sample under a 128-row m-tile sit in LDS: bound them (tiny maps fall back to pw_gemm_kernel)
     return use_dma && a.zeros && (!a.gate || a.HW % 64 == 0 || pw_gate_nsamp(128, a.HW) <= 4);
 }
@@ -530,8 +523,8 @@ static bool pw_use_dma(const PwArgs& a) {
 void pw_kernel_name(const PwArgs& a, PwCfg c, int dtype, char* buf, size_t n) {
     if (pw_use_dma(a)) {
         const int nkb = cdiv(a.K, pw_kb(dtype));
-        static const int deep = getenv("COSY_PW_NS") ? atoi(getenv("COSY_PW_NS")) : 3;
-        static const int mi_env = getenv("COSY_PW_MI") ? atoi(getenv("COSY_PW_MI")) : 4;
+        static const int deep = tune_int("COSY_PW_NS", 3);
+        static const int mi_env = tune_int("COSY_PW_MI", 4);
         const int mi = (mi_env == 2 && nkb > 2 && (!a.gate || a.HW % 64 == 0)) ? 2 : 4;
         snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, %d, %s, %d>", tname(dtype), c.NI, c.WN,
                  nkb <= 2 ? 2 : (deep >= 4 && nkb >= 8 ? 4 : 3), a.gate ? "true" : "false", mi);
@@ -580,7 +573,7 @@ static DwPlan dw_plan(int C, int Ho, int Wo, int k, int s, int esz) {
     p.TH = Ho <= 4 ? 4 : 8;
     p.THin = (p.TH - 1) * s + k; p.TWin = (p.TW - 1) * s + k;
     const int cg = C / 8;
-    static const int lim_kb = getenv("COSY_DW_LDS_KB") ? atoi(getenv("COSY_DW_LDS_KB")) : 40;
+    static const int lim_kb = tune_int("COSY_DW_LDS_KB", 40);
     const size_t lim = esz == 2 ? (size_t)lim_kb * 1024 : 60 * 1024;
     p.CGB = 1;
     for (int d = 1; d <= 16 && d <= cg; ++d) {
@@ -644,7 +637,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwKArgs a) {
             ok[j] = ix >= 0 && ix < a.W;
             goff[j] = ix * a.C + q * (16 / (int)sizeof(T));
         }
-        for (int yy = wave; yy < ((a.dbg & 2) ? 0 : THin); yy += nwaves) {
+        for (int yy = wave; yy < (COSY_DBG(a.dbg & 2) ? 0 : THin); yy += nwaves) {
             const int iy = iy0 + yy;
             const bool yok = iy >= 0 && iy < a.H;
             const T* rowp = in + (size_t)iy * a.W * a.C;
@@ -674,7 +667,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwKArgs a) {
     float sum[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) sum[c] = 0.f;
-    if (tid < stride && !(a.dbg & 1)) {
+    if (tid < stride && !COSY_DBG(a.dbg & 1)) {
         const int cg = tid % CGB;
         float sc[8], bi[8];
         load8(a.scale + c0 + cg * 8, sc);
@@ -742,7 +735,7 @@ static int launch_dw_t(const DwArgs& a, hipStream_t s) {
     k.H = a.H; k.W = a.W; k.C = a.C; k.Ho = a.Ho; k.Wo = a.Wo; k.lo = a.pad_lo;
     k.CGB = p.CGB; k.TH = p.TH; k.TW = p.TW; k.THin = p.THin; k.TWin = p.TWin; k.ntx = p.ntx; k.n_tiles = p.ntx * p.nty;
     k.n_chunks = p.n_chunks; k.n_jobs = k.n_tiles * a.B; k.zeros = a.zeros;
-    static const int dbg = getenv("COSY_DW_DBG") ? atoi(getenv("COSY_DW_DBG")) : 0;   // phase knock-out, timing experiments only
+    static const int dbg = tune_int("COSY_DW_DBG", 0);   // phase knock-out, timing experiments only
     k.dbg = dbg;
     dim3 grid((unsigned)cdiv(k.n_jobs, 8) * 8 * p.n_chunks), block(p.threads);
     if (a.k == 3 && a.s == 1) hipLaunchKernelGGL((dwconv_kernel<T, 3, 1>), grid, block, p.lds, s, k);
@@ -778,7 +771,7 @@ int launch_dwconv(const DwArgs& a, int dtype, hipStream_t s) {
 // of busy cycles for these kernels.
 constexpr int et_pitch(int elem_size, int stride) { (void)stride; return 48 * elem_size + 16; }
 struct FusePlan { int TH, TW, THin, TWin, MB, kbn, threads, ntx, nty, et_f32; size_t lds; };
-static int fuse_et_f32() { static const int v = getenv("COSY_FUSE_ET32") ? atoi(getenv("COSY_FUSE_ET32")) : 1; return v; }
+static int fuse_et_f32() { static const int v = tune_int("COSY_FUSE_ET32", 1); return v; }
 static FusePlan fuse_plan(int Cin, int Ho, int Wo, int k, int s, int esz) {
     FusePlan p;
     const int R = s == 1 ? 4 : 2;
@@ -793,7 +786,7 @@ static FusePlan fuse_plan(int Cin, int Ho, int Wo, int k, int s, int esz) {
     const int cpt = 16 / ees, units = (48 / cpt) * p.TW * (p.TH / R);
     p.threads = ((units < 384 ? units : 384) + 63) / 64 * 64;
     {   // enough waves for the expand phase too: at most 2 sixteen-pixel blocks per wave (COSY_FUSE_MBW, experiments)
-        static const int mbw = getenv("COSY_FUSE_MBW") ? atoi(getenv("COSY_FUSE_MBW")) : 0;
+        static const int mbw = tune_int("COSY_FUSE_MBW", 0);
         if (mbw > 0) { int t = cdiv(p.MB, mbw) * 64; if (t > 384) t = 384; if (t > p.threads) p.threads = t; }
     }
     p.lds = (size_t)p.MB * p.kbn * 1024 + (size_t)p.MB * 16 * et_pitch(ees, s) + (size_t)k * k * 48 * 4 + (size_t)p.threads * 8 * 4;
@@ -885,7 +878,7 @@ __global__ __launch_bounds__(384) void mbconv_front_kernel(FuseKArgs a) {
             float sc[NI * 4], bi[NI * 4];
 #pragma unroll
             for (int q = 0; q < NI; ++q) { load4(a.s0 + n0 + q * 4, sc + q * 4); load4(a.b0 + n0 + q * 4, bi + q * 4); }
-            for (int mb = wave; mb < ((a.dbg & 2) ? 0 : MB); mb += nwaves) {
+            for (int mb = wave; mb < (COSY_DBG(a.dbg & 2) ? 0 : MB); mb += nwaves) {
                 f32x4 acc[NI];
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -917,7 +910,7 @@ __global__ __launch_bounds__(384) void mbconv_front_kernel(FuseKArgs a) {
         float sum[CPT];
 #pragma unroll
         for (int c = 0; c < CPT; ++c) sum[c] = 0.f;
-        if (tid < stride && !(a.dbg & 1)) {
+        if (tid < stride && !COSY_DBG(a.dbg & 1)) {
             const int c0 = ch * CC + cq * CPT;
             float sc[CPT], bi[CPT];
 #pragma unroll
@@ -1003,7 +996,7 @@ static int launch_fuse_t(const FuseArgs& a, hipStream_t s) {
     k.TH = p.TH; k.TW = p.TW; k.THin = p.THin; k.TWin = p.TWin; k.MB = p.MB; k.ntx = p.ntx; k.n_tiles = p.ntx * p.nty;
     k.nkb_total = pw_nkb_total(a.Cin, sizeof(T) == 4 ? COSY_F32 : COSY_BF16);   // k-block geometry depends on the element size only
     k.rcp_tw = (65536u + p.TWin - 1) / p.TWin;
-    static const int dbg = getenv("COSY_FUSE_DBG") ? atoi(getenv("COSY_FUSE_DBG")) : 0;   // phase knock-out, timing experiments only
+    static const int dbg = tune_int("COSY_FUSE_DBG", 0);   // phase knock-out, timing experiments only
     k.dbg = dbg;
     for (int q = 0; q < p.MB * 16; ++q)
         if ((int)(((unsigned)q * k.rcp_tw) >> 16) != q / p.TWin) { set_error("mbconv_front: reciprocal division inexact"); return COSY_EINVAL; }
@@ -1096,7 +1089,7 @@ __global__ __launch_bounds__(512) void mbconv_small_kernel(FuseSKArgs a) {
     const int units = NG * a.Wo * nyq;           // <= threads: every thread owns at most ONE (4-channel, column, R rows) unit
     const int stride = (nthr / NG) * NG;
     const int cq = tid % NG;
-    const bool has_unit = tid < units && !(a.dbg & 1);
+    const bool has_unit = tid < units && !COSY_DBG(a.dbg & 1);
     const int uq = tid / NG, ux = uq % a.Wo, uyq = uq / a.Wo;
     // Global stores count in vmcnt on this ISA and retire in order with the loads: a wait for the NEXT chunk's DMA issued
     // after this chunk's output stores would also wait for the stores' acknowledgements (~2-3 us per chunk, measured).
@@ -1115,7 +1108,7 @@ __global__ __launch_bounds__(512) void mbconv_small_kernel(FuseSKArgs a) {
 #pragma unroll
             for (int mi = 0; mi < MPW; ++mi) {
                 const int mb = wave + mi * nwaves;
-                if (mb < a.MBr && !(a.dbg & 2)) {
+                if (mb < a.MBr && !COSY_DBG(a.dbg & 2)) {
                     f32x4 acc[NI];
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) acc[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1144,7 +1137,7 @@ __global__ __launch_bounds__(512) void mbconv_small_kernel(FuseSKArgs a) {
             }
         }
         __syncthreads();                       // Et complete; the weight buffer is free
-        if (ch + 1 < ch1 && !(a.dbg & 4)) issue_w(ch + 1);     // lands while the depthwise phase computes
+        if (ch + 1 < ch1 && !COSY_DBG(a.dbg & 4)) issue_w(ch + 1);     // lands while the depthwise phase computes
         // ---- depthwise from Et: compute first, store after the DMA wait
         float sum[CPT], yv[R][CPT];
 #pragma unroll
@@ -1219,7 +1212,7 @@ static FuseSmallPlan fuse_small_plan(int Cin, int Cmid, int H, int W, int Ho, in
     const int pj = (4 * 12 + k * k * 12 + 63) / 64;     // parameter block, see the kernel
     p.lds = (size_t)p.THin * p.TWin * et_pitch(4, s) + (size_t)3 * p.kbn * 1024 + (size_t)2 * pj * 1024 + (size_t)p.threads * 4 * 4;
     const int nchunks = Cmid / 48;
-    static const int cpw_target = getenv("COSY_SMALL_CPW") ? atoi(getenv("COSY_SMALL_CPW")) : 15;
+    static const int cpw_target = tune_int("COSY_SMALL_CPW", 15);
     p.cpw = nchunks <= cpw_target ? nchunks : cdiv(nchunks, cdiv(nchunks, cpw_target));   // ~15 chunks per workgroup (measured 3..29)
     p.ncg = cdiv(nchunks, p.cpw);
     // built for the 8x8 (7x10) maps of blocks 19-25: stride 1, one 16-pixel block per wave, 232 or 384 input channels.
@@ -1228,7 +1221,7 @@ static FuseSmallPlan fuse_small_plan(int Cin, int Cmid, int H, int W, int Ho, in
            12 * Wo * cdiv(Ho, 4) <= p.threads;
     return p;
 }
-static int fuse_small_enabled() { static const int v = getenv("COSY_FUSE_SMALL") ? atoi(getenv("COSY_FUSE_SMALL")) : 1; return v; }
+static int fuse_small_enabled() { static const int v = tune_int("COSY_FUSE_SMALL", 1); return v; }
 
 template <typename T, int KS, int KBN>
 static int launch_fuse_small_m(const FuseSmallPlan& p, const FuseSKArgs& k, int B, hipStream_t s) {
@@ -1251,7 +1244,7 @@ static int launch_fuse_small_t(const FuseArgs& a, hipStream_t s) {
     k.zeros = a.zeros; k.H = a.H; k.W = a.W; k.NP = a.H * a.W; k.Cin = a.Cin; k.Cmid = a.Cmid; k.Ho = a.Ho; k.Wo = a.Wo; k.lo = a.pad_lo;
     k.THin = p.THin; k.TWin = p.TWin; k.nkb_total = pw_nkb_total(a.Cin, COSY_BF16); k.MBr = p.MBr; k.ncg = p.ncg; k.cpw = p.cpw;
     k.rcp_w = (65536u + a.W - 1) / a.W;
-    static const int dbg = getenv("COSY_SMALL_DBG") ? atoi(getenv("COSY_SMALL_DBG")) : 0;   // timing experiments only
+    static const int dbg = tune_int("COSY_SMALL_DBG", 0);   // timing experiments only
     k.dbg = dbg;
     for (int q = 0; q < p.MBr * 16; ++q)
         if ((int)(((unsigned)q * k.rcp_w) >> 16) != q / a.W) { set_error("mbconv_small: reciprocal division inexact"); return COSY_EINVAL; }

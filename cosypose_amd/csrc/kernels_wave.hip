@@ -1,0 +1,389 @@
+// Wave-autonomous fused MBConv front (2-byte storage types):
+//     expand 1x1 (MFMA) -> BN -> SiLU -> depthwise kxk -> BN -> SiLU -> D, squeeze sums
+// with the expanded rows held in REGISTERS -- no LDS ring, no workgroup barrier.
+// Reference: MBConvBlock.forward, cosypose/models/efficientnet.py:71-90.
+//
+// Why.  VALU micro-benchmark on MI355X (profiles/exp/valu_bench.hip): plain fp32 op 3.1, v_pk_fma_f32 5.9 (no gain),
+// v_exp_f32 / v_rcp_f32 8.7 cycles per wave instruction -> BN + SiLU costs ~32 cycles per 64 elements and the fused fronts
+// are VALU-bound; the LDS-ring kernels (mbconv_front / mbconv_rows) reach only ~35 % of that bound because every
+// workgroup alternates barrier-separated expand / depthwise phases at 2-3 waves per SIMD.  Here every wave is independent:
+//   * a wave owns (sample, 16*NI expanded channels) and walks down the rows of the whole map;
+//   * pixel mapping of the MFMA B operand: lane (p = lane & 15) owns the PPL CONSECUTIVE pixels x = p*PPL .. p*PPL+PPL-1
+//     of a row (one 16-pixel fragment per q = x - p*PPL), so after the expansion a lane holds 4 channels (kg = lane >> 4)
+//     of PPL neighbouring pixels: horizontal taps are plain FMAs on the lane's own registers, only the run ends come
+//     from the neighbouring lane -- one DPP row_shr / row_shl move per halo pixel (bound_ctrl:0 yields the zero padding
+//     at the image border for free);
+//   * BN parameters and depthwise taps sit in a wave-private LDS block (broadcast ds_read_b128, 4 distinct addresses);
+//   * depthwise accumulation is INPUT-stationary: an expanded row lives in registers only while it is scattered into the
+//     ceil(KS/S) output rows it feeds (accumulators of the rows in flight), so no ring of expanded rows is kept; the row
+//     loop is unrolled S*ceil(KS/S) times so that every accumulator slot is a compile-time constant;
+//   * the block input is read as MFMA fragments straight from global memory one row ahead; per row the global memory
+//     operations are ordered [previous output row's stores] -> [next input row's loads] (vmcnt retires in order and the
+//     compiler waits with vmcnt(0): see mbconv_rows_kernel), so a wait never sees a store younger than one row;
+//   * squeeze sums: per-lane registers over the whole image, one DPP tree per 16-lane row at the end (fixed order).
+// The 16*NI-channel chunks of one sample re-read the block input (x Cmid/16/NI through L2; it is the small tensor).
+#include "net_device.h"
+#include <type_traits>
+#include <utility>
+
+namespace cosy {
+
+struct WaveKArgs {
+    const void* X; const void* Wp; const float* s0; const float* b0; const float* dww; const float* s1; const float* b1;
+    void* D; float* partial; const void* zeros;
+    int B, H, W, Cin, Cmid, Ho, Wo, nkb_total, nchunks, rsplit, rows_per, dbg;   // rsplit row bands per (sample, chunk), rows_per output rows each
+};
+
+template <int CTRL> __device__ __forceinline__ float dpp_mov0(float v) {   // lanes without a source read 0 (bound_ctrl:0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int N> __device__ __forceinline__ float row_shr0(float v) { return dpp_mov0<0x110 + N>(v); }   // lane i <- lane i-N of its 16-lane row
+template <int N> __device__ __forceinline__ float row_shl0(float v) { return dpp_mov0<0x100 + N>(v); }   // lane i <- lane i+N
+
+// SiLU of four values as ONE hand-scheduled block: y = x / (1 + 2^-(x * log2 e)); SCALED: x arrives pre-multiplied by log2(e)
+// and y = x / (1 + 2^-x) (= log2(e) * silu).  The four dependency chains are interleaved so that every transcendental
+// result is consumed three instructions after it was issued.  Hand-written because hipcc's own schedule of the same
+// arithmetic was observed to be NOT run-to-run deterministic under load on gfx950 (blocks 6/7 variant, 256 crops: a few
+// outputs per launch one bf16 ulp off, gone with any change of the schedule or with wait states behind v_exp / v_rcp --
+// the signature of a transcendental result read before it has landed); inside an asm block nothing is re-scheduled.
+template <bool SCALED> __device__ __forceinline__ void silu4(float* v) {
+    float t0, t1, t2, t3;
+    if constexpr (SCALED) {
+        asm volatile(
+            "v_exp_f32 %4, -%0\n v_exp_f32 %5, -%1\n v_exp_f32 %6, -%2\n v_exp_f32 %7, -%3\n"
+            "v_add_f32 %4, 1.0, %4\n v_add_f32 %5, 1.0, %5\n v_add_f32 %6, 1.0, %6\n v_add_f32 %7, 1.0, %7\n"
+            "v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
+            "v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %5\n v_mul_f32 %2, %2, %6\n v_mul_f32 %3, %3, %7\n s_nop 0"
+            : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3));
+    } else {
+        asm volatile(
+            "v_mul_f32 %4, 0xbfb8aa3b, %0\n v_mul_f32 %5, 0xbfb8aa3b, %1\n v_mul_f32 %6, 0xbfb8aa3b, %2\n v_mul_f32 %7, 0xbfb8aa3b, %3\n"
+            "v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n"
+            "v_add_f32 %4, 1.0, %4\n v_add_f32 %5, 1.0, %5\n v_add_f32 %6, 1.0, %6\n v_add_f32 %7, 1.0, %7\n"
+            "v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
+            "v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %5\n v_mul_f32 %2, %2, %6\n v_mul_f32 %3, %3, %7\n s_nop 0"
+            : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3));
+    }
+}
+
+template <typename F, int... Us>
+__device__ __forceinline__ void unroll_seq(F&& f, std::integer_sequence<int, Us...>) { (f(std::integral_constant<int, Us>{}), ...); }
+
+constexpr int wave_lcm(int a, int b) { int x = a; while (x % b) x += a; return x; }
+
+template <typename T, int KS, int S, int KBN, int PPL, int NI, bool FULLW, int MINW>
+__global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
+    using raw_t = typename DT<T>::raw_t;
+    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
+    constexpr int NCH = 4 * NI;                               // channels per lane
+    constexpr int LO = S == 1 ? (KS - 1) / 2 : (KS - 2) / 2;  // static "same" padding, both axes
+    constexpr int HI = KS - S - LO;                           // right halo pixels a lane needs
+    constexpr int TO = PPL / S;                               // output pixels per lane and row
+    constexpr int RP = LO + PPL + HI;                         // pixels of an expanded row a lane sees: [left halo | own | right halo]
+    constexpr int NOPEN = (KS + S - 1) / S;                   // output rows that are accumulating at the same time
+    constexpr int U = S * NOPEN;                              // input rows per unrolled super-iteration
+    constexpr int PF = (4 + KS * KS) * 16 * NI;               // floats of the parameter block
+    static_assert(PPL % S == 0, "a lane's pixel run must hold whole output pixels");
+    typedef T out_t __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float smem_w[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = lane & 15, kg = lane >> 4;
+    // XCD-aware job order: the chunks of one sample run on one XCD (block id % 8), 4 jobs (waves) per block
+    const int id = blockIdx.x, xcd = id & 7, sidx = (id >> 3) * 4 + wave;
+    // a job = (sample, chunk, row band); the jobs of one sample stay on one XCD
+    const int jps = a.nchunks * a.rsplit;
+    const int b = (sidx / jps) * 8 + xcd, jrem = sidx % jps, ch = jrem / a.rsplit, band = jrem - ch * a.rsplit;
+    const bool active = b < a.B;
+    const int c0 = ch * 16 * NI;
+
+    // ---- parameters of the chunk -> wave-private LDS block [s0][b0][s1][b1][taps], 16*NI floats each
+    float* P = smem_w + wave * PF;
+    if (active) {
+        for (int i = lane; i < PF / 4; i += 64) {
+            const int arr = i / (4 * NI), q4 = i - arr * (4 * NI);
+            const float* src = arr == 0 ? a.s0 : arr == 1 ? a.b0 : arr == 2 ? a.s1 : arr == 3 ? a.b1 : a.dww + (size_t)(arr - 4) * a.Cmid;
+            // The expansion's SiLU runs on t = log2(e) * v: t / (1 + 2^-t) = log2(e) * silu(v) -- one multiply fewer per expanded
+            // element (v_exp_f32 takes the negation as a source modifier).  log2(e) is folded into BN0 here and its inverse into
+            // the depthwise taps, which are the only consumers of the expanded values.
+            const float f = arr < 2 ? 1.4426950408889634f : arr >= 4 ? 0.6931471805599453f : 1.f;
+            *(f32x4*)(P + arr * 16 * NI + q4 * 4) = *(const f32x4*)(src + c0 + q4 * 4) * f;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+
+    const T* __restrict__ X = (const T*)a.X + (size_t)b * a.H * a.W * a.Cin;
+    raw_t wf[NI][KBN];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int kb = 0; kb < KBN; ++kb)
+            wf[ni][kb] = *(const raw_t*)((const T*)a.Wp + ((size_t)(ch * NI + ni) * a.nkb_total + kb) * 64 * EPL + lane * EPL);
+    const float* Pl = P + kg * 4;            // this lane's channel quad inside every 16-float group
+    const float* taps = Pl + 4 * 16 * NI;
+
+    raw_t xc[PPL][KBN];
+    auto load_row = [&](int iy) {            // B fragments of input row iy: fragment q holds the lanes' pixels p*PPL + q
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+            const int x = p * PPL + q;
+#pragma unroll
+            for (int kb = 0; kb < KBN; ++kb) {
+                const int k = kb * KB + kg * EPL;
+                const bool ok = iy < a.H && x < a.W && k < a.Cin;
+                xc[q][kb] = *(const raw_t*)(ok ? (const void*)(X + ((size_t)iy * a.W + x) * a.Cin + k) : a.zeros);
+            }
+        }
+    };
+    // this job's output rows [oy_a, oy_b) and the input rows they need (rows above a band are recomputed, KS-S of them)
+    const int oy_a = band * a.rows_per, oy_b = min(a.Ho, oy_a + a.rows_per);
+    const int iy_first = max(0, oy_a * S - LO), iy_last = (oy_b - 1) * S - LO + KS - 1;
+    load_row(iy_first);
+
+    float acc[NOPEN][TO][NCH];               // output rows in flight (input-stationary accumulation)
+#pragma unroll
+    for (int s = 0; s < NOPEN; ++s)
+#pragma unroll
+        for (int t = 0; t < TO; ++t)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) acc[s][t][c] = 0.f;
+    float sum[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) sum[c] = 0.f;
+    out_t yv[TO][NI];                        // finished output row waiting for its store (issued one row later)
+    int oy_pending = -1;
+    T* __restrict__ Dout = (T*)a.D + (size_t)b * a.Ho * a.Wo * a.Cmid + c0 + kg * 4;
+    auto flush = [&]() {                     // store the pending output row
+        if (oy_pending >= 0) {
+#pragma unroll
+            for (int t = 0; t < TO; ++t) {
+                const int ox = p * TO + t;
+                if (FULLW || ox < a.Wo) {
+                    T* o = Dout + ((size_t)oy_pending * a.Wo + ox) * a.Cmid;
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) *(out_t*)(o + ni * 16) = yv[t][ni];
+                }
+            }
+        }
+    };
+
+    for (int base = (iy_first / U) * U; base <= iy_last; base += U) {
+        unroll_seq([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            const int iy = base + u;
+            if (iy < iy_first || iy > iy_last) return;
+            // ---- A. expanded row iy (transient registers); its global loads were issued one row ago
+            float Er[RP][NCH];
+            if (iy < a.H) {
+                float sc0[NCH], bi0[NCH];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) { load4(Pl + 0 * 16 * NI + ni * 16, sc0 + ni * 4); load4(Pl + 1 * 16 * NI + ni * 16, bi0 + ni * 4); }
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) {
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        f32x4 m = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kb = 0; kb < KBN; ++kb) mma(m, wf[ni][kb], xc[q][kb]);
+                        float y4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y4[e] = m[e] * sc0[ni * 4 + e] + bi0[ni * 4 + e];     // = log2(e) * BN0(expand)
+                        silu4<true>(y4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if constexpr (!FULLW) { if (p * PPL + q >= a.W) y4[e] = 0.f; }   // pixels beyond the row end pad their neighbours
+                            Er[LO + q][ni * 4 + e] = y4[e];
+                        }
+                    }
+                }
+                // halo pixels of the lane's run come from the neighbouring lanes of its 16-lane row (0 at the image border)
+#pragma unroll
+                for (int m = 0; m < LO; ++m) {            // ring pixel m = local pixel m - LO (< 0)
+                    const int d = m - LO;
+                    const int off = (d - (PPL - 1)) / PPL;   // floor(d / PPL) for d < 0
+                    const int q = d - off * PPL;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const float src = Er[LO + q][c];
+                        Er[m][c] = off == -1 ? row_shr0<1>(src) : off == -2 ? row_shr0<2>(src) : row_shr0<3>(src);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < HI; ++m) {            // ring pixel LO + PPL + m = local pixel PPL + m
+                    const int off = (PPL + m) / PPL, q = (PPL + m) % PPL;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const float src = Er[LO + q][c];
+                        Er[LO + PPL + m][c] = off == 1 ? row_shl0<1>(src) : off == 2 ? row_shl0<2>(src) : row_shl0<3>(src);
+                    }
+                }
+            }
+            // ---- B. scatter the row into the output rows it feeds: input row iy is tap row ky of output row (iy + LO - ky) / S
+            bool done = false;
+            int oy_done = -1;
+            out_t ynew[TO][NI];
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                constexpr int KSc = KS;
+                const int num = u + LO - ky;                          // compile-time after unrolling
+                if (((num % S) + S) % S != 0) continue;
+                const int os = (((num - (((num % S) + S) % S)) / S) % NOPEN + NOPEN) % NOPEN;   // accumulator slot of that output row
+                const int oy = (iy + LO - ky) / S;
+                if (iy + LO - ky < 0 || oy < oy_a || oy >= oy_b) continue;   // wave-uniform
+                if (iy < a.H) {
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) {
+                        float w[NCH];
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) load4(taps + (ky * KSc + kx) * 16 * NI + ni * 16, w + ni * 4);
+#pragma unroll
+                        for (int t = 0; t < TO; ++t)
+#pragma unroll
+                            for (int c = 0; c < NCH; ++c) acc[os][t][c] += w[c] * Er[t * S + kx][c];
+                    }
+                }
+                if (ky == KS - 1) {                                   // last tap row: the output row is complete
+                    float sc1[NCH], bi1[NCH];
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) { load4(Pl + 2 * 16 * NI + ni * 16, sc1 + ni * 4); load4(Pl + 3 * 16 * NI + ni * 16, bi1 + ni * 4); }
+#pragma unroll
+                    for (int t = 0; t < TO; ++t) {
+                        const bool okx = FULLW || p * TO + t < a.Wo;
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            float y4[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y4[e] = acc[os][t][ni * 4 + e] * sc1[ni * 4 + e] + bi1[ni * 4 + e];
+                            silu4<false>(y4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int c = ni * 4 + e;
+                                if constexpr (FULLW) sum[c] += y4[e]; else sum[c] += okx ? y4[e] : 0.f;
+                                if constexpr (__is_same(T, f16_t)) ynew[t][ni][e] = to_f16_sat(y4[e]);
+                                else ynew[t][ni][e] = (T)y4[e];
+                                acc[os][t][c] = 0.f;
+                            }
+                        }
+                    }
+                    done = true; oy_done = oy;
+                }
+            }
+            // ---- C. global memory, in this order: the PREVIOUS output row's stores, then the next input row's loads.  The wait
+            // for those loads (next row's MFMA) is a vmcnt(0) that also covers these stores: both are one row old by then.
+            flush();
+            oy_pending = -1;
+            if (done) {
+#pragma unroll
+                for (int t = 0; t < TO; ++t)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) yv[t][ni] = ynew[t][ni];
+                oy_pending = oy_done;
+            }
+            if (iy + 1 <= iy_last) load_row(iy + 1);
+        }, std::make_integer_sequence<int, U>{});
+    }
+    flush();
+    // ---- squeeze sums: fixed-order tree over the 16 lanes of a row (one channel quad per row), lane 15 writes
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        float v = sum[c];
+        v += row_shr0<1>(v); v += row_shr0<2>(v); v += row_shr0<4>(v); v += row_shr0<8>(v);
+        sum[c] = v;
+    }
+    if (p == 15) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+            *(f32x4*)(a.partial + ((size_t)b * a.rsplit + band) * a.Cmid + c0 + ni * 16 + kg * 4) = f32x4{sum[ni * 4], sum[ni * 4 + 1], sum[ni * 4 + 2], sum[ni * 4 + 3]};
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+// built shapes (KS, S, KBN, PPL, NI, row is exactly 16*PPL pixels wide, minimum waves per SIMD the register allocation
+// must allow, row bands per (sample, chunk)): the MBConv blocks of EfficientNet-B3 at 256x256 and 240x320 inputs whose maps
+// are 16..128 pixels wide.  Row bands: a job = (sample, chunk, band of output rows); bands only balance the number of jobs
+// against the resident wave slots of the chip (e.g. block 2 at 256 crops: 2304 jobs on 2048 slots = a second round that is
+// 12 % full; 4 bands: 4.5 rounds of quarter-length jobs) at the price of KS-S recomputed rows per band.  The band count is
+// a property of the SHAPE, never of the batch size: the squeeze sums are reduced per band, so results stay bit-identical
+// across batch sizes.
+#define COSY_WAVE_VARIANTS(X)                                                                                      \
+    X(3, 2, 1, 8, 1, true, 2, 4) X(3, 1, 1, 4, 1, true, 2, 2) X(5, 2, 1, 4, 1, true, 3, 1) X(5, 1, 2, 2, 1, true, 2, 2)      \
+    X(3, 2, 2, 2, 1, true, 4, 1) X(3, 1, 3, 1, 1, true, 4, 1) X(5, 1, 3, 1, 1, true, 4, 1) X(5, 1, 5, 1, 1, true, 3, 1)      \
+    X(3, 1, 1, 5, 1, true, 2, 2) X(5, 2, 1, 6, 1, false, 2, 1) X(5, 1, 2, 3, 1, false, 2, 2) X(3, 2, 2, 4, 1, false, 3, 1)   \
+    X(3, 1, 3, 2, 1, false, 3, 1) X(5, 1, 3, 2, 1, false, 2, 1) X(5, 1, 5, 2, 1, false, 2, 1)
+enum { WAVE_MAX_RSPLIT = 4 };
+
+struct WavePlan { int kbn, ppl, ni; bool fullw, ok; };
+static WavePlan wave_plan(int Cin, int Cmid, int H, int W, int k, int s) {
+    WavePlan p{};
+    p.kbn = cdiv(Cin, 32);
+    p.ppl = cdiv(W, 16);
+    if (p.ppl % s) ++p.ppl;
+    p.ni = 1;
+    p.fullw = W == 16 * p.ppl;
+    p.ok = false;
+    if (Cmid % (16 * p.ni) || H < k) return p;
+#define X(KS, S, KBN, PPL, NI, FW, MW, RSP) if (k == KS && s == S && p.kbn == KBN && p.ppl == PPL && p.ni == NI && p.fullw == FW) p.ok = true;
+    COSY_WAVE_VARIANTS(X)
+#undef X
+    return p;
+}
+bool wave_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W) {
+    if (dtype == COSY_F32 || H <= 0) return false;
+    return wave_plan(Cin, Cmid, H, W, k, s).ok;
+}
+int wave_max_tiles() { return WAVE_MAX_RSPLIT; }
+void wave_kernel_name(int Cin, int Cmid, int k, int s, int dtype, int H, int W, char* buf, size_t n) {
+    const WavePlan p = wave_plan(Cin, Cmid, H, W, k, s);
+    int mw = 0;
+#define X(KS, S, KBN, PPL, NI, FW, MW, RSP) if (k == KS && s == S && p.kbn == KBN && p.ppl == PPL && p.ni == NI && p.fullw == FW) mw = MW;
+    COSY_WAVE_VARIANTS(X)
+#undef X
+    snprintf(buf, n, "mbconv_wave_kernel<%s, %d, %d, %d, %d, %d, %s, %d>", dtype == COSY_BF16 ? "__bf16" : "_Float16", k, s, p.kbn, p.ppl,
+             p.ni, p.fullw ? "true" : "false", mw);
+}
+
+template <typename T, int KS, int S, int KBN, int PPL, int NI, bool FW, int MW, int RSP>
+static int launch_wave_k(WaveKArgs k, int* n_tiles_out, hipStream_t s) {
+    const size_t lds = (size_t)4 * (4 + KS * KS) * 16 * NI * sizeof(float);
+    k.dbg = tune_int("COSY_WAVE_DBG", 0);
+    k.rsplit = tune_int("COSY_WAVE_RSPLIT", RSP);
+    if (k.rsplit < 1) k.rsplit = 1;
+    if (k.rsplit > WAVE_MAX_RSPLIT) k.rsplit = WAVE_MAX_RSPLIT;
+    while (k.rsplit > 1 && cdiv(k.Ho, k.rsplit) < 8) --k.rsplit;
+    k.rows_per = cdiv(k.Ho, k.rsplit);
+    *n_tiles_out = k.rsplit;
+    const long jobs_per_xcd = (long)cdiv(k.B, 8) * k.nchunks * k.rsplit;
+    const dim3 grid((unsigned)(cdiv(jobs_per_xcd, 4) * 8)), block(256);
+    hipLaunchKernelGGL((mbconv_wave_kernel<T, KS, S, KBN, PPL, NI, FW, MW>), grid, block, lds, s, k);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+template <typename T>
+static int launch_wave_t(const FuseArgs& a, int* n_tiles_out, hipStream_t s) {
+    const WavePlan p = wave_plan(a.Cin, a.Cmid, a.H, a.W, a.k, a.s);
+    COSY_REQUIRE(p.ok, "mbconv_wave: unsupported shape Cin=%d Cmid=%d %dx%d k=%d s=%d", a.Cin, a.Cmid, a.H, a.W, a.k, a.s);
+    WaveKArgs k;
+    k.X = a.X; k.Wp = a.Wp; k.s0 = a.s0; k.b0 = a.b0; k.dww = a.dww; k.s1 = a.s1; k.b1 = a.b1; k.D = a.D; k.partial = a.partial;
+    k.zeros = a.zeros; k.B = a.B; k.H = a.H; k.W = a.W; k.Cin = a.Cin; k.Cmid = a.Cmid; k.Ho = a.Ho; k.Wo = a.Wo;
+    k.nkb_total = (p.kbn + 1) & ~1; k.nchunks = a.Cmid / (16 * p.ni); k.rsplit = 1; k.rows_per = a.Ho;
+    const int ks_ = a.k, st_ = a.s, kbn_ = p.kbn, ppl_ = p.ppl, ni_ = p.ni;
+    const bool fw_ = p.fullw;
+#define X(KS, S, KBN, PPL, NI, FW, MW, RSP) \
+    if (ks_ == KS && st_ == S && kbn_ == KBN && ppl_ == PPL && ni_ == NI && fw_ == FW) return launch_wave_k<T, KS, S, KBN, PPL, NI, FW, MW, RSP>(k, n_tiles_out, s);
+    COSY_WAVE_VARIANTS(X)
+#undef X
+    set_error("mbconv_wave: variant not built");
+    return COSY_EINVAL;
+}
+// n_tiles_out: number of partial-sum tiles per sample this launch wrote (row bands), for the squeeze-excite kernel
+int launch_mbconv_wave(const FuseArgs& a, int dtype, int* n_tiles_out, hipStream_t s) {
+    *n_tiles_out = 1;
+    if (a.B == 0) return COSY_OK;
+    COSY_REQUIRE(dtype != COSY_F32, "mbconv_wave: 2-byte storage types only");
+    if (dtype == COSY_BF16) return launch_wave_t<bf16_t>(a, n_tiles_out, s);
+    return launch_wave_t<f16_t>(a, n_tiles_out, s);
+}
+
+}  // namespace cosy
