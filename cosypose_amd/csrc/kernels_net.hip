@@ -48,7 +48,13 @@ PwCfg pw_choose_cfg(int N) {
 // us (82 us with a 2-stage ring that restores two workgroups per CU), 256 x 128 (NI8,WN1) 66 -> 107 us, 2 x 192 for N = 384
 // 61 -> 70 us.
 PwCfg pw_choose_cfg_late(int K, int N, int HW, bool gated) {
-    (void)gated;
+    // 8-wave tiles (128 x 128 as 2 x 4 waves of 64 x 32): each wave issues half the LDS-DMAs, gate multiplies and MFMAs of a
+    // k-step and two waves share a SIMD, so one wave's gate arithmetic / fragment reads overlap the other's MFMAs (the
+    // 4-wave tile runs them back to back).  Measured at 256 crops: N = 232 project 44 -> 36 us, N = 816 expand 55 -> 44 us,
+    // head (N = 1536) 43 -> 38 us, N = 384 unchanged; N = 96 unchanged and N = 136 slower (63 us vs 45 us with the one-pass
+    // 160-column tile) -> only for N >= 192.
+    static const int pw8 = tune_int("COSY_PW8", 1);
+    if (pw8 && K >= 128 && N >= 192 && (!gated || HW % 64 == 0)) return PwCfg{2, 4, 8};
     static const int wide = tune_int("COSY_PW_WIDE", 1);
     if (wide && K >= 96 && HW >= 64 && N > 128 && N <= 160) return PwCfg{5, 2};
     return pw_choose_cfg(N);
@@ -263,14 +269,14 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwKArgs a) {
 // (W[n,k]*g[b,k]) at fragment-read time from a gate row staged in LDS when the 64 pixel rows of a wave belong to one
 // sample (HW % 64 == 0); otherwise (240x320 input) each lane scales its ACTIVATION fragments with its own row's gate.
 // ------------------------------------------------------------------------------------------
-template <typename T, int NI, int WN, int NS, bool GATE, int MI>
-__global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwKArgs a) {
+template <typename T, int NI, int WN, int NS, bool GATE, int MI, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void pw_gemm_dma_kernel(PwKArgs a) {
     using D = DT<T>;
     using raw_t = typename D::raw_t;
     constexpr int EPL = D::EPL, KB = D::KB;
-    constexpr int WM = 4 / WN, BM = 16 * MI * WM, BN = 16 * NI * WN;
+    constexpr int WM = NWV / WN, BM = 16 * MI * WM, BN = 16 * NI * WN;
     constexpr int NA = BM / 16, NW = NI * WN, NB = NA + NW;
-    constexpr int L = (NB + 3) / 4;   // DMA instructions per wave per k-block
+    constexpr int L = (NB + NWV - 1) / NWV;   // DMA instructions per wave per k-block
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* dummy = lds + NS * NB * 1024;
     float* gl = (float*)(dummy + 1024);   // GATE: [nsamp][Kpad] gate rows of the samples under this m-tile
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwKArgs a) {
     int gsel = 0, grow[MI];
     if constexpr (GATE) {
         const int b_first = m0 / a.HW;
-        for (int i = tid; i < a.nsamp * Kpad; i += 256) {
+        for (int i = tid; i < a.nsamp * Kpad; i += NWV * 64) {
             const int sidx = i / Kpad, k = i - sidx * Kpad;
             const long mrow = (long)(b_first + sidx) * a.HW;
             const float g = (k < K && mrow < M) ? a.gate[(size_t)(b_first + sidx) * K + k] : 0.f;
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwKArgs a) {
         char* st = lds + (kb % NS) * NB * 1024;
 #pragma unroll
         for (int i = 0; i < L; ++i) {
-            const int blk = i * 4 + wave;
+            const int blk = i * NWV + wave;
             const void* src = a.zeros;
             char* dst = dummy;
             if (kb < a.nkb_valid && blk < NB) {
@@ -440,9 +446,9 @@ __global__ __launch_bounds__(256) void pw_gemm_dma_kernel(PwKArgs a) {
     }
 }
 
-template <typename T, int NI, int WN, bool GATE, int NS, int MI>
+template <typename T, int NI, int WN, bool GATE, int NS, int MI, int NWV = 4>
 static int launch_pw_dma_mi(PwKArgs k, hipStream_t s) {
-    constexpr int WM = 4 / WN, NB = MI * WM + NI * WN;
+    constexpr int WM = NWV / WN, NB = MI * WM + NI * WN;
     k.MT = cdiv(k.M, 16 * MI * WM);
     const int grid = cdiv(k.MT, 8) * 8 * k.NT;
     k.rowgate = GATE && (k.HW % 64 != 0);
@@ -450,11 +456,11 @@ static int launch_pw_dma_mi(PwKArgs k, hipStream_t s) {
     const size_t lds = (size_t)NS * NB * 1024 + 1024 + (GATE ? (size_t)k.nsamp * k.nkb_total * DT<T>::KB * 4 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        COSY_CHECK_HIP(hipFuncSetAttribute((const void*)pw_gemm_dma_kernel<T, NI, WN, NS, GATE, MI>,
+        COSY_CHECK_HIP(hipFuncSetAttribute((const void*)pw_gemm_dma_kernel<T, NI, WN, NS, GATE, MI, NWV>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((pw_gemm_dma_kernel<T, NI, WN, NS, GATE, MI>), dim3(grid), dim3(256), lds, s, k);
+    hipLaunchKernelGGL((pw_gemm_dma_kernel<T, NI, WN, NS, GATE, MI, NWV>), dim3(grid), dim3(NWV * 64), lds, s, k);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }
@@ -483,6 +489,16 @@ static int launch_pw_dma_cfg(const PwKArgs& k, int grid, hipStream_t s) {
 }
 template <typename T, bool GATE>
 static int launch_pw_dma(const PwKArgs& k, PwCfg c, int grid, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {   // 8-wave tiles of the late layers: 2 waves per SIMD take turns on the matrix pipe
+        if (c.WV == 8) {
+            const bool wave_gate = !GATE || (k.HW % 64 == 0);    // weight-side gate needs a wave's 64 rows inside one sample
+            if (k.nkb_valid > 2 && wave_gate) {
+                if (c.NI == 2 && c.WN == 4) return launch_pw_dma_mi<T, 2, 4, GATE, 3, 4, 8>(k, s);
+            }
+            set_error("pw_gemm_dma: 8-wave tile NI=%d WN=%d not built for this layer", c.NI, c.WN);
+            return COSY_EINVAL;
+        }
+    }
     if (c.NI == 4 && c.WN == 2) return launch_pw_dma_cfg<T, 4, 2, GATE>(k, grid, s);
     if (c.NI == 3 && c.WN == 2) return launch_pw_dma_cfg<T, 3, 2, GATE>(k, grid, s);
     if (c.NI == 3 && c.WN == 1) return launch_pw_dma_cfg<T, 3, 1, GATE>(k, grid, s);
@@ -526,7 +542,8 @@ void pw_kernel_name(const PwArgs& a, PwCfg c, int dtype, char* buf, size_t n) {
         static const int deep = tune_int("COSY_PW_NS", 3);
         static const int mi_env = tune_int("COSY_PW_MI", 4);
         const int mi = (mi_env == 2 && nkb > 2 && (!a.gate || a.HW % 64 == 0)) ? 2 : 4;
-        snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, %d, %s, %d>", tname(dtype), c.NI, c.WN,
+        if (c.WV == 8) snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, 3, %s, 4, 8>", tname(dtype), c.NI, c.WN, a.gate ? "true" : "false");
+        else snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, %d, %s, %d>", tname(dtype), c.NI, c.WN,
                  nkb <= 2 ? 2 : (deep >= 4 && nkb >= 8 ? 4 : 3), a.gate ? "true" : "false", mi);
     } else {
         snprintf(buf, n, "pw_gemm_kernel<%s, %d, %d>", tname(dtype), c.NI, c.WN);

@@ -1,12 +1,5 @@
-export COSY_TUNE_LIB=1
-python profiles/exp/det.py "COSY_WAVE_MASK=0x3fffc" 2>&1 | grep -v amdgpu | cut -c1-260
-python profiles/ab_check.py "COSY_ROWS_MASK=0 COSY_WAVE_MASK=0" "COSY_WAVE_MASK=0x3fffc" 2>&1 | grep -v amdgpu.ids | grep "vs fp32"
-run() { # tag env...
-  tag=$1; shift
-  env "$@" python bench.py --steps 4 --warmup 1 --no-cpu-baseline --layers > gpurun_out/rb_$tag.json 2> gpurun_out/rb_$tag.txt
-  echo "== $tag: $(python -c "import json;print(json.load(open('gpurun_out/rb_$tag.json'))['value'])")"
-  grep -E "^ *([2-9]|1[0-8]) (mbconv)" gpurun_out/rb_$tag.txt | cut -c1-120
-}
-run wave COSY_WAVE_MASK=0x3fffc
-unset COSY_TUNE_LIB
-python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python bench.py --steps 6 --warmup 2 --no-cpu-baseline --layers > gpurun_out/rb_ship.json 2> gpurun_out/rb_ship.txt
+python -c "import json;d=json.load(open('gpurun_out/rb_ship.json'));print(d['value'], d['ms_per_step'], d['roofline'])"
+python bench.py --steps 6 --warmup 2 --no-cpu-baseline --dtype fp16 > gpurun_out/rb_ship_fp16.json 2>/dev/null; python -c "import json;d=json.load(open('gpurun_out/rb_ship_fp16.json'));print('fp16', d['value'])"
+python bench.py --steps 6 --warmup 2 --no-cpu-baseline --crop 240x320 > gpurun_out/rb_ship_240.json 2>/dev/null; python -c "import json;d=json.load(open('gpurun_out/rb_ship_240.json'));print('240x320', d['value'])"
