@@ -402,8 +402,27 @@ class FlatAdam:
                 p.grad = self.grad[off:off + p.numel()].view_as(p.data)
             off += p.numel()
 
+    def _collect_stray_gradients(self):
+        """`model.zero_grad()` / a torch optimizer's `zero_grad(set_to_none=True)` detach p.grad from the flat buffer: the
+        next backward then allocates fresh .grad tensors and the flat buffer would silently stay zero.  Copy such
+        gradients in and re-attach the views (a missing .grad counts as zero, as in torch.optim)."""
+        off = 0
+        base = self.grad.data_ptr()
+        for p in self.params:
+            k = p.numel()
+            g = p.grad
+            if g is None or g.data_ptr() != base + 4 * off:
+                view = self.grad[off:off + k].view_as(p.data)
+                if g is None:
+                    view.zero_()
+                else:
+                    view.copy_(g)
+                p.grad = view
+            off += k
+
     def step(self):
         """-> total gradient norm before clipping (device scalar)"""
+        self._collect_stray_gradients()
         n = self.flat.numel()
         check(lib().cosy_grad_norm_clip(ptr(self.grad), n, float(self.max_norm or 0.0), ptr(self.norm_coef), ptr(_workspace(self.flat.device)),
                                         stream()))

@@ -6,6 +6,7 @@ backbone fp32 path -> <= 1e-4 relative on features and pose parameters (north_st
 bf16 throughput mode is reported against a looser, explicitly stated bound.
 """
 import argparse
+import os
 
 import numpy as np
 import pytest
@@ -18,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 GEOM_TOL = 2e-6
 NET_TOL = 1e-4      # BASELINE.json: <= 1e-4 relative on pose parameters (fp32 parity mode)
-BF16_FEAT_TOL = 6e-2  # bf16 storage through 26 MBConv blocks; measured value is printed
+BF16_FEAT_TOL = 1.7e-2  # bf16 storage through 26 MBConv blocks: <= 3x the measured 5.7e-3 (printed)
 
 
 def dev(a, dtype=torch.float32):
@@ -176,7 +177,7 @@ def test_backbone_bf16_deviation(model, golden):
     feat, pose, taps = _run_net(model, x, 'bf16')
     fe, pe = rel_err(feat, golden['bb_256x256_feat']), rel_err(pose, golden['bb_256x256_pose'])
     print(f'bf16 deviation vs reference fp32: features {fe:.3e}, pose params {pe:.3e}')
-    assert fe < BF16_FEAT_TOL
+    assert fe < BF16_FEAT_TOL and pe < 1.6e-4     # pose parameters: <= 3x the measured 5.1e-5
     model.compute_dtype = 'fp32'; model.render_size = (240, 320)
 
 
@@ -186,11 +187,11 @@ def test_backbone_fp16_deviation(model, golden):
     feat, pose, taps = _run_net(model, x, 'fp16')
     fe, pe = rel_err(feat, golden['bb_256x256_feat']), rel_err(pose, golden['bb_256x256_pose'])
     print(f'fp16 deviation vs reference fp32: features {fe:.3e}, pose params {pe:.3e}')
-    assert fe < 1e-2      # 11-bit mantissa: ~8x tighter than bf16
+    assert fe < 2.6e-3 and pe < 3e-5     # <= 3x the measured 8.4e-4 / 9e-6 (11-bit mantissa)
     model.compute_dtype = 'fp32'; model.render_size = (240, 320)
 
 
-@pytest.mark.parametrize('dtype,tol', [('bf16', 2e-2), ('fp16', 3e-3)])
+@pytest.mark.parametrize('dtype,tol', [('bf16', 2.3e-4), ('fp16', 5e-5)])     # <= 3x the measured 7.4e-5 / 1.6e-5
 def test_refiner_loop_low_precision(model, golden, labels21, dtype, tol):
     """configs[1]/[2] style run (4 refiner iterations, 16-bit backbone) stays close to the fp32 reference poses."""
     name, B, n_it, (h, w), seed = 'b3_n4_480', 3, 4, (480, 640), 32
@@ -291,10 +292,82 @@ def test_external_coarse_path_and_empty(model, labels21):
     assert len(tc.concatenate([init[[]], init[[]]])) == 0
 
 
+def test_zero_detections_end_to_end(model, labels21):
+    """get_predictions with an EMPTY detection table (an empty device tensor has a null data pointer: the C ABI returns
+    before its null checks when B == 0) -> empty collections under the same keys, for both init methods"""
+    import pandas as pd
+    from cosypose_amd import tensor_collection as tc
+    from cosypose_amd.pose_predictor import CoarseRefinePosePredictor
+    images = dev(syn.make_frames(5, 2, 480, 640)); K = dev(syn.make_K(2, 480, 640))
+    det = tc.PandasTensorCollection(infos=pd.DataFrame(dict(label=np.zeros(0, dtype=labels21.dtype), batch_im_id=np.zeros(0, np.int64),
+                                                            score=np.zeros(0))), bboxes=torch.zeros(0, 4, device='cuda'))
+    pred = CoarseRefinePosePredictor(coarse_model=model, refiner_model=model)
+    for init in ('v0', 'z-up+auto-depth'):
+        model.cfg.init_method = init
+        final, allp = pred.get_predictions(images, K, detections=det, n_coarse_iterations=1, n_refiner_iterations=2)
+        assert len(final) == 0 and list(allp) == ['coarse/iteration=1', 'refiner/iteration=1', 'refiner/iteration=2']
+    model.cfg.init_method = 'v0'
+
+
 def test_cpu_tensors_fail_loudly(model):
     from cosypose_amd._lib import CosyHipError
     with pytest.raises(CosyHipError):
         model.net_forward(torch.zeros(1, 6, 240, 320))
+
+
+# ---------------------------------------------------------------------------------------------
+# the headline workload, numerically: BASELINE configs[1]'s shape (256x256 crops from 512x512 frames, coarse 1 + refiner 4
+# through CoarseRefinePosePredictor), 32 detections from the bench's own generator, against the oracle loop
+# (reference: cosypose/integrated/pose_predictor.py:76-107 driving cosypose/models/pose.py:89-132)
+# ---------------------------------------------------------------------------------------------
+def _headline_case(D=32, n_frames=4, seed=1):
+    h = w = 512
+    obj, im, boxes = syn.make_detections(seed + 10, D, n_frames, 21, h, w)
+    return obj, im, boxes, syn.make_frames(seed, n_frames, h, w), syn.make_K(n_frames, h, w)
+
+
+@pytest.fixture(scope='module')
+def headline_oracle(oracle, golden_sd, mesh_table):
+    """fp32 oracle poses of the headline case: every iteration's TCO_output (C geometry / roi_align + torch-CPU backbone)."""
+    obj, im, boxes, frames, K = _headline_case()
+    tr = oracle.TorchRef(golden_sd)
+    rend = lambda call: syn.make_renders(9000 + call, len(obj), 256, 256)
+    TCO = oracle.tco_init_from_boxes(boxes, K[im])
+    coarse = oracle.pose_predictor_forward(frames[im], K[im], obj, TCO, mesh_table, None, lambda n, t, k: rend(n), 1, (256, 256),
+                                           backbone=tr.net_forward)
+    refine = oracle.pose_predictor_forward(frames[im], K[im], obj, coarse['iteration=1']['TCO_output'], mesh_table, None,
+                                           lambda n, t, k: rend(1 + n), 4, (256, 256), backbone=tr.net_forward)
+    out = {'coarse/iteration=1': coarse['iteration=1']}
+    out.update({f'refiner/iteration={n}': refine[f'iteration={n}'] for n in range(1, 5)})
+    return out
+
+
+@pytest.mark.parametrize('dtype,tol_pose,tol_kcrop', [('fp32', NET_TOL, NET_TOL), ('bf16', 3e-4, 3e-4), ('fp16', 6e-5, 6e-5)])
+def test_headline_config_vs_oracle(model, labels21, headline_oracle, dtype, tol_pose, tol_kcrop):
+    """fp32: <= 1e-4 relative on every iteration's poses / crop cameras / boxes (north_star's bound).  bf16 / fp16: the
+    deviation of the throughput modes from the fp32 oracle, asserted at <= 3x what was measured when the test was written
+    (poses / crop cameras: bf16 1.3e-4 / 9.5e-5, fp16 3.0e-5 / 1.3e-5; fp32 itself lands at 6e-8 / 1e-6)."""
+    import pandas as pd
+    from cosypose_amd import tensor_collection as tc
+    from cosypose_amd.pose_predictor import CoarseRefinePosePredictor
+    obj, im, boxes, frames, K = _headline_case()
+    det = tc.PandasTensorCollection(infos=pd.DataFrame(dict(label=labels21[obj], batch_im_id=im, score=1.0)), bboxes=dev(boxes))
+    model.renderer = FakeRenderer(9000)
+    model.compute_dtype = dtype
+    model.render_size = (256, 256)
+    model.cfg.init_method = 'v0'
+    pred = CoarseRefinePosePredictor(coarse_model=model, refiner_model=model, bsz_objects=64)
+    final, allp = pred.get_predictions(dev(frames), dev(K), detections=det, n_coarse_iterations=1, n_refiner_iterations=4)
+    model.compute_dtype = 'fp32'; model.render_size = (240, 320)
+    worst = {}
+    for key, want in headline_oracle.items():
+        got = allp[key]
+        for f, src in (('poses', 'TCO_output'), ('K_crop', 'K_crop'), ('boxes_rend', 'boxes_rend'), ('boxes_crop', 'boxes_crop')):
+            worst[f] = max(worst.get(f, 0.0), rel_err(getattr(got, f).cpu().numpy(), want[src]))
+    print(f'headline config, {dtype}: worst relative deviation over 5 iterations: ' + ', '.join(f'{k} {v:.2e}' for k, v in worst.items()))
+    assert torch.equal(final.poses, allp['refiner/iteration=4'].poses)
+    assert worst['poses'] < tol_pose and worst['K_crop'] < tol_kcrop
+    assert worst['boxes_rend'] < max(tol_pose, 10 * tol_kcrop) and worst['boxes_crop'] < max(tol_pose, 10 * tol_kcrop)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -559,6 +632,39 @@ def test_training_gradients_vs_oracle_with_drop_connect(oracle, golden_train, go
         assert _grad_err(p.grad.cpu().numpy(), go, scale) < GRAD_TOL, n
 
 
+def test_training_step_batch64_vs_oracle(oracle, golden_sd):
+    """BASELINE configs[4]'s per-GPU shape (64 crops of 240x320, 2600 loss points -- what bench_train.py times; the
+    streaming weight-gradient kernel and its tile choices only engage at these row counts) against the torch-CPU
+    restatement of the reference step: loss, pose outputs and every gradient tensor."""
+    from cosypose_amd import train_engine
+    B, P = 64, 2600
+    rs = np.random.RandomState(64)
+    x = rs.random_sample((B, 6, 240, 320)).astype(np.float32)
+    TCO_in = syn.make_TCO(65, B)
+    gt = TCO_in[:, None].copy()
+    gt[:, 0, :3, 3] += rs.normal(0, 0.02, (B, 3)).astype(np.float32)
+    K_crop = syn.make_K(B, 240, 320)
+    points = (rs.uniform(-1, 1, (B, P, 3)) * rs.uniform(0.03, 0.12, (B, 1, 3))).astype(np.float32)
+    oracle.set_threads(min(os.cpu_count() or 1, 32)); torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    loss_o, pose_o, grads_o = oracle.TorchRef(golden_sd).train_forward_backward(x, gt, TCO_in, K_crop, points, drop=None)
+    model, _, _ = _train_model(golden_sd)
+    model.train()
+    x8 = torch.zeros(B, 240, 320, 8, device='cuda')
+    x8[..., :6] = torch.from_numpy(x).cuda().permute(0, 2, 3, 1)
+    pose = train_engine.backbone_train(model, x8, {})
+    loss = train_engine.loss_refiner_CO_disentangled(dev(gt), dev(TCO_in), pose, dev(K_crop), dev(points)).mean()
+    loss.backward()
+    assert abs(loss.item() - loss_o) < 1e-4 * abs(loss_o)
+    assert rel_err(pose.detach().cpu().numpy(), pose_o) < 1e-4
+    worst = 0.0
+    for n, p in model.named_parameters():
+        go = grads_o[n]
+        e = _grad_err(p.grad.cpu().numpy(), go, max(np.linalg.norm(go.ravel()), 1e-6))
+        worst = max(worst, e)
+        assert e < GRAD_TOL, (n, e)
+    print(f'B=64 training step: worst gradient error relative to the tensor norm {worst:.2e}')
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE configs[2] and configs[3] as parity cases (the bench line is configs[1]; SURVEY 8d)
 # ---------------------------------------------------------------------------------------------
@@ -770,14 +876,17 @@ def test_training_reference_loop_unchanged_and_deterministic(golden_train, golde
         model.train(); model.drop_connect_rate = 0.0
         data = types.SimpleNamespace(images=torch.from_numpy(frames), K=torch.from_numpy(K), TCO=torch.from_numpy(TCO),
                                      objects=[dict(name=l) for l in labels_all[obj]], bboxes=torch.from_numpy(golden_train['tr_bboxes']))
-        opt = train_engine.FlatAdam(model, lr=3e-4, clip_grad_norm=0.5) if kind == 'flat' else torch.optim.Adam(model.parameters(), lr=3e-4)
+        opt = train_engine.FlatAdam(model, lr=3e-4, clip_grad_norm=0.5) if kind.startswith('flat') else torch.optim.Adam(model.parameters(), lr=3e-4)
         losses = []
         for step in range(2):
-            opt.zero_grad()
+            if kind == 'flat_zg':
+                model.zero_grad()       # set_to_none: detaches p.grad from the flat buffer; FlatAdam.step has to notice
+            else:
+                opt.zero_grad()
             np.random.seed(123 + step)
             loss = pfl.h_pose(model=model, mesh_db=mesh_db, data=data, meters=defaultdict(M), cfg=cfg, n_iterations=1, input_generator='fixed')
             loss.backward()
-            if kind != 'flat':
+            if not kind.startswith('flat'):
                 torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=0.5, norm_type=2)
             opt.step()
             losses.append(loss.item())
@@ -786,6 +895,8 @@ def test_training_reference_loop_unchanged_and_deterministic(golden_train, golde
     l_ref, p_ref = run('torch')
     l_flat, p_flat = run('flat')
     l_flat2, p_flat2 = run('flat')
+    l_zg, p_zg = run('flat_zg')
+    assert l_zg == l_flat and all(np.array_equal(p_flat[n], p_zg[n]) for n in p_flat)           # model.zero_grad() is harmless
     assert l_flat == l_flat2 and all(np.array_equal(p_flat[n], p_flat2[n]) for n in p_flat)      # deterministic
     assert abs(l_ref[0] - float(golden_train['tr_loss'])) < 1e-4 * abs(l_ref[0]) and l_ref[1] != l_ref[0]
     assert np.allclose(l_ref, l_flat, rtol=1e-5)
