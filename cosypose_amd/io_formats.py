@@ -1,83 +1,90 @@
-"""Data formats either side of the hot path: detector output -> candidate collection, refined poses ->
-BOP result files and back.
+"""Data formats either side of the hot path, written from their contracts and pinned by fixtures the
+reference's own code produced (tests/golden/generate_golden_io.py -> reference_golden_io.npz).
 
-* `make_detections`: the post-processing contract of Detector.get_detections (cosypose/integrated/detector.py:19-72)
-  after the Mask R-CNN itself (out of scope): per-image boxes/labels/scores -> PandasTensorCollection(infos[batch_im_id,
-  label, score], bboxes (D,4) float on the device [, masks]), score threshold, one_instance_per_class.
-* `tc_to_csv` / `read_csv_candidates`: cosypose/scripts/run_custom_scenario.py:26-58 (poses in metres <-> BOP rows with `t` in
-  millimetres and row-major `R`).  The writer restates bop_toolkit_lib.inout.save_bop_results (third-party, BOP19 format:
-  header `scene_id,im_id,obj_id,score,R,t,time`, R and t as space-separated floats) -- that dependency is not in the
-  reference tree, so the file format is pinned by the round trip through the reference's own reader logic only.
+Detector output -> candidates.  Contract of Detector.get_detections after the Mask R-CNN itself
+(cosypose/integrated/detector.py:36-72; the network is out of scope): one row per detection in image order, `infos`
+columns [batch_im_id, label, score], `bboxes` (D,4) float32 xyxy on the device, optional boolean `masks` (probability >
+mask_th); `detection_th` keeps scores strictly above it; `one_instance_per_class` keeps the best-scoring detection of
+every label, listed by descending score.
+
+Poses <-> BOP result files.  Contract of cosypose/scripts/run_custom_scenario.py:26-58: BOP19 rows
+`scene_id,im_id,obj_id,score,R,t,time` with R row-major, t in millimetres, both space separated (the writer itself is
+bop_toolkit_lib.inout.save_bop_results, third-party); the reader returns infos [view_id, scene_id, score, label] with
+label 'obj_%06d' and poses in metres.
 """
+
 import numpy as np
 import pandas as pd
 import torch
 
 from . import tensor_collection as tc
 
+BOP19_HEADER = 'scene_id,im_id,obj_id,score,R,t,time'
+
+
+def _host(a):
+    return a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+
 
 def make_detections(per_image, device='cuda', detection_th=None, one_instance_per_class=False, output_masks=False, mask_th=0.8):
-    """per_image: list (one entry per frame, in batch order) of dicts with 'boxes' (n,4) xyxy px, 'labels' (n,) str,
-    'scores' (n,) [, 'masks' (n,1,h,w) probabilities].  Same output as Detector.get_detections."""
-    infos, bboxes, masks = [], [], []
-    for n, out in enumerate(per_image):
-        for obj_id in range(len(out['boxes'])):
-            infos.append(dict(batch_im_id=n, label=out['labels'][obj_id], score=float(out['scores'][obj_id])))
-            bboxes.append(torch.as_tensor(out['boxes'][obj_id]))
-            if output_masks:
-                masks.append(torch.as_tensor(out['masks'][obj_id, 0]) > mask_th)
-    if len(bboxes) > 0:
-        bboxes = torch.stack(bboxes).to(device).float()
-        if output_masks:
-            masks = torch.stack(masks).to(device)
+    """per_image: one dict per frame, in batch order: 'boxes' (n,4) xyxy px, 'labels' (n,) label strings, 'scores' (n,)
+    [, 'masks' (n,1,h,w) probabilities] -> PandasTensorCollection as Detector.get_detections returns it."""
+    counts = [len(out['boxes']) for out in per_image]
+    total = int(sum(counts))
+    frame_of = np.repeat(np.arange(len(per_image)), counts)
+    labels = np.array([str(l) for out in per_image for l in list(out['labels'])], dtype=object)
+    scores = np.concatenate([_host(out['scores']).astype(np.float64).reshape(-1) for out in per_image]) if total else np.zeros(0)
+    if total:
+        boxes = torch.cat([torch.as_tensor(out['boxes']).reshape(-1, 4) for out in per_image]).to(device=device, dtype=torch.float32)
+        table = pd.DataFrame({'batch_im_id': frame_of, 'label': labels, 'score': scores})
     else:
-        infos = dict(score=[], label=[], batch_im_id=[])
-        bboxes = torch.empty(0, 4, device=device).float()
-    outputs = tc.PandasTensorCollection(infos=pd.DataFrame(infos), bboxes=bboxes)
-    if output_masks and len(outputs) > 0:
-        outputs.register_tensor('masks', masks)
+        boxes = torch.empty(0, 4, device=device, dtype=torch.float32)
+        table = pd.DataFrame({'score': [], 'label': [], 'batch_im_id': []})      # the reference's column order for "nothing found"
+    keep = np.arange(total)
     if detection_th is not None:
-        keep = np.where(outputs.infos['score'] > detection_th)[0]
-        outputs = outputs[keep]
+        keep = keep[scores[keep] > detection_th]
     if one_instance_per_class:
-        infos = outputs.infos
-        infos['det_idx'] = np.arange(len(infos))
-        keep_ids = infos.sort_values('score', ascending=False).drop_duplicates('label')['det_idx'].values
-        outputs = outputs[keep_ids]
-        outputs.infos = outputs.infos.drop('det_idx', axis=1)
-    return outputs
+        # best score first (stable: the earlier detection wins a tie), then the first occurrence of every label
+        ranked = keep[np.argsort(-scores[keep], kind='stable')]
+        _, first = np.unique(labels[ranked].astype(str), return_index=True)
+        keep = ranked[np.sort(first)]
+    fields = {'bboxes': boxes[torch.as_tensor(keep, device=boxes.device)] if total else boxes}
+    if output_masks and total:
+        probs = torch.cat([torch.as_tensor(out['masks'])[:, 0] for out in per_image if len(out['boxes'])])
+        fields['masks'] = (probs > mask_th).to(device)[torch.as_tensor(keep, device=device)]
+    return tc.PandasTensorCollection(infos=table.iloc[keep].reset_index(drop=True) if total else table, **fields)
 
 
-def save_bop_results(path, results):
-    """BOP19 result file (bop_toolkit_lib.inout.save_bop_results): one row per estimate."""
-    lines = ['scene_id,im_id,obj_id,score,R,t,time']
-    for res in results:
-        R = ' '.join(map(str, np.asarray(res['R'], dtype=np.float64).flatten().tolist()))
-        t = ' '.join(map(str, np.asarray(res['t'], dtype=np.float64).flatten().tolist()))
-        lines.append(f"{res['scene_id']},{res['im_id']},{res['obj_id']},{res['score']},{R},{t},{res.get('time', -1)}")
+def bop19_rows(predictions):
+    """The estimates of a collection (infos: label 'obj_%06d', score, scene_id, view_id; poses (D,4,4) in metres) as BOP19
+    fields: what run_custom_scenario.tc_to_csv hands to the BOP toolkit's writer."""
+    T = predictions.poses.detach().to('cpu', torch.float32)                   # ONE device -> host copy
+    R, t_mm = T[:, :3, :3].numpy(), (T[:, :3, 3] * 1e3).numpy()               # metres -> millimetres in float32, as the reference
+    info = predictions.infos
+    obj = [int(str(l).rsplit('_', 1)[-1]) for l in info['label']]
+    return [dict(scene_id=info['scene_id'].iloc[i], im_id=info['view_id'].iloc[i], obj_id=obj[i], score=info['score'].iloc[i],
+                 R=R[i], t=t_mm[i], time=-1.0) for i in range(len(info))]
+
+
+def save_bop_results(path, rows):
+    """BOP19 result file, one line per estimate (format of bop_toolkit_lib.inout.save_bop_results)."""
+    fmt = lambda v: ' '.join(repr(float(x)) for x in np.asarray(v, np.float64).ravel())
+    body = [f"{r['scene_id']},{r['im_id']},{r['obj_id']},{r['score']},{fmt(r['R'])},{fmt(r['t'])},{r.get('time', -1)}" for r in rows]
     with open(path, 'w') as f:
-        f.write('\n'.join(lines))
+        f.write('\n'.join([BOP19_HEADER] + body))
 
 
 def tc_to_csv(predictions, csv_path):
-    """PandasTensorCollection(infos[label 'obj_%06d', score, scene_id, view_id], poses (D,4,4) metres) -> BOP csv."""
-    poses = predictions.poses.detach().cpu().numpy()      # ONE device->host copy for the whole collection
-    preds = []
-    for n in range(len(predictions)):
-        row = predictions.infos.iloc[n]
-        preds.append(dict(scene_id=row.scene_id, im_id=row.view_id, obj_id=int(row.label.split('_')[-1]), score=row.score,
-                          t=poses[n, :3, -1] * 1e3, R=poses[n, :3, :3], time=-1.0))
-    save_bop_results(csv_path, preds)
+    save_bop_results(csv_path, bop19_rows(predictions))
 
 
 def read_csv_candidates(csv_path):
+    """BOP19 csv -> PandasTensorCollection(infos [view_id, scene_id, score, label], poses (D,4,4) float32 in metres)."""
     df = pd.read_csv(csv_path)
-    infos = df.loc[:, ['im_id', 'scene_id', 'score', 'obj_id']]
-    infos['obj_id'] = infos['obj_id'].apply(lambda x: f'obj_{x:06d}')
-    infos = infos.rename(dict(im_id='view_id', obj_id='label'), axis=1)
-    R = np.stack(df['R'].apply(lambda x: list(map(float, x.split(' '))))).reshape(-1, 3, 3)
-    t = np.stack(df['t'].apply(lambda x: list(map(float, x.split(' '))))).reshape(-1, 3) * 1e-3
-    TCO = torch.eye(4, dtype=torch.float).unsqueeze(0).repeat(len(R), 1, 1)
-    TCO[:, :3, :3] = torch.tensor(R, dtype=torch.float)
-    TCO[:, :3, -1] = torch.tensor(t, dtype=torch.float)
-    return tc.PandasTensorCollection(poses=TCO, infos=infos)
+    vec = lambda col, n: np.array([np.array(s.split(), dtype=np.float64) for s in df[col]], dtype=np.float64).reshape(len(df), n)
+    poses = np.tile(np.eye(4), (len(df), 1, 1))
+    poses[:, :3, :3] = vec('R', 9).reshape(-1, 3, 3)
+    poses[:, :3, 3] = vec('t', 3) * 1e-3
+    infos = pd.DataFrame({'view_id': df['im_id'], 'scene_id': df['scene_id'], 'score': df['score'],
+                          'label': ['obj_%06d' % int(o) for o in df['obj_id']]})
+    return tc.PandasTensorCollection(infos=infos, poses=torch.as_tensor(poses, dtype=torch.float32))

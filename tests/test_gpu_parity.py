@@ -857,6 +857,32 @@ def test_crop_pack_all_window_paths(oracle):
     assert (got[..., 6:] == 0).all()                                                 # the two padding channels
 
 
+def test_roi_align_handmade_fixtures():
+    """both HIP roi_align paths (cosy_roi_align and the fused crop + pack kernel) against vectors that do not come from
+    this repository's 2-D code: separable images whose expected crops are outer products of 1-D means, derived in
+    tests/golden/generate_roi_align_fixtures.py (affine ramps, a box thinner than a pixel, one-hot borders, the [-1, n]
+    validity window, a box fully outside).  Reference call site: cosypose/lib3d/cropping.py:64-75."""
+    import pathlib
+    from cosypose_amd import lib3d
+    from cosypose_amd._lib import lib, check, ptr, stream, COSY_F32
+    d = np.load(pathlib.Path(__file__).parent / 'golden' / 'roi_align_handmade.npz')
+    images, rois, want = d['images'], d['rois'], d['expected']
+    H, W = (int(v) for v in d['out_hw'])
+    scale = np.abs(want).max()
+    got = lib3d.roi_align(dev(images), dev(rois), (H, W), 4).cpu().numpy()
+    assert np.abs(got - want).max() < 2e-6 * scale
+    N, _, h, w = images.shape
+    B = len(rois)
+    frames4 = torch.empty(N, h, w, 4, device='cuda')
+    frames_d = dev(images)
+    check(lib().cosy_frames_to_nhwc4(ptr(frames_d), ptr(frames4), N, h, w, stream()))
+    x8 = torch.full((B, H, W, 8), -7.0, device='cuda')
+    im_d, boxes_d, renders_d = dev(rois[:, 0], torch.int32), dev(rois[:, 1:]), torch.zeros(B, 3, H, W, device='cuda')
+    check(lib().cosy_crop_pack_to(ptr(x8), COSY_F32, ptr(frames4), ptr(im_d), ptr(boxes_d), ptr(renders_d), B, N, h, w, H, W, stream()))
+    got2 = x8.cpu().numpy()[..., :3].transpose(0, 3, 1, 2)
+    assert np.abs(got2 - want).max() < 2e-6 * scale
+
+
 def test_training_reference_loop_unchanged_and_deterministic(golden_train, golden_sd):
     """the reference's own loop (train_pose.py:317-331: zero_grad / h / backward / clip_grad_norm_ / torch.optim.Adam.step)
     runs unchanged on a cosypose_amd model and lands on the same weights as the fused FlatAdam path after 2 steps;

@@ -156,3 +156,55 @@ def test_detection_and_bop_csv_formats(tmp_path):
     back = io_formats.read_csv_candidates(path)
     assert back.infos['label'].tolist() == infos['label'].tolist() and back.infos['view_id'].tolist() == [1, 1, 733]
     assert torch.allclose(back.poses, poses, atol=1e-6)
+
+
+def test_io_formats_vs_reference_fixtures(tmp_path):
+    """io_formats against what the reference's own Detector.get_detections (detector.py:36-72) and run_custom_scenario
+    (:26-58) produced on the same inputs (tests/golden/generate_golden_io.py): every option of the detector
+    post-processing incl. the empty case, the csv reader on a literal BOP19 file, and the rows handed to the BOP writer."""
+    import pandas as pd
+    from conftest import REPO
+    from cosypose_amd import io_formats, tensor_collection as tc
+    g = dict(np.load(REPO / 'tests' / 'golden' / 'reference_golden_io.npz', allow_pickle=False))
+    names = {int(i): str(n) for n, i in zip(g['det_label_names'], g['det_label_ids'])}
+    per_image = [dict(boxes=g[f'det_in{i}_boxes'], labels=[names[int(c)] for c in g[f'det_in{i}_labels']], scores=g[f'det_in{i}_scores'],
+                      masks=g[f'det_in{i}_masks']) for i in range(3)]
+    cases = dict(plain={}, th=dict(detection_th=0.5), one=dict(one_instance_per_class=True),
+                 masks=dict(output_masks=True, mask_th=0.6, detection_th=0.3), th_one=dict(detection_th=0.2, one_instance_per_class=True))
+    for name, kw in cases.items():
+        det = io_formats.make_detections(per_image, device='cpu', **kw)
+        assert list(det.infos.columns) == list(g[f'det_{name}_columns']), name
+        assert det.infos['batch_im_id'].tolist() == g[f'det_{name}_info_batch_im_id'].tolist(), name
+        assert det.infos['label'].tolist() == g[f'det_{name}_info_label'].tolist(), name
+        assert np.allclose(det.infos['score'].values, g[f'det_{name}_info_score'], rtol=0, atol=1e-7), name
+        assert det.bboxes.dtype == torch.float32 and np.array_equal(det.bboxes.numpy(), g[f'det_{name}_bboxes']), name
+        if f'det_{name}_masks' in g:
+            assert det.masks.dtype == torch.bool and np.array_equal(det.masks.numpy(), g[f'det_{name}_masks'])
+        else:
+            assert 'masks' not in det.tensors
+    empty = io_formats.make_detections([dict(boxes=np.zeros((0, 4)), labels=[], scores=[], masks=np.zeros((0, 1, 6, 8)))] * 3, device='cpu',
+                                       output_masks=True)
+    assert len(empty) == int(g['det_empty_n']) == 0 and list(empty.infos.columns) == list(g['det_empty_columns'])
+    assert tuple(empty.bboxes.shape) == tuple(g['det_empty_bboxes_shape'])
+    # csv reader on the literal file the reference read
+    p = tmp_path / 'ref.csv'; p.write_text(str(g['csv_text']))
+    cand = io_formats.read_csv_candidates(p)
+    assert list(cand.infos.columns) == list(g['csv_columns'])
+    for c in cand.infos.columns:
+        want = g[f'csv_info_{c}']
+        assert cand.infos[c].tolist() == want.tolist() if c == 'label' else np.allclose(cand.infos[c].values.astype(float), want.astype(float))
+    assert cand.poses.dtype == torch.float32 and np.array_equal(cand.poses.numpy(), g['csv_poses'])
+    # the rows the reference hands to the BOP writer; then our file read back by our reader
+    infos = pd.DataFrame(dict(label=['obj_000005', 'obj_000021', 'obj_000001'], score=[0.87, 0.5, 0.125], scene_id=[48, 48, 7], view_id=[1, 1, 103]))
+    preds = tc.PandasTensorCollection(infos=infos, poses=cand.poses.clone())
+    rows = io_formats.bop19_rows(preds)
+    assert sorted(rows[0]) == list(g['rows_keys'])
+    for k in ('scene_id', 'im_id', 'obj_id', 'score', 'time'):
+        assert np.allclose([float(r[k]) for r in rows], g[f'rows_{k}'])
+    assert np.allclose(np.stack([r['t'] for r in rows]), g['rows_t'], rtol=0, atol=1e-9 * 1e3)
+    assert np.allclose(np.stack([r['R'] for r in rows]), g['rows_R'], rtol=0, atol=0)
+    out = tmp_path / 'ours.csv'
+    io_formats.tc_to_csv(preds, out)
+    assert out.read_text().split('\n')[0] == 'scene_id,im_id,obj_id,score,R,t,time'
+    back = io_formats.read_csv_candidates(out)
+    assert back.infos['label'].tolist() == infos['label'].tolist() and torch.allclose(back.poses, cand.poses, atol=1e-6)

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from cosypose_amd import synthetic as syn
-from conftest import rel_err
+from conftest import rel_err, REPO
 
 TOL = 2e-6   # fp32 restatement vs torch CPU: same formulas, different summation order at most
 
@@ -186,3 +186,17 @@ def test_training_step_vs_reference(oracle, golden_train, golden_sd, mesh_table)
     for k in g:
         if k.startswith('tr_bn/'):
             assert rel_err(ref.sd[k[len('tr_bn/'):]].numpy(), g[k]) < 1e-5, k      # running statistics after the step
+
+
+def test_roi_align_oracle_vs_handmade_fixtures(oracle):
+    """The C restatement and the independent numpy twin of torchvision-0.4.2 roi_align against hand-derivable vectors
+    (tests/golden/generate_roi_align_fixtures.py: separable images -> outer products of 1-D means; no 2-D code of this
+    repository produced them): affine ramps = value at the bin centre, max(roi, 1) for a box thinner than a pixel,
+    one-hot border rows / columns for the clamp at n - 1 and the [-1, n] validity window, a box fully outside."""
+    d = np.load(REPO / 'tests' / 'golden' / 'roi_align_handmade.npz')
+    hw = tuple(int(v) for v in d['out_hw'])
+    scale = np.abs(d['expected']).max()
+    for fn in (oracle.roi_align, oracle.roi_align_numpy):
+        got = fn(d['images'], d['rois'], hw, 4)
+        assert np.abs(got - d['expected']).max() < 1e-6 * scale
+    assert np.all(d['expected'][5] == 0) and np.all(oracle.roi_align(d['images'], d['rois'], hw, 4)[5] == 0)
