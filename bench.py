@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
 """Headline benchmark: refined pose-iterations/sec of the render-and-compare hot path on MI355X.
 
-A "step" = one pass of the hot path over one batch of synthetic input (BASELINE.json configs[1]):
-D=256 detections over 16 frames, 21 objects, coarse 1 + refiner 4 iterations = 1280 pose-iterations per
-GPU per step, 256x256 crops, bf16 backbone, geometry/pose update fp32.  Everything (frames, intrinsics,
-detections, mesh table, weights, the synthetic renderer's images) is resident in HBM before the timed region.
-With --gpus N each rank runs its own 256 detections (weak scaling) and the refined poses are all-gathered
-over RCCL once per step.
+A "step" = one pass of the hot path over one batch of synthetic input.  --config selects the BASELINE.json workload:
+  1 (default, the metric's config): D=256 detections per GPU over 16 frames 512x512, 21 objects, coarse 1 + refiner 4
+    iterations = 1280 pose-iterations per GPU per step, 256x256 crops, bf16 backbone; weak scaling (each rank its own 256);
+  2: T-LESS shape: 1024 candidates over 64 frames 540x720, 30 objects, refiner-only 4 iterations from given poses, fp16;
+     STRONG scaling: the 1024 candidates are sharded over the ranks (get_predictions_sharded);
+  3: BOP mix: 2048 candidates over 7 frame sizes (5x 640x480, 720x540, 1280x960), coarse 1 + refiner 4, bf16, strong
+     scaling with --split skewed (per-rank shares ~ [512,384,320,256,224,160,128,64]/2048) or balanced (equal counts).
+Everything (frames, intrinsics, detections, mesh table, weights, the synthetic renderer's images) is resident in HBM
+before the timed region.  The refined poses of all ranks are exchanged by ONE RCCL all-gather per step.
 
-One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel of the backbone, timed live with
-HIP events recorded on the launch stream after every launch (cosy_effnet_b3_set_profiling) in a second pass over
-the same steps right after the timed region (an event per kernel costs ~6 % of throughput, so not inside it);
-`cpu_baseline` is the CPU oracle (a port of the reference's PyTorch-CPU arithmetic) on a bounded sample.
+One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel FAMILY of the backbone (all instantiations of one
+kernel template together; the dominant single instantiation is reported beside it), timed live with HIP events recorded on
+the launch stream after every launch (cosy_effnet_b3_set_profiling) in a second pass over the same steps right after the
+timed region (an event per kernel costs ~6 % of throughput, so not inside it).  `roofline.traffic` (HBM bytes per launch
+from PMC counters) cannot be measured from inside this process: it is taken from profiles/r02_pmc_traffic.json ONLY when
+that file was collected for the same kernel sources (its `csrc_sha` matches the tree); otherwise null.
+`cpu_baseline` is the CPU oracle (a port of the reference's PyTorch-CPU arithmetic) on a bounded sample: warm-up, then the
+median of 5 repeats, at 1 thread (the reference pins OMP_NUM_THREADS=1) and at N threads.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -27,6 +35,7 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0, 'fp32': 157.3}
 ALGO_MB_PER_POSE_ITER = {('bf16', 256): 10.7, ('fp16', 256): 10.7, ('fp32', 256): 21.3, ('bf16', 240): 12.4, ('fp16', 240): 12.4, ('fp32', 240): 24.9}
+SKEW = [512, 384, 320, 256, 224, 160, 128, 64]
 
 
 class SyntheticRenderer:
@@ -55,17 +64,22 @@ def build_model(seed, mesh_db, render_size, dtype, renderer):
     return m.cuda().eval()
 
 
-def cpu_baseline(crop, n_det=32):
-    """The oracle (torch-CPU port of the reference arithmetic + C geometry/roi_align) on a bounded sample."""
+def csrc_sha():
+    h = hashlib.sha256()
+    d = os.path.join(REPO, 'cosypose_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode()); h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(crop, n_det=8, repeats=5):
+    """The oracle (torch-CPU port of the reference arithmetic + C geometry/roi_align) on a bounded sample: one warm-up
+    batch, then the median of `repeats` (bop_predictions.py:132-134 times the reference the same way), at 1 thread (the
+    reference sets OMP_NUM_THREADS=1, cosypose/__init__.py:1-4) and at N threads."""
     sys.path.insert(0, os.path.join(REPO, 'oracle'))
     import torch
     import cosy_oracle as O
     from cosypose_amd import synthetic as syn
-    # the stock torch-CPU convolutions stop scaling at ~16 threads on the GPU box's 256-core host
-    # (measured: 1 thread 10.3, 16 threads 17.3, 64 threads 10.6, 128 threads 3.7 crops/s at B=16)
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
-    O.set_threads(cores)
     H, W = crop
     h, w = (512, 512) if H == W else (480, 640)
     sd = syn.golden_state_dict(0)
@@ -76,15 +90,33 @@ def cpu_baseline(crop, n_det=32):
     K = syn.make_K(n_det, h, w)
     TCO = O.tco_init_from_boxes(boxes, K)
     rend = syn.make_renders(3, n_det, H, W)
-    run = lambda n, b: O.pose_predictor_forward(frames[:b], K[:b], obj[:b], TCO[:b], pts, None, lambda i, t, k: rend[:b],
-                                                 n, (H, W), backbone=tr.net_forward)
-    run(1, 2)  # warm-up
-    t0 = time.time()
-    run(2, n_det)  # coarse 1 + refiner 1 worth of iterations
-    dt = time.time() - t0
-    return dict(value=round(2 * n_det / dt, 3), unit='pose-iterations/s', cores=cores, kind='port',
-                sample=f'{n_det} detections x 2 iterations ({2 * n_det} pose-iterations), {H}x{W} crops, fp32, '
-                       f'torch-CPU backbone + C geometry/roi_align oracle, {cores} threads, {dt:.1f} s')
+    run = lambda: O.pose_predictor_forward(frames, K, obj, TCO, pts, None, lambda i, t, k: rend, 1, (H, W), backbone=tr.net_forward)
+    # the stock torch-CPU convolutions stop scaling at ~16 threads on the GPU box's 256-core host
+    # (measured: 1 thread 10.3, 16 threads 17.3, 64 threads 10.6, 128 threads 3.7 crops/s at B=16)
+    many = min(os.cpu_count() or 1, 16)
+    rates = {}
+    for cores in (1, many):
+        torch.set_num_threads(cores)
+        O.set_threads(cores)
+        run()  # warm-up
+        ts = []
+        for _ in range(repeats):
+            t0 = time.time(); run(); ts.append(time.time() - t0)
+        rates[cores] = n_det / float(np.median(ts))
+    return dict(value=round(rates[many], 3), unit='pose-iterations/s', cores=many, kind='port', value_1_thread=round(rates[1], 3),
+                sample=f'{n_det} detections x 1 iteration, {H}x{W} crops, fp32, torch-CPU backbone + C geometry/roi_align oracle; '
+                       f'warm-up then median of {repeats} at 1 and at {many} threads')
+
+
+def make_scene(syn, torch, tc, pd, labels, seed, D, n_frames, h, w, n_obj, with_poses=False):
+    """(frames, K, table) of one frame size on the device; table = detections, or given poses for the refiner-only config"""
+    frames = torch.from_numpy(syn.make_frames(seed, n_frames, h, w)).cuda()
+    K = torch.from_numpy(syn.make_K(n_frames, h, w)).cuda()
+    obj, im, boxes = syn.make_detections(seed + 10, D, n_frames, n_obj, h, w)
+    infos = pd.DataFrame(dict(label=labels[obj], batch_im_id=im, score=1.0))
+    if with_poses:
+        return frames, K, tc.PandasTensorCollection(infos=infos, poses=torch.from_numpy(syn.make_TCO(seed + 20, D)).cuda())
+    return frames, K, tc.PandasTensorCollection(infos=infos, bboxes=torch.from_numpy(boxes).cuda())
 
 
 def main():
@@ -92,12 +124,14 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--config', type=int, default=1, choices=[1, 2, 3], help='BASELINE.json configs[i] (see the module docstring)')
+    ap.add_argument('--split', default='skewed', choices=['skewed', 'balanced'], help='config 3: how candidates are shared out')
     ap.add_argument('--crop', default='256x256', help='HxW of the crops: 256x256 (metric) or 240x320 (reference native)')
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
-    ap.add_argument('--detections', type=int, default=256, help='detections per GPU per step')
+    ap.add_argument('--dtype', default=None, choices=['bf16', 'fp16', 'fp32'], help='default: bf16 (configs 1, 3), fp16 (config 2)')
+    ap.add_argument('--detections', type=int, default=None, help='override the number of candidates (per GPU for config 1, total otherwise)')
     ap.add_argument('--bsz-objects', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-profile', action='store_true', help='do not record per-kernel HIP events in the timed region')
+    ap.add_argument('--no-profile', action='store_true', help='skip the per-kernel HIP-event pass (no roofline object)')
     ap.add_argument('--layers', action='store_true', help='print the per-launch table to stderr')
     ap.add_argument('--renderer', default='pregenerated', choices=['pregenerated', 'hip'],
                     help="renderer.render source: pre-generated device images (default: the reference's renderer is outside the "
@@ -111,7 +145,8 @@ def main():
     from cosypose_amd import tensor_collection as tc
     from cosypose_amd.mesh_db import BatchedMeshes
     from cosypose_amd.pose_predictor import CoarseRefinePosePredictor
-    from cosypose_amd.distributed import init_distributed_mode, all_gather_rows, local_device_index
+    from cosypose_amd.distributed import (init_distributed_mode, all_gather_rows, local_device_index, get_predictions_sharded,
+                                          get_predictions_sharded_scenes, plan_shards)
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
@@ -120,37 +155,74 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
     torch.cuda.set_device(local_device_index())
     H, W = (int(v) for v in args.crop.split('x'))
-    h, w = (512, 512) if H == W else (480, 640)   # square frames for square crops
-    D, n_frames, n_obj = args.detections, 16, 21
-    seed = 1 + rank                                  # BASELINE config index 1; each rank its own candidates
-
+    cfg_i = args.config
+    dtype = args.dtype or ('fp16' if cfg_i == 2 else 'bf16')
+    n_obj = 30 if cfg_i == 2 else 21
+    n_coarse, n_refine = (0, 4) if cfg_i == 2 else (1, 4)
     labels = np.array([f'obj_{i:06d}' for i in range(1, n_obj + 1)])
     pts = syn.make_mesh_points(7, n_obj, 2500)
     infos = {l: dict(label=l, n_points=2500, n_sym=1) for l in labels}
     mesh_db = BatchedMeshes(infos, labels, torch.from_numpy(pts), torch.eye(4).reshape(1, 1, 4, 4).repeat(n_obj, 1, 1, 1)).float().cuda()
-    frames = torch.from_numpy(syn.make_frames(seed, n_frames, h, w)).cuda()
-    K = torch.from_numpy(syn.make_K(n_frames, h, w)).cuda()
-    obj, im, boxes = syn.make_detections(seed + 10, D, n_frames, n_obj, h, w)
-    det = tc.PandasTensorCollection(infos=pd.DataFrame(dict(label=labels[obj], batch_im_id=im, score=1.0)),
-                                    bboxes=torch.from_numpy(boxes).cuda())
-    g = torch.Generator(device='cuda'); g.manual_seed(seed)
-    renders = [torch.rand(min(D, args.bsz_objects), 3, H, W, device='cuda', generator=g) for _ in range(5)]
+
+    # ---- workload
+    if cfg_i == 1:
+        D = args.detections or 256
+        h, w = (512, 512) if H == W else (480, 640)   # square frames for square crops
+        scenes = [make_scene(syn, torch, tc, pd, labels, 1 + rank, D, 16, h, w, n_obj)]      # each rank its own candidates (weak scaling)
+        total, scaling, per_rank = D * world, 'weak', [D] * world
+        desc = f'BASELINE configs[1]: {D} detections/GPU over 16 frames {h}x{w}, {n_obj} objects'
+    elif cfg_i == 2:
+        D = args.detections or 1024
+        scenes = [make_scene(syn, torch, tc, pd, labels, 2, D, 64, 540, 720, n_obj, with_poses=True)]
+        total, scaling = D, 'strong'
+        per_rank = [len(p) for p in plan_shards(D, world)]
+        desc = f'BASELINE configs[2]: {D} candidates over 64 frames 540x720, {n_obj} objects (T-LESS shape), refiner-only from given poses'
+    else:
+        D = args.detections or 2048
+        sizes = [(480, 640)] * 5 + [(540, 720), (960, 1280)]
+        share = [D // 7 + (1 if g < D % 7 else 0) for g in range(7)]
+        scenes = [make_scene(syn, torch, tc, pd, labels, 30 + g, share[g], 8, hh, ww, n_obj) for g, (hh, ww) in enumerate(sizes)]
+        total, scaling = D, 'strong'
+        if args.split == 'skewed':
+            frac = np.array(SKEW[:world] if world <= 8 else SKEW + [64] * (world - 8), dtype=np.float64)
+            cnt = np.floor(frac / frac.sum() * D).astype(int); cnt[0] += D - cnt.sum()
+            plan_kw = dict(balance='counts', counts=cnt.tolist())
+        else:
+            plan_kw = dict(balance='cost')
+        per_rank = [len(p) for p in plan_shards(D, world, **plan_kw)]
+        desc = (f'BASELINE configs[3]: {D} candidates over 7 datasets (5x 640x480, 720x540, 1280x960 frames), {n_obj} objects, '
+                f'{args.split} shares {per_rank}')
+    cap = min(max(per_rank), args.bsz_objects)
+    g = torch.Generator(device='cuda'); g.manual_seed(1 + rank)
+    renders = [torch.rand(cap, 3, H, W, device='cuda', generator=g) for _ in range(5)]
     renderer = SyntheticRenderer(renders)
     if args.renderer == 'hip':
         from cosypose_amd.rasterizer import RenderMeshes, HipBatchRenderer
         mv, mf, mc = syn.make_render_meshes(7, n_obj, n_lat=48, n_lon=64)        # 6,016 triangles per object
         renderer = HipBatchRenderer(RenderMeshes(labels, mv, mf, mc).cuda())
-    coarse = build_model(0, mesh_db, (H, W), args.dtype, renderer)
-    refiner = build_model(1, mesh_db, (H, W), args.dtype, renderer)
+    coarse = build_model(0, mesh_db, (H, W), dtype, renderer)
+    refiner = build_model(1, mesh_db, (H, W), dtype, renderer)
     predictor = CoarseRefinePosePredictor(coarse_model=coarse, refiner_model=refiner, bsz_objects=args.bsz_objects)
-    n_coarse, n_refine = 1, 4
-    iters_per_step = D * (n_coarse + n_refine)
+    iters_total = total * (n_coarse + n_refine)
+    gather_us = []
 
     def step():
-        final, _ = predictor.get_predictions(frames, K, detections=det, n_coarse_iterations=n_coarse, n_refiner_iterations=n_refine)
-        poses = final.poses
-        if world > 1:
-            poses = all_gather_rows(poses, max_rows=D)   # ONE collective: refined poses of all ranks, rank order
+        t_g = None
+        if cfg_i == 1:
+            frames, K, det = scenes[0]
+            final, _ = predictor.get_predictions(frames, K, detections=det, n_coarse_iterations=n_coarse, n_refiner_iterations=n_refine)
+            poses = final.poses
+            if world > 1:
+                torch.cuda.synchronize(); t_g = time.perf_counter()
+                poses = all_gather_rows(poses, counts=per_rank)   # ONE collective: refined poses of all ranks, rank order
+        elif cfg_i == 2:
+            frames, K, init = scenes[0]
+            final, _ = get_predictions_sharded(predictor, frames, K, data_TCO_init=init, n_coarse_iterations=0, n_refiner_iterations=n_refine)
+            poses = final.poses
+        else:
+            poses, _ = get_predictions_sharded_scenes(predictor, scenes, n_coarse, n_refine, **plan_kw)
+        if t_g is not None:
+            torch.cuda.synchronize(); gather_us.append((time.perf_counter() - t_g) * 1e6)
         return poses
 
     def sync():
@@ -161,9 +233,10 @@ def main():
     for _ in range(args.warmup):
         out = step()
     assert torch.isfinite(out).all(), 'non-finite refined poses'
-    assert out.shape == (world * D, 4, 4)
-    nets = [coarse._net(min(D, args.bsz_objects), frames.device), refiner._net(min(D, args.bsz_objects), frames.device)]
+    assert out.shape == (total, 4, 4)
+    nets = [m._net(cap, out.device) for m in ([refiner] if cfg_i == 2 else [coarse, refiner])]
     profile = not args.no_profile
+    gather_us.clear()
     sync()
     t0 = time.perf_counter()
     host_ms = []
@@ -196,65 +269,81 @@ def main():
         for n_ in nets:
             recs += _lib.profile_read(n_)
             _lib.check(_lib.lib().cosy_effnet_b3_set_profiling(n_, 0))
-        kinds = {}
-        for r in recs:
-            k = kinds.setdefault(r['name'], dict(ms=0.0, bytes=0.0, flops=0.0, n=0))
-            k['ms'] += r['ms_avg'] * r['n']; k['bytes'] += r['bytes'] * r['n']; k['flops'] += r['flops'] * r['n']; k['n'] += r['n']
-        total_ms = sum(k['ms'] for k in kinds.values())
-        if args.layers:
-            per = {}
-            for r in recs:   # a chunked segment launches the same layer several times per forward: aggregate
-                k = per.setdefault((r['layer'], r['name']), dict(ms=0.0, bytes=0.0, flops=0.0, n=0))
+
+        def agg(key):
+            out = {}
+            for r in recs:
+                k = out.setdefault(key(r), dict(ms=0.0, bytes=0.0, flops=0.0, n=0))
                 k['ms'] += r['ms_avg'] * r['n']; k['bytes'] += r['bytes'] * r['n']; k['flops'] += r['flops'] * r['n']; k['n'] += r['n']
-            nfw = prof_steps * (n_coarse + n_refine)
+            return out
+        kinds = agg(lambda r: r['name'])
+        fams = agg(lambda r: r['name'].split('<')[0].split('+')[0])
+        total_ms = sum(k['ms'] for k in kinds.values())
+        n_fw = sum(r['n'] for r in recs if r['name'].startswith('stem_kernel'))      # forwards timed
+        if args.layers:
+            per = agg(lambda r: (r['layer'], r['name']))
             for (layer, name), k in per.items():
-                print(f"{layer:3d} {name:34s} n={k['n']:4d} {k['ms'] / nfw * 1e3:9.1f} us/fwd  {k['bytes'] / k['ms'] / 1e6:8.1f} GB/s "
+                print(f"{layer:3d} {name:34s} n={k['n']:4d} {k['ms'] / max(n_fw, 1) * 1e3:9.1f} us/fwd  {k['bytes'] / k['ms'] / 1e6:8.1f} GB/s "
                       f"{k['flops'] / k['ms'] / 1e9:8.1f} TFLOP/s", file=sys.stderr)
-            for name, k in sorted(kinds.items(), key=lambda kv: -kv[1]['ms']):
-                print(f"{name:34s} {100 * k['ms'] / total_ms:5.1f}%  avg {k['ms'] / k['n'] * 1e3:8.1f} us  {k['bytes'] / k['ms'] / 1e6:8.1f} GB/s "
-                      f"{k['flops'] / k['ms'] / 1e9:8.1f} TFLOP/s", file=sys.stderr)
-        name, k = max(kinds.items(), key=lambda kv: kv[1]['ms'])
-        intensity = k['flops'] / k['bytes']
-        balance = MFMA_PEAK_TFLOPS[args.dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
-        if intensity < balance:
-            ach = k['bytes'] / k['ms'] / 1e6
-            roofline = dict(bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4))
-        else:
-            ach = k['flops'] / k['ms'] / 1e9
-            roofline = dict(bound='mfma', achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS[args.dtype], unit='TFLOP/s',
-                            frac=round(ach / MFMA_PEAK_TFLOPS[args.dtype], 4))
-        traffic = None   # HBM bytes per launch from the committed PMC passes of the same command (profiles/collect.sh)
-        tfile = os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')
-        if os.path.exists(tfile) and args.crop == '256x256' and args.dtype == 'bf16' and D == 256:
-            t = json.load(open(tfile)).get(name)
-            if t:
-                traffic = round(t['read_bytes'] + t['write_bytes'])
-        roofline.update(traffic=traffic, kernel=name, launches_timed=k['n'], avg_launch_us=round(k['ms'] / k['n'] * 1e3, 2),
-                        algorithmic_bytes_per_launch=round(k['bytes'] / k['n']), algorithmic_flops_per_launch=round(k['flops'] / k['n']),
-                        share_of_backbone_time=round(k['ms'] / total_ms, 4),
-                        backbone_ms_per_forward=round(total_ms / (prof_steps * (n_coarse + n_refine)), 3))
+            for table in (fams, kinds):
+                for name, k in sorted(table.items(), key=lambda kv: -kv[1]['ms']):
+                    print(f"{name:34s} {100 * k['ms'] / total_ms:5.1f}%  avg {k['ms'] / k['n'] * 1e3:8.1f} us  {k['bytes'] / k['ms'] / 1e6:8.1f} GB/s "
+                          f"{k['flops'] / k['ms'] / 1e9:8.1f} TFLOP/s", file=sys.stderr)
+
+        def line(name, k):
+            intensity = k['flops'] / k['bytes']
+            balance = MFMA_PEAK_TFLOPS[dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
+            if intensity < balance:
+                ach = k['bytes'] / k['ms'] / 1e6
+                d = dict(bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4))
+            else:
+                ach = k['flops'] / k['ms'] / 1e9
+                d = dict(bound='mfma', achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS[dtype], unit='TFLOP/s', frac=round(ach / MFMA_PEAK_TFLOPS[dtype], 4))
+            d.update(kernel=name, launches_timed=k['n'], avg_launch_us=round(k['ms'] / k['n'] * 1e3, 2),
+                     algorithmic_bytes_per_launch=round(k['bytes'] / k['n']), algorithmic_flops_per_launch=round(k['flops'] / k['n']),
+                     share_of_backbone_time=round(k['ms'] / total_ms, 4))
+            return d
+        fam_name, fam = max(fams.items(), key=lambda kv: kv[1]['ms'])
+        members = {n: k for n, k in kinds.items() if n.split('<')[0].split('+')[0] == fam_name}
+        inst_name, inst = max(members.items(), key=lambda kv: kv[1]['ms'])
+        roofline = line(inst_name, inst)                       # the dominant instantiation of the dominant family
+        roofline['family'] = line(fam_name, fam)               # ... and the whole family (every instantiation together)
+        roofline['traffic'] = None
+        tfile = os.path.join(REPO, 'profiles', 'r02_pmc_traffic.json')
+        note = 'HBM counters need rocprofv3 (separate process): see profiles/collect.sh'
+        if os.path.exists(tfile) and cfg_i == 1 and args.crop == '256x256' and dtype == 'bf16' and (args.detections or 256) == 256:
+            tj = json.load(open(tfile))
+            if tj.get('csrc_sha') == csrc_sha() and inst_name in tj.get('kernels', {}):
+                t = tj['kernels'][inst_name]
+                roofline['traffic'] = round(t['read_bytes'] + t['write_bytes'])
+                note = f"profiles/r02_pmc_traffic.json (PMC passes of this command on kernel sources {tj['csrc_sha']})"
+            else:
+                note = 'profiles/r02_pmc_traffic.json was collected for other kernel sources: not reported'
+        roofline['traffic_source'] = note
+        roofline['backbone_ms_per_forward'] = round(total_ms / max(n_fw, 1), 3)
 
     if rank == 0:
-        value = world * iters_per_step * args.steps / dt
-        mb = ALGO_MB_PER_POSE_ITER.get((args.dtype, H))
-        line = {
-            'metric': 'refined pose-iterations/sec (256x256 crops, n_iter=1+4)' if H == W else f'refined pose-iterations/sec ({H}x{W} crops, n_iter=1+4)',
+        value = iters_total * args.steps / dt
+        mb = ALGO_MB_PER_POSE_ITER.get((dtype, H))
+        line_ = {
+            'metric': 'refined pose-iterations/sec (256x256 crops, n_iter=1+4)' if (H == W and cfg_i != 2) else
+                      f'refined pose-iterations/sec ({H}x{W} crops, n_iter={n_coarse}+{n_refine})',
             'value': round(value, 1), 'unit': 'pose-iterations/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'BASELINE configs[1]: {D} detections/GPU over {n_frames} frames {h}x{w}, {n_obj} objects, '
-                                   f'coarse {n_coarse} + refiner {n_refine} iterations, {H}x{W} crops, ' +
+            'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
+            'dtype': dtype, 'data': 'synthetic',
+            'config': {'workload': desc + f', coarse {n_coarse} + refiner {n_refine} iterations, {H}x{W} crops, ' +
                                    ('synthetic on-device renders' if args.renderer == 'pregenerated' else
                                     'renders by the on-device HIP rasteriser (6k-triangle meshes) inside the loop'),
-                       'pose_iterations_per_step_per_gpu': iters_per_step, 'bsz_objects': args.bsz_objects,
-                       'parallelism': f'candidate-sharded x{world}, 1 all-gather of refined poses per step'},
+                       'pose_iterations_per_step': iters_total, 'candidates_per_rank': per_rank, 'bsz_objects': args.bsz_objects,
+                       'parallelism': f'candidate-sharded x{world}, 1 all-gather of refined poses per step',
+                       'all_gather_us': round(float(np.median(gather_us)), 1) if gather_us else None},
             'roofline': roofline,
             'path_hbm_frac': round(value / world * mb * 1e6 / (HBM_PEAK_GBS * 1e9), 5) if mb else None,
             'cpu_baseline': None,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline((H, W))
-        print(json.dumps(line), flush=True)
+            line_['cpu_baseline'] = cpu_baseline((H, W))
+        print(json.dumps(line_), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -283,3 +283,38 @@ def get_predictions_sharded(predictor, images, K, detections=None, data_TCO_init
         out['external_coarse'] = data_TCO_init
     last = keys[-1] if keys else 'external_coarse'
     return out[last], out
+
+
+def get_predictions_sharded_scenes(predictor, scenes, n_coarse_iterations=1, n_refiner_iterations=1, balance='contiguous', costs=None,
+                                   counts=None, rank=None, world_size=None, gather_rows=None):
+    """The sharded driver for a MIX of frame sizes (BASELINE configs[3]: seven datasets with different cameras): `scenes` is
+    a list of (images (N_g,3,h_g,w_g), K (N_g,3,3), table_g) -- one entry per frame size, `table_g` a detection table or a
+    data_TCO_init table whose batch_im_id index that group's frames.  The candidates of all groups form ONE global list
+    (group after group) that is partitioned by `plan_shards`; a rank runs its candidates group by group and the refined
+    poses of everything come back with ONE byte all-gather.  Returns (poses (D,4,4) in global candidate order, the plan)."""
+    rank = get_rank() if rank is None else rank
+    world = get_world_size() if world_size is None else world_size
+    sizes = [len(t) for _, _, t in scenes]
+    n = int(sum(sizes))
+    plan = plan_shards(n, world, balance, costs=costs, counts=counts)
+    mine = plan[rank]
+    edges = np.concatenate([[0], np.cumsum(sizes)])
+    kw = dict(n_coarse_iterations=n_coarse_iterations, n_refiner_iterations=n_refiner_iterations)
+    device = scenes[0][0].device
+    parts = []
+    for g, (images, K, table) in enumerate(scenes):
+        ids = mine[(mine >= edges[g]) & (mine < edges[g + 1])] - edges[g]
+        if len(ids) == 0:
+            continue
+        final, _ = run_shard(predictor, images, K, table, ids, **kw)
+        parts.append(final.poses.reshape(len(ids), 16))
+    local = torch.cat(parts) if parts else torch.zeros(0, 16, device=device)
+    shard_counts = [len(p) for p in plan]
+    rows = _as_byte_rows(local.float())
+    full = gather_rows(rows, shard_counts) if gather_rows is not None else all_gather_rows(rows, counts=shard_counts)
+    order = np.concatenate(plan) if n else np.zeros(0, np.int64)
+    poses = full.contiguous().view(torch.float32).reshape(-1, 4, 4)
+    if n and not np.array_equal(order, np.arange(n)):
+        inv = np.empty(n, np.int64); inv[order] = np.arange(n)
+        poses = poses[torch.as_tensor(inv, device=poses.device)]
+    return poses, plan

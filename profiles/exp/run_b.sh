@@ -1,5 +1,4 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python bench.py --steps 6 --warmup 2 --no-cpu-baseline --layers > gpurun_out/rb_ship.json 2> gpurun_out/rb_ship.txt
-python -c "import json;d=json.load(open('gpurun_out/rb_ship.json'));print(d['value'], d['ms_per_step'], d['roofline'])"
-python bench.py --steps 6 --warmup 2 --no-cpu-baseline --dtype fp16 > gpurun_out/rb_ship_fp16.json 2>/dev/null; python -c "import json;d=json.load(open('gpurun_out/rb_ship_fp16.json'));print('fp16', d['value'])"
-python bench.py --steps 6 --warmup 2 --no-cpu-baseline --crop 240x320 > gpurun_out/rb_ship_240.json 2>/dev/null; python -c "import json;d=json.load(open('gpurun_out/rb_ship_240.json'));print('240x320', d['value'])"
+python bench.py --steps 4 --warmup 1 > gpurun_out/b_c1.json 2> gpurun_out/b_c1.err; tail -c 1500 gpurun_out/b_c1.json; tail -3 gpurun_out/b_c1.err
+python bench.py --config 2 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/b_c2.json 2> gpurun_out/b_c2.err; cut -c1-900 gpurun_out/b_c2.json; tail -3 gpurun_out/b_c2.err
+python bench.py --config 3 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/b_c3.json 2> gpurun_out/b_c3.err; cut -c1-900 gpurun_out/b_c3.json; tail -3 gpurun_out/b_c3.err
+python bench.py --config 3 --split balanced --steps 2 --warmup 1 --no-cpu-baseline --no-profile > gpurun_out/b_c3b.json 2> gpurun_out/b_c3b.err; cut -c1-400 gpurun_out/b_c3b.json; tail -3 gpurun_out/b_c3b.err

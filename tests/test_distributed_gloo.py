@@ -193,3 +193,27 @@ def test_plan_shards_and_simulated_ranks():
             _, out = get_predictions_sharded(pred, images, K, detections=det, n_coarse_iterations=1, n_refiner_iterations=2, rank=r,
                                              world_size=world, gather_rows=gather, **kw)
             assert _same(out, ref)
+
+
+def test_sharded_scenes_mixed_frame_sizes_simulated_ranks():
+    """configs[3]'s driver: candidates over several frame sizes form one global list; contiguous, skewed ('counts') and
+    balanced ('cost') plans all give the single-process poses bit for bit (the collective replaced by an in-process concat)."""
+    from cosypose_amd.distributed import get_predictions_sharded_scenes
+    scenes = []
+    for D, nf in ((11, 3), (7, 2), (9, 4)):
+        det, images, K = _global_table(D, nf)
+        scenes.append((images, K, det))
+    pred = FakePredictor()
+    ref = torch.cat([pred.get_predictions(i, k, detections=t, n_coarse_iterations=1, n_refiner_iterations=2)[0].poses for i, k, t in scenes])
+    world = 4
+    for kw in (dict(balance='contiguous'), dict(balance='counts', counts=[12, 8, 5, 2]), dict(balance='cost', costs=np.arange(27) % 4 + 1.0)):
+        local_rows = []
+        for r in range(world):      # what every rank would contribute
+            grabbed = []
+            get_predictions_sharded_scenes(pred, scenes, 1, 2, rank=r, world_size=world,
+                                           gather_rows=lambda l, c: (grabbed.append(l), torch.zeros(sum(c), l.shape[1], dtype=torch.uint8))[1], **kw)
+            local_rows.append(grabbed[0])
+        for r in (0, 3):
+            poses, plan = get_predictions_sharded_scenes(pred, scenes, 1, 2, rank=r, world_size=world,
+                                                         gather_rows=lambda l, c: torch.cat(local_rows), **kw)
+            assert torch.equal(poses, ref) and sum(len(p) for p in plan) == 27
