@@ -1,4 +1,5 @@
-python bench.py --steps 4 --warmup 1 > gpurun_out/b_c1.json 2> gpurun_out/b_c1.err; tail -c 1500 gpurun_out/b_c1.json; tail -3 gpurun_out/b_c1.err
-python bench.py --config 2 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/b_c2.json 2> gpurun_out/b_c2.err; cut -c1-900 gpurun_out/b_c2.json; tail -3 gpurun_out/b_c2.err
-python bench.py --config 3 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/b_c3.json 2> gpurun_out/b_c3.err; cut -c1-900 gpurun_out/b_c3.json; tail -3 gpurun_out/b_c3.err
-python bench.py --config 3 --split balanced --steps 2 --warmup 1 --no-cpu-baseline --no-profile > gpurun_out/b_c3b.json 2> gpurun_out/b_c3b.err; cut -c1-400 gpurun_out/b_c3b.json; tail -3 gpurun_out/b_c3b.err
+export COSY_DIST_BACKEND=gloo
+for c in "--config 1" "--config 2" "--config 3" "--config 3 --split balanced"; do
+  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 2 --warmup 1 --no-profile $c > gpurun_out/b2.json 2> gpurun_out/b2.err
+  echo "rc=$? $c"; cut -c1-200 gpurun_out/b2.json; python -c "import json;d=json.load(open('gpurun_out/b2.json'));print(d['config']['candidates_per_rank'], d['config']['all_gather_us'], d['scaling'])"; grep -i "error\|Traceback" gpurun_out/b2.err | head -3
+done

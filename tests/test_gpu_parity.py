@@ -883,6 +883,36 @@ def test_roi_align_handmade_fixtures():
     assert np.abs(got2 - want).max() < 2e-6 * scale
 
 
+def test_ddp_two_ranks_on_one_gpu():
+    """h_pose through a DistributedDataParallel wrapper (train_pose.py:246), two ranks with different batches (gloo, both on
+    this GPU): after backward both ranks hold the SAME gradients, equal to the mean of what each rank computes alone --
+    i.e. DDP.forward ran and armed the reducer (calling model.module directly would leave per-rank gradients)."""
+    import socket
+    import torch.multiprocessing as mp
+    import ddp_worker
+
+    def launch(world, ranks):
+        ctx = mp.get_context('spawn')
+        q = ctx.Queue()
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        procs = [ctx.Process(target=ddp_worker.main, args=(r, world, port, q)) for r in ranks]
+        for p in procs:
+            p.start()
+        res = sorted((q.get(timeout=300) for _ in ranks), key=lambda t: t[0])
+        for p in procs:
+            p.join(60)
+        assert all(r[1] is not None for r in res)
+        return res
+    pair = launch(2, [0, 1])
+    solo0 = launch(1, [0])[0]
+    g0, g1 = pair[0][2], pair[1][2]
+    assert pair[0][1] != pair[1][1]                                       # different batches -> different losses
+    worst = max(abs(g0[n][0] - g1[n][0]) / max(g0[n][1], 1e-12) for n in g0)
+    assert worst < 1e-6, worst                                            # identical gradients on both ranks
+    differs = max(abs(g0[n][0] - solo0[2][n][0]) / max(solo0[2][n][1], 1e-12) for n in g0)
+    assert differs > 1e-4                                                 # ... and they are not rank 0's own gradients
+
+
 def test_training_reference_loop_unchanged_and_deterministic(golden_train, golden_sd):
     """the reference's own loop (train_pose.py:317-331: zero_grad / h / backward / clip_grad_norm_ / torch.optim.Adam.step)
     runs unchanged on a cosypose_amd model and lands on the same weights as the fused FlatAdam path after 2 steps;
