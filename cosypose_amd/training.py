@@ -1,0 +1,164 @@
+"""The loop around the training step: learning-rate schedule, checkpoints, epochs.
+
+Contract (cosypose/training/train_pose.py):
+  * schedule (:282-299): Adam at `lr`; during the first `n_epochs_warmup` epochs the rate ramps linearly PER BATCH,
+    lr * (b + 1) / n_batches_warmup after the b-th optimizer step (a LambdaLR stepped once per batch); from then on it is
+    divided by 10 every `lr_epoch_decay` epochs (a StepLR stepped at the end of every epoch >= n_epochs_warmup).  Both torch
+    schedulers act on the same optimizer in "chained" form; `LRSchedule` is the same state machine -- including the state a
+    resumed run starts from (:286, :297-298: warm-up counter = start_epoch * batches_per_epoch, StepLR stepped once).
+  * checkpoint (:54-61, :260-275): `checkpoint.pth.tar` = {'state_dict': module.state_dict(), 'epoch': epoch}, written after
+    every epoch; resuming loads the state_dict and continues at epoch + 1.  Optimizer moments are NOT part of the format
+    (a resumed run restarts Adam's statistics, as in the reference).
+  * step (:317-331): zero_grad -> h_pose -> backward -> clip_grad_norm_(clip_grad_norm) -> Adam.step, then the warm-up
+    scheduler; with `FlatAdam` clip + Adam are two fused launches on the flat buffers and the gradient all-reduce of a
+    multi-rank run is one RCCL call (or pass a DistributedDataParallel model and let DDP do it).
+Datasets, samplers and evaluation are out of scope: `train_loop` takes any iterable of batches.
+"""
+import pathlib
+from collections import defaultdict
+
+import torch
+
+from . import train_engine
+from .pose_forward_loss import h_pose
+
+
+class LRSchedule:
+    """The learning rate of every optimizer step, as a small state machine that reproduces what the reference's two chained
+    torch schedulers do to the optimizer (train_pose.py:284-299, :331-334), INCLUDING what happens on resume:
+
+        fresh run   : ramp lr*(s+1)/n_warm_batches over the warm-up steps s, ending one notch ABOVE lr (the LambdaLR is
+                      stepped once more after the last warm-up batch: lr*(n+1)/n), then x0.1 every `lr_epoch_decay` epochs
+                      counted from the END of the warm-up;
+        resumed run : the LambdaLR's constructor leaves lr at lr/n_warm_batches and nothing resets it once the warm-up is
+                      over, and the StepLR restarts its counter at start_epoch (one decay at most is applied at start).
+
+    `faithful=True` (default) is that behaviour, bit for bit (tests/test_host_logic.py drives torch's schedulers in the
+    reference's order beside it).  `faithful=False` is the evident intent: the fresh-run schedule as a pure function of the
+    global step, so that a resumed run continues where the interrupted one left off."""
+
+    def __init__(self, lr, n_epochs_warmup, batches_per_epoch, lr_epoch_decay, start_epoch=0, gamma=0.1, faithful=True):
+        self.base, self.n_warm, self.bpe, self.decay, self.gamma, self.faithful = float(lr), int(n_epochs_warmup), int(batches_per_epoch), int(lr_epoch_decay), gamma, faithful
+        self.nbw = self.n_warm * self.bpe
+        self.start_epoch = int(start_epoch)
+        # state after the reference's construction sequence
+        self.warm_counter = self.start_epoch * self.bpe                 # LambdaLR.last_epoch (overwritten after construction)
+        self.lr = self.base * self._lam(0)                              # LambdaLR's constructor applied lambda(0)
+        self.step_counter = self.start_epoch                            # StepLR.last_epoch after `last_epoch = start - 1; step()`
+        if self.step_counter > 0 and self.step_counter % self.decay == 0:
+            self.lr *= self.gamma
+
+    def _lam(self, counter):
+        return 1.0 if self.n_warm == 0 else (counter + 1) / self.nbw
+
+    def intended(self, epoch, batch):
+        """the fresh-run schedule as a function of the position in training"""
+        if self.n_warm and epoch < self.n_warm:
+            return self.base * (epoch * self.bpe + batch + 1) / self.nbw
+        top = self.base * ((self.nbw + 1) / self.nbw if self.n_warm else 1.0)
+        return top * self.gamma ** ((epoch - self.n_warm) // self.decay)
+
+    def current(self, epoch, batch):
+        return self.lr if self.faithful else self.intended(epoch, batch)
+
+    def after_batch(self, epoch):
+        if epoch < self.n_warm:                                         # lr_scheduler_warmup.step()
+            self.warm_counter += 1
+            self.lr = self.base * self._lam(self.warm_counter)
+
+    def after_epoch(self, epoch):
+        if epoch >= self.n_warm:                                        # lr_scheduler.step(), chainable form
+            self.step_counter += 1
+            if self.step_counter % self.decay == 0:
+                self.lr *= self.gamma
+
+    def apply(self, optimizer, epoch, batch):
+        v = self.current(epoch, batch)
+        if isinstance(optimizer, train_engine.FlatAdam):
+            optimizer.lr = v
+        else:
+            for g in optimizer.param_groups:
+                g['lr'] = v
+        return v
+
+
+def checkpoint_path(save_dir):
+    return pathlib.Path(save_dir) / 'checkpoint.pth.tar'
+
+
+def save_checkpoint(model, epoch, save_dir):
+    """{'state_dict', 'epoch'} exactly as the reference writes it (train_pose.py:54-61); DDP wrappers are unwrapped."""
+    save_dir = pathlib.Path(save_dir)
+    save_dir.mkdir(parents=True, exist_ok=True)
+    module = model.module if hasattr(model, 'module') else model
+    path = checkpoint_path(save_dir)
+    torch.save({'state_dict': {k: v.detach().cpu() for k, v in module.state_dict().items()}, 'epoch': int(epoch)}, path)
+    return path
+
+
+def load_checkpoint(path_or_dir, model, strict=True):
+    """Loads a reference-format checkpoint into `model`; returns the epoch to continue with (saved epoch + 1)."""
+    p = pathlib.Path(path_or_dir)
+    if p.is_dir():
+        p = checkpoint_path(p)
+    save = torch.load(p, map_location='cpu')
+    module = model.module if hasattr(model, 'module') else model
+    module.load_state_dict(save['state_dict'], strict=strict)
+    return int(save['epoch']) + 1
+
+
+def train_loop(model, mesh_db, cfg, batches, n_epochs, save_dir=None, start_epoch=0, optimizer=None, on_epoch_end=None,
+               input_generator='fixed', faithful_schedule=True):
+    """Runs epochs [start_epoch, n_epochs) of the reference's training loop on `batches` (a callable epoch -> iterable of
+    batch objects with images / K / TCO / objects / bboxes, or a re-iterable).  cfg: lr, weight_decay, n_epochs_warmup,
+    lr_epoch_decay, clip_grad_norm, n_iterations (+ what h_pose needs).  Returns {epoch: mean loss}."""
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    is_ddp = hasattr(model, 'module')
+    if optimizer is None:
+        optimizer = train_engine.FlatAdam(model.module if is_ddp else model, lr=cfg.lr, weight_decay=getattr(cfg, 'weight_decay', 0.0),
+                                          clip_grad_norm=cfg.clip_grad_norm)
+    flat = isinstance(optimizer, train_engine.FlatAdam)
+    history = {}
+    schedule = None
+    for epoch in range(start_epoch, n_epochs):
+        it = batches(epoch) if callable(batches) else batches
+        items = list(it) if schedule is None and not hasattr(it, '__len__') else it
+        if schedule is None:
+            schedule = LRSchedule(cfg.lr, cfg.n_epochs_warmup, len(items), cfg.lr_epoch_decay, start_epoch=start_epoch, faithful=faithful_schedule)
+        model.train()
+        meters = defaultdict(_Mean)
+        for b, sample in enumerate(items):
+            schedule.apply(optimizer, epoch, b)
+            optimizer.zero_grad()
+            loss = h_pose(model=model, mesh_db=mesh_db, data=sample, meters=meters, cfg=cfg, n_iterations=getattr(cfg, 'n_iterations', 1),
+                          input_generator=input_generator)
+            loss.backward()
+            if flat:
+                if world > 1 and not is_ddp:
+                    train_engine.allreduce_gradients(optimizer.grad)
+                meters['grad_norm'].add(float(optimizer.step()))
+            else:
+                params = (model.module if is_ddp else model).parameters()
+                meters['grad_norm'].add(float(torch.nn.utils.clip_grad_norm_(params, max_norm=cfg.clip_grad_norm, norm_type=2)))
+                optimizer.step()
+            schedule.after_batch(epoch)
+        schedule.after_epoch(epoch)
+        history[epoch] = meters['loss_total'].mean
+        if save_dir is not None and (not dist.is_initialized() or dist.get_rank() == 0):
+            save_checkpoint(model, epoch, save_dir)
+        if on_epoch_end is not None:
+            on_epoch_end(epoch, {k: m.mean for k, m in meters.items()})
+    return history
+
+
+class _Mean:
+    def __init__(self):
+        self.total, self.n = 0.0, 0
+
+    def add(self, v):
+        self.total += float(v); self.n += 1
+
+    @property
+    def mean(self):
+        return self.total / max(self.n, 1)

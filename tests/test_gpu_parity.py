@@ -883,6 +883,50 @@ def test_roi_align_handmade_fixtures():
     assert np.abs(got2 - want).max() < 2e-6 * scale
 
 
+def test_training_loop_checkpoint_and_resume(tmp_path, golden_sd):
+    """the loop around the step (cosypose/training/train_pose.py:282-343): warm-up ramp + step decay applied to
+    the optimizer, one reference-format checkpoint per epoch ({'state_dict', 'epoch'}, loadable strict=True into the
+    reference-keyed module), resume at epoch + 1, and a resumed run that walks on from the checkpointed weights."""
+    import argparse, types
+    from cosypose_amd import training, train_engine
+    B = 2
+    cfg = argparse.Namespace(n_points_loss=600, loss_disentangled=True, n_pose_dims=9, init_method='v0', lr=3e-4, weight_decay=0.0,
+                             n_epochs_warmup=1, lr_epoch_decay=1, clip_grad_norm=0.5, n_iterations=1)
+
+    def batches(epoch):
+        out = []
+        for b in range(2):
+            frames, K, TCO, obj = syn.make_training_batch(100 + 10 * epoch + b, B)
+            rs = np.random.RandomState(epoch * 7 + b)
+            xy = rs.uniform(150, 300, (B, 2)); wh = rs.uniform(80, 160, (B, 2))
+            out.append(types.SimpleNamespace(images=torch.from_numpy(frames), K=torch.from_numpy(K), TCO=torch.from_numpy(TCO),
+                                             objects=[dict(name=f'obj_{int(o) + 1:06d}') for o in obj],
+                                             bboxes=torch.from_numpy(np.concatenate([xy, xy + wh], 1).astype(np.float32))))
+        return out
+    model, mesh_db, _ = _train_model(golden_sd)
+    model.drop_connect_rate = 0.0
+    opt = train_engine.FlatAdam(model, lr=cfg.lr, clip_grad_norm=cfg.clip_grad_norm)
+    lrs = []
+    np.random.seed(0)
+    hist = training.train_loop(model, mesh_db, cfg, batches, n_epochs=3, save_dir=tmp_path, optimizer=opt,
+                               on_epoch_end=lambda e, m: lrs.append(opt.lr))
+    assert sorted(hist) == [0, 1, 2] and all(np.isfinite(v) for v in hist.values())
+    assert np.allclose(lrs, [3e-4 * 2 / 2, 3e-4 * 3 / 2, 3e-4 * 3 / 2 * 0.1])      # rate in force during the last batch of each epoch
+    save = torch.load(training.checkpoint_path(tmp_path), map_location='cpu')
+    assert sorted(save) == ['epoch', 'state_dict'] and save['epoch'] == 2
+    fresh, _, _ = _train_model(golden_sd)
+    start = training.load_checkpoint(tmp_path, fresh, strict=True)
+    assert start == 3
+    for (n1, p1), (n2, p2) in zip(model.state_dict().items(), fresh.state_dict().items()):
+        assert n1 == n2 and torch.equal(p1.cpu(), p2.cpu()), n1
+    before = {n: p.detach().clone() for n, p in fresh.named_parameters()}
+    np.random.seed(1)
+    fresh.drop_connect_rate = 0.0
+    hist2 = training.train_loop(fresh, mesh_db, cfg, batches, n_epochs=4, save_dir=tmp_path, start_epoch=start)
+    assert sorted(hist2) == [3] and torch.load(training.checkpoint_path(tmp_path), map_location='cpu')['epoch'] == 3
+    assert any(not torch.equal(before[n], p.detach()) for n, p in fresh.named_parameters())
+
+
 def test_ddp_two_ranks_on_one_gpu():
     """h_pose through a DistributedDataParallel wrapper (train_pose.py:246), two ranks with different batches (gloo, both on
     this GPU): after backward both ranks hold the SAME gradients, equal to the mean of what each rank computes alone --

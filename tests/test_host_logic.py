@@ -208,3 +208,48 @@ def test_io_formats_vs_reference_fixtures(tmp_path):
     assert out.read_text().split('\n')[0] == 'scene_id,im_id,obj_id,score,R,t,time'
     back = io_formats.read_csv_candidates(out)
     assert back.infos['label'].tolist() == infos['label'].tolist() and torch.allclose(back.poses, cand.poses, atol=1e-6)
+
+
+def test_lr_schedule_matches_the_reference_scheduler_sequence():
+    """training.LRSchedule (faithful mode) against torch's LambdaLR + StepLR driven exactly in the order of the reference
+    (cosypose/training/train_pose.py:284-299 construction incl. the resume fast-forward, :331-334 stepping), fresh and resumed,
+    with and without warm-up; and the `faithful=False` schedule continues across a resume."""
+    import warnings
+    from cosypose_amd.training import LRSchedule
+
+    def reference_sequence(lr, n_warm, bpe, decay, start_epoch, end_epoch):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p], lr=lr)
+        nbw = n_warm * bpe
+        lambd = (lambda e: 1) if n_warm == 0 else (lambda b: (b + 1) / nbw)
+        warm = torch.optim.lr_scheduler.LambdaLR(opt, lambd)
+        warm.last_epoch = start_epoch * bpe
+        sch = torch.optim.lr_scheduler.StepLR(opt, step_size=decay, gamma=0.1)
+        sch.last_epoch = start_epoch - 1
+        sch.step()
+        out = []
+        for e in range(start_epoch, end_epoch):
+            for _ in range(bpe):
+                out.append(opt.param_groups[0]['lr'])
+                opt.step()
+                if e < n_warm:
+                    warm.step()
+            if e >= n_warm:
+                sch.step()
+        return out
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for lr, n_warm, bpe, decay, start, end in [(1e-3, 2, 3, 2, 0, 8), (1e-3, 2, 3, 2, 3, 8), (1e-3, 0, 3, 2, 0, 6), (1e-3, 0, 3, 2, 4, 7),
+                                                   (3e-4, 2, 3, 2, 1, 5), (3e-4, 50, 4, 100, 0, 60), (3e-4, 50, 4, 100, 55, 60)]:
+            want = reference_sequence(lr, n_warm, bpe, decay, start, end)
+            sch = LRSchedule(lr, n_warm, bpe, decay, start_epoch=start)
+            got = []
+            for e in range(start, end):
+                for b in range(bpe):
+                    got.append(sch.current(e, b)); sch.after_batch(e)
+                sch.after_epoch(e)
+            assert np.allclose(got, want, rtol=1e-12, atol=0), (lr, n_warm, bpe, decay, start)
+    fresh = LRSchedule(1e-3, 2, 3, 2, faithful=False)
+    resumed = LRSchedule(1e-3, 2, 3, 2, start_epoch=5, faithful=False)
+    assert [fresh.current(e, b) for e in range(5, 8) for b in range(3)] == [resumed.current(e, b) for e in range(5, 8) for b in range(3)]
+    assert abs(fresh.current(1, 2) - 1e-3) < 1e-15 and abs(fresh.current(4, 0) - 1e-3 * 7 / 6 * 0.1) < 1e-15
