@@ -27,6 +27,7 @@ struct PwArgs {
     int M, K, N, HW;     // HW = rows per sample (for the gate)
     int silu;
     const void* zeros;   // >= 16 zero bytes (global): source of padded rows/k for the LDS-DMA pipeline; null -> classic kernel
+    int a_chunked;       // 1: A is laid out [sample][K/16][HW][16] (what the wave front writes: a wave's row is one contiguous run); DMA kernel only
 };
 int launch_pw_gemm(const PwArgs& a, PwCfg cfg, int dtype, hipStream_t s);
 void pw_kernel_name(const PwArgs& a, PwCfg c, int dtype, char* buf, size_t n);

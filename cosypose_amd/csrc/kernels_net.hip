@@ -98,6 +98,7 @@ struct PwKArgs {
     int M, K, N, HW, silu, MT, NT, nkb_total, nkb_valid;
     const void* zeros;
     int nsamp, rowgate;   // DMA kernel gate: samples under one m-tile; 1 = gate the activation fragments per row
+    int a_chunked;        // A is [sample][K/16][HW][16] (see PwArgs)
 };
 
 template <typename T, int NI, int WN>
@@ -309,6 +310,13 @@ __global__ __launch_bounds__(NWV * 64) void pw_gemm_dma_kernel(PwKArgs a) {
         __syncthreads();
     }
 
+    // chunked A ([sample][K/16][HW][16]): element offset of this lane's row at k = 0, per DMA slot
+    size_t achunk[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const int m = min(m0 + (i * NWV + wave) * 16 + row, M - 1), bs = m / a.HW;
+        achunk[i] = a.a_chunked ? ((size_t)bs * (K >> 4) * a.HW + (m - bs * a.HW)) * 16 : 0;
+    }
     auto issue = [&](int kb) {
         char* st = lds + (kb % NS) * NB * 1024;
 #pragma unroll
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(NWV * 64) void pw_gemm_dma_kernel(PwKArgs a) {
                 dst = st + blk * 1024;
                 if (blk < NA) {
                     const int m = m0 + blk * 16 + row, k = kb * KB + kg * EPL;
-                    if (m < M && k < K) src = A + (size_t)m * K + k;
+                    if (m < M && k < K) src = a.a_chunked ? A + achunk[i] + (size_t)(k >> 4) * a.HW * 16 + (k & 15) : A + (size_t)m * K + k;
                 } else {
                     src = Wp + ((size_t)(nt * NW + (blk - NA)) * a.nkb_total + kb) * 64 * EPL + lane * EPL;
                 }
@@ -513,12 +521,14 @@ static int launch_pw_dma(const PwKArgs& k, PwCfg c, int grid, hipStream_t s) {
 template <typename T>
 static int launch_pw_t(const PwArgs& a, PwCfg c, int dtype, hipStream_t s) {
     PwKArgs k;
+    k.a_chunked = a.a_chunked;
     k.A = a.A; k.Wp = a.Wp; k.out = a.out; k.scale = a.scale; k.bias = a.bias; k.res = a.res; k.gate = a.gate;
     k.M = a.M; k.K = a.K; k.N = a.N; k.HW = a.HW; k.silu = a.silu;
     k.MT = cdiv(a.M, pw_bm(c)); k.NT = cdiv(a.N, pw_bn(c));
     k.nkb_total = pw_nkb_total(a.K, dtype); k.nkb_valid = cdiv(a.K, pw_kb(dtype));
     const int grid = cdiv(k.MT, 8) * 8 * k.NT;
     k.zeros = a.zeros; k.nsamp = 2; k.rowgate = 0;
+    if (a.a_chunked && (!pw_use_dma(a) || a.K % 16)) { set_error("pw_gemm: the chunked activation layout needs the DMA kernel and K %% 16 == 0 (K=%d)", a.K); return COSY_EINVAL; }
     if (pw_use_dma(a)) return a.gate ? launch_pw_dma<T, true>(k, c, grid, s) : launch_pw_dma<T, false>(k, c, grid, s);
     if (c.NI == 4 && c.WN == 2) hipLaunchKernelGGL((pw_gemm_kernel<T, 4, 2>), dim3(grid), dim3(256), 0, s, k);
     else if (c.NI == 3 && c.WN == 2) hipLaunchKernelGGL((pw_gemm_kernel<T, 3, 2>), dim3(grid), dim3(256), 0, s, k);

@@ -18,8 +18,9 @@
 //     ceil(KS/S) output rows it feeds (accumulators of the rows in flight), so no ring of expanded rows is kept; the row
 //     loop is unrolled S*ceil(KS/S) times so that every accumulator slot is a compile-time constant;
 //   * the block input is read as MFMA fragments straight from global memory one row ahead; per row the global memory
-//     operations are ordered [previous output row's stores] -> [next input row's loads] (vmcnt retires in order and the
-//     compiler waits with vmcnt(0): see mbconv_rows_kernel), so a wait never sees a store younger than one row;
+//     operations are issued right after the expansion, ordered [previous output row's stores] -> [next input row's loads]
+//     (vmcnt retires in order and the compiler waits with vmcnt(0): see mbconv_rows_kernel), so the wait in front of the
+//     next row's MFMAs only sees operations that are a whole depthwise phase old;
 //   * squeeze sums: per-lane registers over the whole image, one DPP tree per 16-lane row at the end (fixed order).
 // The 16*NI-channel chunks of one sample re-read the block input (x Cmid/16/NI through L2; it is the small tensor).
 #include "net_device.h"
@@ -64,6 +65,30 @@ template <bool SCALED> __device__ __forceinline__ void silu4(float* v) {
             "v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %5\n v_mul_f32 %2, %2, %6\n v_mul_f32 %3, %3, %7\n s_nop 0"
             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3));
     }
+}
+
+
+// Input fragment i of the wave kernel is loaded into a RESERVED register quad at the top of the kernel's VGPR budget,
+// v[TOP-4(i+1) : TOP-4i-1], and copied into ordinary registers behind the wait.  The compiler never sees a value whose load
+// is still in flight (given one, it copies it at the merge points of the row loop -- garbage).  The reservation is not
+// something hipcc can be told: the kernel only forces the allocation up to TOP with a clobber, and relies on the register
+// allocator filling from v0 upwards; profiles/check_wave_isa.py verifies on the built ISA that no compiler-generated
+// instruction touches the reserved range (tests/test_build_isa.py).  (AGPRs would be the natural home, but naming one in
+// inline asm makes hipcc split the budget 128 + 128 and spill through v_accvgpr_write.)
+template <int TOP, int I> __device__ __forceinline__ void xfrag_load(int voff, const char* sbase) {
+    asm volatile("global_load_dwordx4 v[%2:%3], %0, %1 ; XLOAD" :: "v"(voff), "s"(sbase), "n"(TOP - 4 * (I + 1)), "n"(TOP - 4 * I - 1) : "memory");
+}
+template <int TOP, int I> __device__ __forceinline__ f32x4 xfrag_read() {
+    float x0, x1, x2, x3;
+    asm volatile("v_mov_b32 %0, v[%4]\n v_mov_b32 %1, v[%5]\n v_mov_b32 %2, v[%6]\n v_mov_b32 %3, v[%7] ; XREAD"
+                 : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3)
+                 : "n"(TOP - 4 * (I + 1)), "n"(TOP - 4 * (I + 1) + 1), "n"(TOP - 4 * (I + 1) + 2), "n"(TOP - 4 * (I + 1) + 3));
+    return f32x4{x0, x1, x2, x3};
+}
+template <int MINW> __device__ __forceinline__ void xfrag_reserve() {
+    if constexpr (MINW == 2) asm volatile("; XRESERVE" ::: "v255");
+    else if constexpr (MINW == 3) asm volatile("; XRESERVE" ::: "v167");
+    else asm volatile("; XRESERVE" ::: "v127");
 }
 
 template <typename F, int... Us>
@@ -124,24 +149,43 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
 
     // Global addressing without per-row multiplies: a row's address = uniform row base + a per-lane byte offset that never
     // changes.  Lanes outside the row / channel range read a valid neighbour instead of a zero page: pixels beyond the row
-    // end are forced to zero after the expansion anyway, and the channel tail of the last k-block is cleared at its use.
+    // end are forced to zero after the expansion anyway, and the channel tail of the last k-block meets the zero padding of the
+    // packed weights (finite * 0).
+    const size_t xrow_bytes = (size_t)a.W * a.Cin * sizeof(T);
     int xoff[PPL][KBN];
-    bool kok[KBN];
 #pragma unroll
     for (int kb = 0; kb < KBN; ++kb) {
         const int k = kb * KB + kg * EPL;
-        kok[kb] = k < a.Cin;
 #pragma unroll
         for (int q = 0; q < PPL; ++q) xoff[q][kb] = (min(p * PPL + q, a.W - 1) * a.Cin + min(k, a.Cin - EPL)) * (int)sizeof(T);
     }
-    const size_t xrow_bytes = (size_t)a.W * a.Cin * sizeof(T);
-    raw_t xc[PPL][KBN];
+    // The input fragments are loaded by inline asm and waited for with a COUNTED s_waitcnt: vmcnt retires loads and stores
+    // in order, and hipcc, which cannot count stores across this loop's control flow, waits with vmcnt(0) -- i.e. for the
+    // acknowledgement of the output row stored a moment ago as well (knock-out timing: 30 % of block 3's time).  Here the
+    // next row's loads are issued FIRST and the previous output row's stores behind them, so vmcnt(#stores) in front of
+    // the next row's MFMAs covers the loads and leaves the stores in flight.
+    constexpr int XTOP = MINW == 2 ? 256 : MINW == 3 ? 168 : 128;
+    static_assert(MINW >= 2 && MINW <= 4);
+    xfrag_reserve<MINW>();
+    f32x4 xc[PPL][KBN];
+    int st_in_flight = 0;                    // stores issued behind the newest loads (wave-uniform)
     auto load_row = [&](int iy) {            // B fragments of input row iy: fragment q holds the lanes' pixels p*PPL + q
         const char* rowp = (const char*)X + (size_t)min(iy, a.H - 1) * xrow_bytes;    // rows below the map are never used
-#pragma unroll
-        for (int q = 0; q < PPL; ++q)
-#pragma unroll
-            for (int kb = 0; kb < KBN; ++kb) xc[q][kb] = *(const raw_t*)(rowp + xoff[q][kb]);
+        unroll_seq([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            xfrag_load<XTOP, i>(xoff[i / KBN][i % KBN], rowp);
+        }, std::make_integer_sequence<int, PPL * KBN>{});
+        st_in_flight = 0;
+    };
+    auto wait_row = [&]() {
+        constexpr int NST = (PPL / S) * NI;
+        if (st_in_flight) asm volatile("s_waitcnt vmcnt(%0) ; XWAIT" :: "n"(NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) ; XWAIT" ::: "memory");
+        unroll_seq([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            xc[i / KBN][i % KBN] = xfrag_read<XTOP, i>();
+        }, std::make_integer_sequence<int, PPL * KBN>{});
+        asm volatile("s_nop 1");             // VALU write -> MFMA read
     };
     // this job's output rows [oy_a, oy_b) and the input rows they need (rows above a band are recomputed, KS-S of them)
     const int oy_a = band * a.rows_per, oy_b = min(a.Ho, oy_a + a.rows_per);
@@ -160,18 +204,26 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     for (int c = 0; c < NCH; ++c) sum[c] = 0.f;
     out_t yv[TO][NI];                        // finished output row waiting for its store (issued one row later)
     int oy_pending = -1;
-    T* __restrict__ Dlane = (T*)a.D + (size_t)b * a.Ho * a.Wo * a.Cmid + c0 + kg * 4 + (size_t)(p * TO) * a.Cmid;   // + uniform row offset
-    const size_t drow = (size_t)a.Wo * a.Cmid;
+    // D is written in the CHUNKED layout [sample][Cmid/16][Ho*Wo][16]: this wave's output row is one contiguous run of
+    // Wo * 32 bytes, so every 128-byte line is completed by one wave within one row.  (In plain NHWC the four 32-byte quarters
+    // of a line belong to four different jobs that run at different times; with ~30 MB of half-written rows in flight per XCD
+    // the 4 MB L2 evicted them quarter by quarter -- 25 % of block 3's time by knock-out timing.)  The project GEMM reads
+    // this layout directly (PwArgs::a_chunked).
+    static_assert(NI == 1, "chunked D: one 16-channel chunk per job");
+    T* __restrict__ Dlane = (T*)a.D + ((size_t)(b * a.nchunks + ch) * a.Ho * a.Wo + p * TO) * 16 + kg * 4;   // + uniform row offset
+    const size_t drow = (size_t)a.Wo * 16;
     auto flush = [&]() {                     // store the pending output row
-        if (oy_pending >= 0) {
-            T* o = Dlane + (size_t)oy_pending * drow;
+        if (oy_pending >= 0 && !COSY_DBG(a.dbg & 1)) {      // dbg 1: no output stores (timing experiments)
+            T* o = Dlane + (size_t)(COSY_DBG(a.dbg & 8) ? 0 : oy_pending) * drow;      // dbg 8: every row lands on row 0
 #pragma unroll
             for (int t = 0; t < TO; ++t) {
+                if (COSY_DBG(a.dbg & 4) && t > 0) break;                                 // dbg 4: one store per row
                 if (FULLW || p * TO + t < a.Wo) {
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) *(out_t*)(o + (size_t)t * a.Cmid + ni * 16) = yv[t][ni];
+                    for (int ni = 0; ni < NI; ++ni) *(out_t*)(o + t * 16) = yv[t][ni];
                 }
             }
+            st_in_flight = 1;
         }
     };
 
@@ -182,6 +234,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
             if (iy < iy_first || iy > iy_last) return;
             // ---- A. expanded row iy (transient registers); its global loads were issued one row ago
             float Er[RP][NCH];
+            wait_row();
             if (iy < a.H) {
                 float sc0[NCH], bi0[NCH];
 #pragma unroll
@@ -193,11 +246,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
                         f32x4 m = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int kb = 0; kb < KBN; ++kb) {
-                            raw_t xv = xc[q][kb];
-                            if (kb == KBN - 1 && !kok[kb]) {          // channel tail of the last k-block (per-lane constant)
-#pragma unroll
-                                for (int e = 0; e < EPL; ++e) xv[e] = (T)0.f;
-                            }
+                            raw_t xv = __builtin_bit_cast(raw_t, xc[q][kb]);
                             mma(m, wf[ni][kb], xv);
                         }
                         float y4[4];
@@ -233,6 +282,11 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
                     }
                 }
             }
+            // ---- global memory, issued HERE (between the expansion and the depthwise work): the next input row's loads, then
+            // the previous output row's stores; both have this row's whole depthwise phase to complete, and the stores longer.
+            if (iy + 1 <= iy_last && !COSY_DBG(a.dbg & 2)) load_row(iy + 1);     // dbg 2: the first row's fragments are reused
+            flush();
+            oy_pending = -1;
             // ---- B. scatter the row into the output rows it feeds: input row iy is tap row ky of output row (iy + LO - ky) / S
             bool done = false;
             int oy_done = -1;
@@ -283,18 +337,13 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
                     done = true; oy_done = oy;
                 }
             }
-            // ---- C. global memory, in this order: the PREVIOUS output row's stores, then the next input row's loads.  The wait
-            // for those loads (next row's MFMA) is a vmcnt(0) that also covers these stores: both are one row old by then.
-            flush();
-            oy_pending = -1;
-            if (done) {
+            if (done) {                      // parked until the next row's memory block
 #pragma unroll
                 for (int t = 0; t < TO; ++t)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) yv[t][ni] = ynew[t][ni];
                 oy_pending = oy_done;
             }
-            if (iy + 1 <= iy_last) load_row(iy + 1);
         }, std::make_integer_sequence<int, U>{});
     }
     flush();

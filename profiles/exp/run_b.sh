@@ -1,5 +1,11 @@
-export COSY_DIST_BACKEND=gloo
-for c in "--config 1" "--config 2" "--config 3" "--config 3 --split balanced"; do
-  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 2 --warmup 1 --no-profile $c > gpurun_out/b2.json 2> gpurun_out/b2.err
-  echo "rc=$? $c"; cut -c1-200 gpurun_out/b2.json; python -c "import json;d=json.load(open('gpurun_out/b2.json'));print(d['config']['candidates_per_rank'], d['config']['all_gather_us'], d['scaling'])"; grep -i "error\|Traceback" gpurun_out/b2.err | head -3
-done
+export COSY_TUNE_LIB=1
+run() { # tag env...
+  tag=$1; shift
+  env "$@" python bench.py --steps 3 --warmup 1 --no-cpu-baseline --layers > gpurun_out/rb_$tag.json 2> gpurun_out/rb_$tag.txt
+  echo "== $tag: $(python -c "import json;print(json.load(open('gpurun_out/rb_$tag.json'))['value'])")"
+  grep -E "^ *([2-9]|1[0-7]) (mbconv)" gpurun_out/rb_$tag.txt | awk '{for(i=1;i<=NF;i++) if($i=="us/fwd") printf "%s:%s ", $1, $(i-1)} END {print ""}'
+}
+run base COSY_WAVE_DBG=0
+run nostore COSY_WAVE_DBG=1
+python profiles/exp/det.py 2>&1 | grep -v amdgpu | tail -6 | cut -c1-200
+COSY_TUNE_LIB= python -m pytest tests -m gpu -x -q 2>&1 | tail -5

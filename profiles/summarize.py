@@ -23,6 +23,7 @@ def short(name):
     toks, i = [], 0
     while i < len(targs):
         if targs.startswith('DF16b', i): toks.append('__bf16'); i += 5
+        elif targs.startswith('DF16_', i): toks.append('_Float16'); i += 5
         elif targs[i] == 'f': toks.append('float'); i += 1
         elif targs.startswith('Li', i):
             j = targs.index('E', i); toks.append(targs[i + 2:j]); i = j + 1
@@ -55,7 +56,14 @@ def main(root):
     traffic = {k: dict(read_bytes=2 * 1024 * sum(v['FETCH_SIZE']) / len(v['FETCH_SIZE']),
                        write_bytes=1024 * sum(v['WRITE_SIZE']) / len(v['WRITE_SIZE']), launches=len(v['FETCH_SIZE']))
                for k, v in agg.items() if v['FETCH_SIZE'] and v['WRITE_SIZE'] and not k.startswith('__amd')}
-    json.dump(traffic, open(f'{root}/pmc_traffic.json', 'w'), indent=1)
+    import hashlib, os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    d = os.path.join(here, 'cosypose_amd', 'csrc')
+    for fn in sorted(os.listdir(d)):
+        h.update(fn.encode()); h.update(open(os.path.join(d, fn), 'rb').read())
+    # csrc_sha ties the numbers to the kernel sources they were measured on (bench.py reports `traffic` only on a match)
+    json.dump(dict(csrc_sha=h.hexdigest()[:16], kernels=traffic), open(f'{root}/pmc_traffic.json', 'w'), indent=1)
     # matrix-core utilisation per kernel: rocprofv3's MfmaUtil (= sum SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * #SIMD), percent)
     # and the MFMA FLOP rate from SQ_INSTS_VALU_MFMA_MOPS_BF16 * 512 over the kernel's mean duration
     mf = defaultdict(lambda: defaultdict(list))
@@ -92,6 +100,9 @@ def main(root):
             wc = m['SQ_WAVE_CYCLES']
             extra.append(f"wait={m.get('SQ_WAIT_ANY', 0) / wc:.2f} waitinst={m.get('SQ_WAIT_INST_ANY', 0) / wc:.2f} "
                          f"valu={m.get('SQ_ACTIVE_INST_VALU', 0) / wc:.2f} vmem={m.get('SQ_ACTIVE_INST_VMEM', 0) / wc:.2f}")
+        if 'SQ_INSTS_VALU' in m and 'GRBM_GUI_ACTIVE' in m and m['GRBM_GUI_ACTIVE'] > 0:
+            # VALU wave-instructions per SIMD-cycle of the launch (1024 SIMDs): x ~3.1-8.7 issue cycles each = pipe occupancy
+            extra.append(f"valu/simd/cyc={m['SQ_INSTS_VALU'] / (m['GRBM_GUI_ACTIVE'] * 1024):.3f} ldsconf={m.get('SQ_LDS_BANK_CONFLICT', 0) / max(m.get('SQ_ACTIVE_INST_LDS', 1), 1):.2f}")
         if 'SQ_BUSY_CYCLES' in m and 'GRBM_GUI_ACTIVE' in m and m['GRBM_GUI_ACTIVE'] > 0:
             extra.append(f"gui={m['GRBM_GUI_ACTIVE']:.0f}")
         if 'TA_BUSY_avr' in m:
