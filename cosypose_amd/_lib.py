@@ -41,6 +41,9 @@ _SIGNATURES = {
     'cosy_dists_add': ([_P, _P, _P, _P, _I, _I, _I, _P, _P], _I),
     'cosy_render_scratch_bytes': ([_I, _I, _I, _I], _c.c_size_t),
     'cosy_render_meshes': ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P], _I),
+    'cosy_render_meshes_ex': ([_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P], _I),
+    'cosy_render_crop_pack': ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P], _I),
+    'cosy_render_crop_pack_to': ([_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P], _I),
     'cosy_train_workspace_bytes': ([], _c.c_size_t),
     'cosy_crop_pack_to': ([_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
     'cosy_bn_train_stats': ([_P, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P], _I),
@@ -63,6 +66,16 @@ _SIGNATURES = {
     'cosy_adam_step': ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P], _I),
 }
 EXPORTS = tuple(_SIGNATURES)
+
+
+class MeshSet(ctypes.Structure):       # cosy_mesh_t
+    _fields_ = [('verts', _P), ('colors', _P), ('normals', _P), ('uvs', _P), ('tex', _P), ('faces', _P), ('n_faces', _P),
+                ('V', _I), ('F', _I), ('TH', _I), ('TW', _I)]
+
+
+class Shade(ctypes.Structure):         # cosy_shade_t
+    _fields_ = [('ambient', _F), ('diffuse', _F), ('specular', _F), ('shininess', _F), ('light', _F * 3),
+                ('light_frame', _I), ('smooth', _I), ('quantize', _I)]
 
 
 class ProfRec(ctypes.Structure):

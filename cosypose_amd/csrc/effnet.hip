@@ -1,6 +1,7 @@
 // cosy_net_t: packed EfficientNet-B3(6ch) weights + activation workspace, and the layer schedule.
 // Also hosts the extern "C" boundary declared in include/cosyhip.h.
 #include "kernels_net.h"
+#include "raster_device.h"
 #include <math.h>
 #include <stdarg.h>
 #include <stdlib.h>
@@ -554,6 +555,15 @@ int cosy_crop_pack(cosy_net_t* n, const float* images, const int* im_id, const f
     COSY_REQUIRE(images && boxes_crop && renders, "crop_pack: null argument");
     COSY_REQUIRE(B >= 0 && B <= n->maxB, "crop_pack: batch %d exceeds max_batch %d", B, n->maxB);
     return launch_crop_pack(n->X, n->dtype, images, im_id, boxes_crop, renders, B, N, h, w, n->H, n->W, (hipStream_t)stream);
+}
+
+int cosy_render_crop_pack(cosy_net_t* n, const cosy_mesh_t* mesh, const cosy_shade_t* shade, const int* obj_id, const float* TCO,
+                          const float* K_crop, const float* frames_nhwc4, const int* im_id, const float* boxes_crop, int B, int N, int h,
+                          int w, void* scratch, cosy_stream_t stream) {
+    COSY_REQUIRE(n, "render_crop_pack: null net");
+    COSY_REQUIRE(B >= 0 && B <= n->maxB, "render_crop_pack: batch %d exceeds max_batch %d", B, n->maxB);
+    return render_crop_pack(n->X, n->dtype, mesh, shade, obj_id, TCO, K_crop, frames_nhwc4, im_id, boxes_crop, B, N, h, w, n->H, n->W, scratch,
+                            (hipStream_t)stream);
 }
 
 int cosy_effnet_b3_forward(cosy_net_t* n, int B, float* feat, float* pose9, float* taps, cosy_stream_t stream) {

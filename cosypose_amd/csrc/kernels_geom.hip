@@ -2,6 +2,7 @@
 // fp32 throughout; FMA contraction is disabled so that results are bit-comparable with the
 // CPU oracle (oracle/cosy_oracle.c), which restates the reference's torch arithmetic.
 #include "cosy_common.h"
+#include "raster_device.h"
 #include <math.h>
 
 #pragma clang fp contract(off)
@@ -335,6 +336,43 @@ __global__ __launch_bounds__(256) void crop_pack_kernel(T* __restrict__ x, const
     const float* r = renders + (size_t)b * 3 * PH * PW + pix;
     v[3] = r[0]; v[4] = r[(size_t)PH * PW]; v[5] = r[(size_t)2 * PH * PW];
     store_px8<T>(x + ((size_t)b * PH * PW + pix) * 8, v);
+}
+
+// render + crop + pack: the rasteriser's resolve pass and the crop in one kernel (one 16-byte store per pixel)
+template <typename T>
+__global__ __launch_bounds__(256) void render_crop_pack_kernel(T* __restrict__ x, const float* __restrict__ frames4,
+                                                               const int* __restrict__ im_id, const float* __restrict__ boxes,
+                                                               const unsigned long long* __restrict__ zbuf, const float* __restrict__ uvz,
+                                                               MeshView m, const int* __restrict__ obj, const float* __restrict__ TCO,
+                                                               ShadeParams sp, int B, int h, int w, int PH, int PW) {
+    const int id = blockIdx.x, xcd = id & 7, bpc = (PH * PW + 255) / 256;
+    const int j = id >> 3, b = (j / bpc) * 8 + xcd;
+    if (b >= B) return;
+    const int pix = (j % bpc) * 256 + threadIdx.x;
+    if (pix >= PH * PW) return;
+    const int ph = pix / PW, pw = pix % PW;
+    const float* bx = boxes + (size_t)b * 4;
+    const float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
+    const float roi_w = fmaxf(x2 - x1, 1.f), roi_h = fmaxf(y2 - y1, 1.f);
+    const float bin_h = roi_h / (float)PH, bin_w = roi_w / (float)PW;
+    const f32x4* img = (const f32x4*)frames4 + (size_t)(im_id ? im_id[b] : b) * h * w;
+    float v[6], zo;
+    roi_pixel_nhwc4(img, h, w, x1, y1, bin_h, bin_w, ph, pw, v);
+    resolve_pixel(zbuf[(size_t)b * PH * PW + pix], uvz + (size_t)b * m.V * 3, m, obj[b], TCO + (size_t)b * 16, pw, ph, sp, v + 3, zo);
+    store_px8<T>(x + ((size_t)b * PH * PW + pix) * 8, v);
+}
+
+int launch_render_crop_pack(void* x, int dtype, const float* frames4, const int* im_id, const float* boxes, const void* scratch,
+                            const MeshView& m, const int* obj, const float* TCO, const ShadeParams& sp, int B, int h, int w, int H, int W,
+                            hipStream_t s) {
+    if (B == 0) return COSY_OK;
+    const unsigned long long* zbuf = (const unsigned long long*)scratch;
+    const float* uvz = (const float*)(zbuf + (size_t)B * H * W);
+    dim3 grid((unsigned)(cdiv(H * W, 256) * cdiv(B, 8) * 8));
+    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(render_crop_pack_kernel<T>, grid, dim3(256), 0, s, (T*)x, frames4, im_id, boxes, zbuf, uvz, m,
+                                                 obj, TCO, sp, B, h, w, H, W));
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
 }
 
 int launch_crop_pack(void* x, int dtype, const float* frames4, const int* im_id, const float* boxes, const float* renders,

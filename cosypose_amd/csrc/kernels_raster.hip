@@ -16,15 +16,13 @@
 // fp32 with contraction off: oracle/cosy_oracle.c:cosy_oracle_rasterize is the same arithmetic in scalar loops and the
 // GPU tests require identical face ids / depths.
 #include "cosy_common.h"
+#include "raster_device.h"
 
 #pragma clang fp contract(off)
 
 namespace cosy {
 namespace {
 
-__device__ __forceinline__ float edge_fn(float ax, float ay, float bx, float by, float px, float py) {
-    return (bx - ax) * (py - ay) - (by - ay) * (px - ax);
-}
 __device__ __forceinline__ bool pose_finite(const float* T, const float* K) {
     bool ok = true;
 #pragma unroll
@@ -94,57 +92,12 @@ __global__ __launch_bounds__(256) void raster_tri_kernel(const float* __restrict
 }
 
 __global__ __launch_bounds__(256) void raster_resolve_kernel(const unsigned long long* __restrict__ zbuf, const float* __restrict__ uvz,
-                                                             const float* __restrict__ verts, const float* __restrict__ colors,
-                                                             const int* __restrict__ faces, const int* __restrict__ obj,
-                                                             const float* __restrict__ TCO, int V, int F, int H, int W, float ambient,
-                                                             float diffuse, float lx, float ly, float lz, float* __restrict__ rgb,
-                                                             float* __restrict__ depth) {
+                                                             MeshView m, const int* __restrict__ obj, const float* __restrict__ TCO, int H,
+                                                             int W, ShadeParams sp, float* __restrict__ rgb, float* __restrict__ depth) {
     const int b = blockIdx.y, pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= H * W) return;
-    const int x = pix % W, y = pix / W;
-    const unsigned long long key = zbuf[(size_t)b * H * W + pix];
-    float out[3] = {0.f, 0.f, 0.f}, zo = 0.f;
-    if (key != ~0ull) {
-        const int o = obj[b], f = (int)(key & 0xffffffffu);
-        const int* tri = faces + ((size_t)o * F + f) * 3;
-        const int i0 = tri[0], i1 = tri[1], i2 = tri[2];
-        const float* base = uvz + (size_t)b * V * 3;
-        const float ax = base[i0 * 3], ay = base[i0 * 3 + 1], az = base[i0 * 3 + 2];
-        const float bx = base[i1 * 3], by = base[i1 * 3 + 1], bz = base[i1 * 3 + 2];
-        const float cx = base[i2 * 3], cy = base[i2 * 3 + 1], cz = base[i2 * 3 + 2];
-        const float px = (float)x + 0.5f, py = (float)y + 0.5f;
-        const float inv_area = 1.f / edge_fn(ax, ay, bx, by, cx, cy);
-        const float w0 = edge_fn(bx, by, cx, cy, px, py) * inv_area;
-        const float w1 = edge_fn(cx, cy, ax, ay, px, py) * inv_area;
-        const float w2 = edge_fn(ax, ay, bx, by, px, py) * inv_area;
-        const float q0 = w0 / az, q1 = w1 / bz, q2 = w2 / cz;
-        const float z = 1.f / ((q0 + q1) + q2);
-        // camera-space vertices of the face (same expression as the projection kernel) -> flat two-sided Lambert term
-        const float* T = TCO + (size_t)b * 16;
-        float P[3][3];
-        const int idx[3] = {i0, i1, i2};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float* p = verts + ((size_t)o * V + idx[k]) * 3;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) P[k][i] = ((T[i * 4] * p[0] + T[i * 4 + 1] * p[1]) + T[i * 4 + 2] * p[2]) + T[i * 4 + 3];
-        }
-        const float e1[3] = {P[1][0] - P[0][0], P[1][1] - P[0][1], P[1][2] - P[0][2]};
-        const float e2[3] = {P[2][0] - P[0][0], P[2][1] - P[0][1], P[2][2] - P[0][2]};
-        const float n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-        const float nn = sqrtf((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);
-        const float lam = nn > 0.f ? fabsf((n[0] * lx + n[1] * ly) + n[2] * lz) / nn : 0.f;
-        const float shade = ambient + diffuse * lam;
-        const float* ca = colors + ((size_t)o * V + i0) * 3;
-        const float* cb = colors + ((size_t)o * V + i1) * 3;
-        const float* cc = colors + ((size_t)o * V + i2) * 3;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float col = (((q0 * ca[k] + q1 * cb[k]) + q2 * cc[k]) * z) * shade;
-            out[k] = fminf(fmaxf(col, 0.f), 1.f);
-        }
-        zo = z;
-    }
+    float out[3], zo;
+    resolve_pixel(zbuf[(size_t)b * H * W + pix], uvz + (size_t)b * m.V * 3, m, obj[b], TCO + (size_t)b * 16, pix % W, pix / W, sp, out, zo);
 #pragma unroll
     for (int k = 0; k < 3; ++k) rgb[((size_t)b * 3 + k) * H * W + pix] = out[k];
     if (depth) depth[(size_t)b * H * W + pix] = zo;
@@ -161,13 +114,12 @@ size_t cosy_render_scratch_bytes(int B, int V, int H, int W) {
     return (size_t)B * H * W * sizeof(unsigned long long) + (size_t)B * V * 3 * sizeof(float);
 }
 
-int cosy_render_meshes(const float* verts, const float* colors, const int* faces, const int* n_faces, const int* obj_id,
-                       const float* TCO, const float* K, int B, int V, int F, int H, int W, float ambient, float diffuse,
-                       float light_x, float light_y, float light_z, float* rgb, float* depth, void* scratch, cosy_stream_t stream) {
-    hipStream_t s = (hipStream_t)stream;
-    COSY_REQUIRE(B >= 0 && V > 0 && F > 0 && H > 0 && W > 0, "render_meshes: B=%d V=%d F=%d H=%d W=%d", B, V, F, H, W);
-    if (B == 0) return COSY_OK;
-    COSY_REQUIRE(verts && colors && faces && n_faces && obj_id && TCO && K && rgb && scratch, "render_meshes: null pointer");
+}  // extern "C"
+
+namespace cosy {
+// clear + project + z-buffer: fills `scratch` = [zbuf (B,H,W) u64 | uvz (B,V,3)]
+int launch_render_zbuffer(const float* verts, const int* faces, const int* n_faces, const int* obj_id, const float* TCO, const float* K, int B,
+                          int V, int F, int H, int W, void* scratch, hipStream_t s) {
     unsigned long long* zbuf = (unsigned long long*)scratch;
     float* uvz = (float*)(zbuf + (size_t)B * H * W);
     const long npx = (long)B * H * W;
@@ -178,10 +130,67 @@ int cosy_render_meshes(const float* verts, const float* colors, const int* faces
     hipLaunchKernelGGL(raster_tri_kernel, dim3(cdiv(F, 256), B), dim3(256), 0, s, (const float*)uvz, faces, n_faces, obj_id, TCO, K, V, F, H, W,
                        zbuf);
     COSY_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(raster_resolve_kernel, dim3(cdiv(H * W, 256), B), dim3(256), 0, s, (const unsigned long long*)zbuf, (const float*)uvz,
-                       verts, colors, faces, obj_id, TCO, V, F, H, W, ambient, diffuse, light_x, light_y, light_z, rgb, depth);
+    return COSY_OK;
+}
+int check_mesh_shade(const cosy_mesh_t* mesh, const cosy_shade_t* shade, MeshView* m, ShadeParams* sp) {
+    COSY_REQUIRE(mesh && shade, "render: null mesh / shade");
+    COSY_REQUIRE(mesh->verts && mesh->colors && mesh->faces && mesh->n_faces && mesh->V > 0 && mesh->F > 0, "render: incomplete mesh set");
+    COSY_REQUIRE(!shade->smooth || mesh->normals, "render: smooth shading needs vertex normals");
+    COSY_REQUIRE(!mesh->tex || (mesh->uvs && mesh->TH > 0 && mesh->TW > 0), "render: a texture needs uvs and its size");
+    *m = MeshView{mesh->verts, mesh->colors, mesh->normals, mesh->uvs, mesh->tex, mesh->faces, mesh->V, mesh->F, mesh->TH, mesh->TW};
+    *sp = ShadeParams{shade->ambient, shade->diffuse, shade->specular, shade->shininess, shade->light[0], shade->light[1], shade->light[2],
+                      shade->light_frame, shade->smooth, shade->quantize};
+    return COSY_OK;
+}
+int render_crop_pack(void* x, int dtype, const cosy_mesh_t* mesh, const cosy_shade_t* shade, const int* obj_id, const float* TCO,
+                     const float* K_crop, const float* frames4, const int* im_id, const float* boxes, int B, int N, int h, int w, int H, int W,
+                     void* scratch, hipStream_t s) {
+    (void)N;
+    MeshView m; ShadeParams sp;
+    int rc;
+    if ((rc = check_mesh_shade(mesh, shade, &m, &sp))) return rc;
+    COSY_REQUIRE(B >= 0 && H > 0 && W > 0 && h > 0 && w > 0, "render_crop_pack: B=%d H=%d W=%d h=%d w=%d", B, H, W, h, w);
+    COSY_REQUIRE(dtype == COSY_F32 || dtype == COSY_BF16 || dtype == COSY_F16, "render_crop_pack: dtype %d", dtype);
+    if (B == 0) return COSY_OK;
+    COSY_REQUIRE(x && obj_id && TCO && K_crop && frames4 && boxes && scratch, "render_crop_pack: null pointer");
+    if ((rc = launch_render_zbuffer(m.verts, m.faces, mesh->n_faces, obj_id, TCO, K_crop, B, m.V, m.F, H, W, scratch, s))) return rc;
+    return launch_render_crop_pack(x, dtype, frames4, im_id, boxes, scratch, m, obj_id, TCO, sp, B, h, w, H, W, s);
+}
+}  // namespace cosy
+
+extern "C" {
+
+int cosy_render_crop_pack_to(void* x_nhwc8, int dtype, const cosy_mesh_t* mesh, const cosy_shade_t* shade, const int* obj_id,
+                             const float* TCO, const float* K_crop, const float* frames_nhwc4, const int* im_id, const float* boxes_crop,
+                             int B, int N, int h, int w, int H, int W, void* scratch, cosy_stream_t stream) {
+    return render_crop_pack(x_nhwc8, dtype, mesh, shade, obj_id, TCO, K_crop, frames_nhwc4, im_id, boxes_crop, B, N, h, w, H, W, scratch,
+                            (hipStream_t)stream);
+}
+
+int cosy_render_meshes_ex(const cosy_mesh_t* mesh, const cosy_shade_t* shade, const int* obj_id, const float* TCO, const float* K, int B,
+                          int H, int W, float* rgb, float* depth, void* scratch, cosy_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MeshView m; ShadeParams sp;
+    int rc;
+    if ((rc = check_mesh_shade(mesh, shade, &m, &sp))) return rc;
+    COSY_REQUIRE(B >= 0 && H > 0 && W > 0, "render_meshes: B=%d H=%d W=%d", B, H, W);
+    if (B == 0) return COSY_OK;
+    COSY_REQUIRE(obj_id && TCO && K && rgb && scratch, "render_meshes: null pointer");
+    if ((rc = launch_render_zbuffer(m.verts, m.faces, mesh->n_faces, obj_id, TCO, K, B, m.V, m.F, H, W, scratch, s))) return rc;
+    const unsigned long long* zbuf = (const unsigned long long*)scratch;
+    const float* uvz = (const float*)(zbuf + (size_t)B * H * W);
+    hipLaunchKernelGGL(raster_resolve_kernel, dim3(cdiv(H * W, 256), B), dim3(256), 0, s, zbuf, uvz, m, obj_id, TCO, H, W, sp, rgb, depth);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
+}
+
+int cosy_render_meshes(const float* verts, const float* colors, const int* faces, const int* n_faces, const int* obj_id,
+                       const float* TCO, const float* K, int B, int V, int F, int H, int W, float ambient, float diffuse,
+                       float light_x, float light_y, float light_z, float* rgb, float* depth, void* scratch, cosy_stream_t stream) {
+    COSY_REQUIRE(B >= 0 && V > 0 && F > 0 && H > 0 && W > 0, "render_meshes: B=%d V=%d F=%d H=%d W=%d", B, V, F, H, W);
+    cosy_mesh_t mesh{verts, colors, nullptr, nullptr, nullptr, faces, n_faces, V, F, 0, 0};
+    cosy_shade_t shade{ambient, diffuse, 0.f, 1.f, {light_x, light_y, light_z}, 0, 0, 0};
+    return cosy_render_meshes_ex(&mesh, &shade, obj_id, TCO, K, B, H, W, rgb, depth, scratch, stream);
 }
 
 }  // extern "C"

@@ -120,22 +120,33 @@ class PosePredictor(nn.Module):
         for n in range(n_iterations):
             TCO_input = TCO_input.detach().float().contiguous()
             boxes_rend, boxes_crop, K_crop = self._geometry(K, TCO_input, obj_ids, (h, w), im_ids=im_ids)
-            renders = self.renderer.render(obj_infos=[dict(name=l) for l in labels], TCO=TCO_input,
-                                           K=K_crop, resolution=self.render_size)
-            require_device(renders)
-            renders = renders.detach().float().contiguous()
-            assert renders.shape == (bsz, 3, H, W), renders.shape
+            # a renderer of this library renders straight into the network input (cosy_render_crop_pack): no (B,3,H,W) fp32
+            # render tensor exists; any other renderer keeps the reference's interface (renderer.render -> images)
+            fused = hasattr(self.renderer, 'render_crop_pack') and not self.debug
+            obj_infos = [dict(name=l) for l in labels]
+            renders = None
+            if not fused:
+                renders = self.renderer.render(obj_infos=obj_infos, TCO=TCO_input, K=K_crop, resolution=self.render_size)
+                require_device(renders)
+                renders = renders.detach().float().contiguous()
+                assert renders.shape == (bsz, 3, H, W), renders.shape
             if train:
                 # train mode: fp32, batch-statistics BatchNorm, drop_connect; `pose` carries the autograd
                 # graph of the parameters (train_engine.backbone_train), the pose update itself is not differentiated
                 # (the reference's default loss, loss_refiner_CO_disentangled, only consumes model_outputs['pose'])
                 x8 = torch.empty(bsz, H, W, 8, device=dev)
-                check(lib().cosy_crop_pack_to(ptr(x8), COSY_F32, ptr(frames4), ptr(im_ids), ptr(boxes_crop), ptr(renders), bsz, n_im,
-                                              h, w, H, W, stream()))
+                if fused:
+                    self.renderer.render_crop_pack(obj_infos, TCO_input, K_crop, frames4, im_ids, boxes_crop, (H, W), x8=x8, dtype=COSY_F32)
+                else:
+                    check(lib().cosy_crop_pack_to(ptr(x8), COSY_F32, ptr(frames4), ptr(im_ids), ptr(boxes_crop), ptr(renders), bsz, n_im,
+                                                  h, w, H, W, stream()))
                 drop = train_engine.make_drop_connect_scales(bsz, dev, self.drop_connect_rate)
                 pose = train_engine.backbone_train(self, x8, drop)
             else:
-                check(lib().cosy_crop_pack(net, ptr(frames4), ptr(im_ids), ptr(boxes_crop), ptr(renders), bsz, n_im, h, w, stream()))
+                if fused:
+                    self.renderer.render_crop_pack(obj_infos, TCO_input, K_crop, frames4, im_ids, boxes_crop, (H, W), net=net)
+                else:
+                    check(lib().cosy_crop_pack(net, ptr(frames4), ptr(im_ids), ptr(boxes_crop), ptr(renders), bsz, n_im, h, w, stream()))
                 pose = torch.empty(bsz, self.pose_dim, device=dev)
                 check(lib().cosy_effnet_b3_forward(net, bsz, None, ptr(pose), None, stream()))
             model_outputs = dict(pose=pose)

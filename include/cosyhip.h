@@ -239,6 +239,44 @@ int cosy_render_meshes(const float* verts, const float* colors, const int* faces
                        const float* TCO, const float* K, int B, int V, int F, int H, int W, float ambient, float diffuse,
                        float light_x, float light_y, float light_z, float* rgb, float* depth, void* scratch, cosy_stream_t stream);
 
+/* The object set on the device (one row per label, padded to V vertices / F faces) and the shading model.
+ * cosy_shade_t.smooth = 1 selects the OpenGL-like model that PyBullet's hardware renderer has in structure
+ * (bullet_scene_renderer.py:38-60 -> getCameraImage(ER_BULLET_HARDWARE_OPENGL)): texture x vertex colour, interpolated
+ * vertex normals, one-sided Lambert + Blinn-Phong highlight, light fixed in the world frame (= the object's frame: every
+ * object is rendered at TWO = identity, bullet_batch_renderer.py:56-59), 8-bit output (quantize = 1:
+ * `images.float() / 255`, bullet_batch_renderer.py:83-84).  The shader's constants are third-party: pixel values stay
+ * parity-unpinned. */
+typedef struct {
+    const float* verts;   /* (n_obj,V,3) metres, object frame */
+    const float* colors;  /* (n_obj,V,3) in [0,1] */
+    const float* normals; /* (n_obj,V,3) unit vertex normals, or NULL (flat shading only) */
+    const float* uvs;     /* (n_obj,V,2) texture coordinates, or NULL */
+    const float* tex;     /* (n_obj,TH,TW,4) RGB(+pad) fp32 in [0,1], or NULL */
+    const int* faces;     /* (n_obj,F,3) */
+    const int* n_faces;   /* (n_obj) */
+    int V, F, TH, TW;
+} cosy_mesh_t;
+typedef struct {
+    float ambient, diffuse, specular, shininess;
+    float light[3];       /* unit vector from the surface towards the light */
+    int light_frame;      /* 0: camera frame, 1: object (PyBullet world) frame */
+    int smooth;           /* 0: flat two-sided face normals, 1: interpolated vertex normals */
+    int quantize;         /* 1: round colours to multiples of 1/255 */
+} cosy_shade_t;
+int cosy_render_meshes_ex(const cosy_mesh_t* mesh, const cosy_shade_t* shade, const int* obj_id, const float* TCO, const float* K, int B,
+                          int H, int W, float* rgb, float* depth, void* scratch, cosy_stream_t stream);
+
+/* Render + crop + pack in one pass (replaces renderer.render -> cosy_crop_pack when the renderer is this library's): the
+ * resolve pass of the rasteriser also samples the observed frame (roi_align, as cosy_crop_pack) and writes the network's
+ * 8-channel NHWC input pixel directly -- no fp32 (B,3,H,W) render tensor is written or read.  K = K_crop (B,3,3); the
+ * render resolution is the network's input resolution. */
+int cosy_render_crop_pack(cosy_net_t* net, const cosy_mesh_t* mesh, const cosy_shade_t* shade, const int* obj_id, const float* TCO,
+                          const float* K_crop, const float* frames_nhwc4, const int* im_id, const float* boxes_crop, int B, int N, int h,
+                          int w, void* scratch, cosy_stream_t stream);
+int cosy_render_crop_pack_to(void* x_nhwc8, int dtype, const cosy_mesh_t* mesh, const cosy_shade_t* shade, const int* obj_id,
+                             const float* TCO, const float* K_crop, const float* frames_nhwc4, const int* im_id, const float* boxes_crop,
+                             int B, int N, int h, int w, int H, int W, void* scratch, cosy_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

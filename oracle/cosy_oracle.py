@@ -238,14 +238,21 @@ def dists_add(pred, gt, points, symmetric=False):
     return out
 
 
-def rasterize(verts, colors, faces, n_faces, obj, TCO, K, H, W, ambient=0.6, diffuse=0.4, light_dir=(0., 0., -1.)):
-    """CPU twin of the HIP mesh rasteriser -> rgb (B,3,H,W), depth (B,H,W), zbuf (B,H,W) uint64"""
+def rasterize(verts, colors, faces, n_faces, obj, TCO, K, H, W, ambient=0.6, diffuse=0.4, light_dir=(0., 0., -1.), normals=None, uvs=None,
+              tex=None, specular=0.0, shininess=1.0, light_frame=0, smooth=0, quantize=0):
+    """CPU twin of the HIP mesh rasteriser -> rgb (B,3,H,W), depth (B,H,W), zbuf (B,H,W) uint64.  tex: (n_obj,TH,TW,4)."""
     verts, vp = _f(verts); colors, cp = _f(colors); faces, fp = _i(faces); n_faces, nfp = _i(n_faces); obj, op = _i(obj)
-    TCO, tp = _f(TCO); K, kp = _f(K); light, lp = _f(np.asarray(light_dir, np.float32))
+    TCO, tp = _f(TCO); K, kp = _f(K)
+    shade, sp = _f(np.array([ambient, diffuse, specular, shininess, *light_dir, light_frame, smooth, quantize], np.float32))
+    nrm, uv, tx, TH, TW = None, None, None, 0, 0
+    if normals is not None:
+        normals, nrm = _f(normals)
+    if uvs is not None and tex is not None:
+        uvs, uv = _f(uvs); tex, tx = _f(tex); TH, TW = tex.shape[1], tex.shape[2]
     B, V, F = TCO.shape[0], verts.shape[1], faces.shape[1]
     rgb = np.empty((B, 3, H, W), np.float32); depth = np.empty((B, H, W), np.float32); zb = np.empty((B, H, W), np.uint64)
-    lib().cosy_oracle_rasterize(vp, cp, fp, nfp, op, tp, kp, B, V, F, H, W, ctypes.c_float(ambient), ctypes.c_float(diffuse), lp,
-                                rgb.ctypes.data_as(ctypes.c_void_p), depth.ctypes.data_as(ctypes.c_void_p), zb.ctypes.data_as(ctypes.c_void_p))
+    lib().cosy_oracle_rasterize_ex(vp, cp, nrm, uv, tx, TH, TW, fp, nfp, op, tp, kp, B, V, F, H, W, sp,
+                                   rgb.ctypes.data_as(ctypes.c_void_p), depth.ctypes.data_as(ctypes.c_void_p), zb.ctypes.data_as(ctypes.c_void_p))
     return rgb, depth, zb
 
 

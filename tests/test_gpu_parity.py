@@ -796,6 +796,89 @@ def test_rasteriser_vs_cpu_twin_and_geometry(oracle):
     assert np.array_equal(again, rgb[:2])
 
 
+def _textured_setup(n_obj=4, shading='opengl'):
+    """meshes with spherical texture coordinates and a procedural texture per object"""
+    from cosypose_amd.rasterizer import RenderMeshes, HipBatchRenderer
+    labels = np.array([f'obj_{i:06d}' for i in range(1, n_obj + 1)])
+    v, f, c = syn.make_render_meshes(7, n_obj)
+    uvs = []
+    for vv in v:
+        d = vv / np.linalg.norm(vv, axis=1, keepdims=True)
+        uvs.append(np.stack([np.arctan2(d[:, 1], d[:, 0]) / (2 * np.pi) + 0.5, np.arccos(np.clip(d[:, 2], -1, 1)) / np.pi], 1).astype(np.float32))
+    rs = np.random.RandomState(3)
+    yy, xx = np.mgrid[0:32, 0:64]
+    tex = np.stack([np.stack([0.5 + 0.5 * np.sin(xx * (0.2 + 0.1 * o) + k) * np.cos(yy * 0.3 + o) for k in range(3)], -1) for o in range(n_obj)])
+    tex = (0.2 + 0.8 * tex * rs.uniform(0.6, 1.0, (n_obj, 1, 1, 3))).astype(np.float32)
+    meshes = RenderMeshes(labels, v, f, c, uvs_list=uvs, textures=tex).cuda()
+    return labels, meshes, HipBatchRenderer(meshes, shading=shading)
+
+
+def test_rasteriser_opengl_like_shading_vs_cpu_twin(oracle):
+    """SURVEY 8f-1 / bullet_scene_renderer.py:38-60 in structure: texture x vertex colour, interpolated vertex normals, one-sided
+    Lambert + Blinn-Phong highlight, light fixed in the object (= PyBullet world) frame, 8-bit output.  Face ids and depths
+    must equal the CPU twin's exactly; colours to one 8-bit step on a vanishing fraction of pixels (powf differs by ulps)."""
+    from cosypose_amd.rasterizer import OPENGL_LIKE
+    labels, meshes, renderer = _textured_setup()
+    B, H, W = 5, 240, 320
+    obj = np.array([0, 1, 2, 3, 1], np.int32)
+    TCO = syn.make_TCO(13, B, z_range=(0.45, 0.9), xy=0.05)
+    K = np.tile(np.array([[520., 0, 158.3], [0, 515., 121.7], [0, 0, 1]], np.float32), (B, 1, 1))
+    rgb, depth = renderer.render([dict(name=labels[o]) for o in obj], dev(TCO), dev(K), resolution=(H, W), render_depth=True)
+    rgb, depth = rgb.cpu().numpy(), depth.cpu().numpy()
+    cfg = OPENGL_LIKE
+    r_o, d_o, _ = oracle.rasterize(meshes.verts.cpu().numpy(), meshes.colors.cpu().numpy(), meshes.faces.cpu().numpy(), meshes.n_faces.cpu().numpy(),
+                                   obj, TCO, K, H, W, ambient=cfg['ambient'], diffuse=cfg['diffuse'], light_dir=cfg['light_dir'],
+                                   normals=meshes.normals.cpu().numpy(), uvs=meshes.uvs.cpu().numpy(), tex=meshes.tex.cpu().numpy(),
+                                   specular=cfg['specular'], shininess=cfg['shininess'], light_frame=1, smooth=1, quantize=1)
+    assert np.array_equal(depth, d_o)
+    diff = np.abs(rgb - r_o)
+    assert diff.max() <= 1 / 255 + 1e-6 and (diff > 1e-6).mean() < 1e-3, (diff.max(), (diff > 1e-6).mean())
+    # 8-bit output: every value is k/255 (bullet_batch_renderer.py:83-84, `images.float() / 255`)
+    assert np.abs(rgb * 255 - np.round(rgb * 255)).max() < 1e-4
+    fg = depth > 0
+    assert fg.mean() > 0.02 and rgb.transpose(0, 2, 3, 1)[fg].std() > 0.05            # textured, lit, not flat
+    # the light is fixed to the OBJECT: spinning object and camera together about the optical axis leaves every surface point's
+    # colour unchanged -- the image just rotates.  A 180 degree roll maps pixel centres onto pixel centres.
+    b = 0
+    Rz = np.diag([-1., -1., 1., 1.]).astype(np.float32)
+    Kc = K[b:b + 1].copy(); Kc[0, 0, 2], Kc[0, 1, 2] = W / 2, H / 2
+    a = renderer.render([dict(name=labels[obj[b]])], dev(TCO[b:b + 1]), dev(Kc), resolution=(H, W)).cpu().numpy()[0]
+    r = renderer.render([dict(name=labels[obj[b]])], dev((Rz @ TCO[b])[None]), dev(Kc), resolution=(H, W)).cpu().numpy()[0]
+    d = np.abs(a - r[:, ::-1, ::-1])
+    assert (d > 1.5 / 255).mean() < 2e-3, (d > 1.5 / 255).mean()       # silhouette pixels may flip with the fill rule
+    # ... while a camera-frame light would change the shading under the same roll only through the highlight: here the object-frame
+    # light makes the unrolled and rolled images identical up to the fill rule, asserted above.
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_render_crop_pack_equals_render_then_crop_pack(dtype):
+    """cosy_render_crop_pack (render resolve + roi_align crop + NHWC8 pack in ONE kernel, no fp32 render tensor) writes
+    bit for bit what renderer.render -> cosy_crop_pack write (pose.py:98-104 of the reference: crop, render, torch.cat)."""
+    from cosypose_amd._lib import lib, check, ptr, stream, COSY_F32, COSY_BF16
+    labels, meshes, renderer = _textured_setup()
+    B, H, W, h, w = 9, 256, 256, 480, 640
+    rs = np.random.RandomState(2)
+    obj = rs.randint(0, len(labels), B)
+    TCO = dev(syn.make_TCO(5, B, z_range=(0.5, 0.9), xy=0.04))
+    Kc = dev(np.tile(np.array([[700., 0, 128.], [0, 700., 128.], [0, 0, 1]], np.float32), (B, 1, 1)))
+    frames = torch.rand(3, 3, h, w, device='cuda', generator=torch.Generator(device='cuda').manual_seed(1))
+    frames4 = torch.empty(3, h, w, 4, device='cuda')
+    check(lib().cosy_frames_to_nhwc4(ptr(frames), ptr(frames4), 3, h, w, stream()))
+    im_ids = torch.tensor(rs.randint(0, 3, B), dtype=torch.int32, device='cuda')
+    x1 = rs.uniform(0, 300, B); y1 = rs.uniform(0, 200, B)
+    boxes = dev(np.stack([x1, y1, x1 + rs.uniform(80, 300, B), y1 + rs.uniform(80, 250, B)], 1).astype(np.float32))
+    infos = [dict(name=labels[o]) for o in obj]
+    code, tdt = (COSY_F32, torch.float32) if dtype == 'fp32' else (COSY_BF16, torch.bfloat16)
+    renders = renderer.render(infos, TCO, Kc, resolution=(H, W)).contiguous()
+    want = torch.zeros(B, H, W, 8, device='cuda', dtype=tdt)
+    check(lib().cosy_crop_pack_to(ptr(want), code, ptr(frames4), ptr(im_ids), ptr(boxes), ptr(renders), B, 3, h, w, H, W, stream()))
+    got = torch.zeros(B, H, W, 8, device='cuda', dtype=tdt)
+    renderer.render_crop_pack(infos, TCO, Kc, frames4, im_ids, boxes, (H, W), x8=got, dtype=code)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16 if dtype == 'bf16' else torch.int32), want.view(torch.int16 if dtype == 'bf16' else torch.int32))
+    assert (got[..., 3:6].float().abs().sum(dim=(1, 2, 3)) > 0).all()                 # every crop shows its object
+
+
 def test_refinement_loop_with_on_device_renderer(golden_sd):
     """coarse 1 + refiner 2 with the HIP rasteriser plugged in as model.renderer: the whole loop stays on the GPU"""
     import pandas as pd
@@ -824,6 +907,14 @@ def test_refinement_loop_with_on_device_renderer(golden_sd):
     rgb = renderer.render([dict(name=l) for l in it.infos['label']], it.poses_input, it.K_crop, resolution=(240, 320))
     cover = (rgb.sum(1) > 0).float().mean((1, 2))
     assert (cover > 0.05).all() and (cover < 0.9).all()
+    # the loop above rendered straight into the network input (cosy_render_crop_pack); a renderer that only has the
+    # reference's interface (render -> images) goes through cosy_crop_pack and must give the same poses bit for bit
+    class RenderOnly:
+        def __init__(self, r): self.r = r
+        def render(self, **kw): return self.r.render(**kw)
+    m.renderer = RenderOnly(renderer)
+    final2, _ = pred.get_predictions(images, K, detections=det, n_coarse_iterations=1, n_refiner_iterations=2)
+    assert torch.equal(final2.poses, final.poses)
 
 
 def test_crop_pack_all_window_paths(oracle):
