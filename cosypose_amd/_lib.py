@@ -54,6 +54,9 @@ _SIGNATURES = {
     'cosy_dw_train_backward_weight': ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P], _I),
     'cosy_wgrad_tall_supported': ([_L, _I, _I], _I),
     'cosy_wgrad_tall': ([_P, _P, _L, _I, _I, _P, _P, _P], _I),
+    'cosy_wgrad': ([_P, _P, _L, _I, _I, _P, _P, _P], _I),
+    'cosy_train_gemm': ([_P, _P, _I, _L, _I, _I, _P, _P, _P, _P], _I),
+    'cosy_stem_im2col_ld': ([_P, _I, _I, _I, _I, _P, _P], _I),
     'cosy_rows_mean': ([_P, _I, _I, _I, _P, _P, _P], _I),
     'cosy_rows_dot': ([_P, _P, _I, _I, _I, _P, _P, _P], _I),
     'cosy_rows_scale': ([_P, _P, _P, _F, _I, _I, _I, _P, _P], _I),

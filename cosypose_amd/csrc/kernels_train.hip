@@ -12,6 +12,8 @@
 // rows; every thread accumulates in double, partial sums go to a workspace and are combined in a fixed order
 // (deterministic, no atomics).
 #include "cosy_common.h"
+#include "kernels_net.h"
+#include <algorithm>
 
 namespace cosy {
 namespace {
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(256) void wgrad_tall_kernel(const float* __restrict
     __shared__ float lds[4 * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kq = lane >> 4;
-    const int n_base = blockIdx.y * TN * 16;
+    const int n_base = blockIdx.y * TN * 16, k_base = blockIdx.z * TK * 16;
     const long r0 = ((long)blockIdx.x * 4 + wave) * rows_per_wave, r1 = min(M, r0 + rows_per_wave);
     f32x4 acc[TN][TK];
 #pragma unroll
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256) void wgrad_tall_kernel(const float* __restrict
             }
 #pragma unroll
             for (int b = 0; b < TK; ++b) {
-                const int k = b * 16 + i;
+                const int k = k_base + b * 16 + i;
                 bv[h][b] = (ok && k < K) ? X[row * K + k] : 0.f;
             }
         }
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(256) void wgrad_tall_kernel(const float* __restrict
             if (wave == 0) {
                 const f32x4 s0 = *(const f32x4*)(lds + lane * 4), s1 = *(const f32x4*)(lds + 256 + lane * 4);
                 const f32x4 s2 = *(const f32x4*)(lds + 512 + lane * 4), s3 = *(const f32x4*)(lds + 768 + lane * 4);
-                const int k = b * 16 + i;
+                const int k = k_base + b * 16 + i;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int n = n_base + a * 16 + 4 * kq + q;
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 
 // stem: 3x3 stride-2 patches of the 8-channel NHWC input (6 used) as GEMM rows: cols[p][(ky*3+kx)*6 + c]
 __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ x8, int H, int W, int Ho, int Wo, int lo, long n,
-                                                          float* __restrict__ cols) {
+                                                          int ld, float* __restrict__ cols) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;   // one thread per (pixel, tap)
     if (i >= n) return;
     const int tap = (int)(i % 9);
@@ -471,9 +473,11 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restric
         const f32x2 c = *(const f32x2*)(s + 4);
         v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = c[0]; v[5] = c[1];
     }
-    float* o = cols + (i / 9) * 54 + tap * 6;
+    float* o = cols + (i / 9) * ld + tap * 6;
 #pragma unroll
     for (int k = 0; k < 6; ++k) o[k] = v[k];
+    if (tap == 8)
+        for (int k = 54; k < ld; ++k) cols[(i / 9) * ld + k] = 0.f;      // padding columns of a 16-byte aligned row
 }
 
 // ------------------------------------------------------------------------------------------
@@ -662,6 +666,30 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     p[i] = pi - (lr / bc1) * (mi / denom);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// 1x1 convolutions of the training step on this library's own fp32 MFMA GEMM (pw_gemm, v_mfma_f32_16x16x4_f32): the
+// weights change every step, so they are re-packed into the kernel's fragment order on the device (a few microseconds:
+// the largest matrix is 2304 x 384), together with the identity epilogue (scale 1, bias 0) the inference kernel expects.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pw_pack_f32_kernel(const float* __restrict__ w, int K, int N, int w_is_kn, int NI, int WN, int nkb,
+                                                          long total, int n_pad, float* __restrict__ dst, float* __restrict__ ones,
+                                                          float* __restrict__ zeros) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < n_pad + 4) {
+        if (idx < n_pad) ones[idx] = 1.f;
+        zeros[idx] = 0.f;                     // n_pad zeros for the bias + 16 zero bytes for the DMA's padding source
+    }
+    if (idx >= total) return;
+    const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+    long r = idx >> 8;
+    const int kbi = (int)(r % nkb); r /= nkb;
+    const int NW = NI * WN, nb = (int)(r % NW), nt = (int)(r / NW);
+    const int i = lane & 15, kg = lane >> 4, wn = nb / NI, ni = nb % NI;
+    const int n = nt * 16 * NW + wn * 16 * NI + (i >> 2) * 4 * NI + ni * 4 + (i & 3);
+    const int k = kbi * 16 + kg * 4 + e;
+    dst[idx] = (n < N && k < K) ? (w_is_kn ? w[(size_t)k * N + n] : w[(size_t)n * K + k]) : 0.f;
+}
 }  // namespace
 }  // namespace cosy
 
@@ -779,33 +807,62 @@ int cosy_dw_train_backward_weight(const float* x, const float* dy, int B, int H,
 
 // dW (N,K) = dY^T (N,M) . X (M,K) for tall-skinny shapes; returns COSY_EINVAL (nothing launched) when the shape is not
 // one this kernel is built for -- the host then uses the library GEMM.
-int cosy_wgrad_tall_supported(long M, int N, int K) {
-    const int tk = cdiv(K, 16), tn = cdiv(N, 16);
-    const bool tk_ok = tk == 2 || tk == 3 || tk == 4 || tk == 9 || tk == 12;
-    return M >= 32768 && tk_ok && tn >= 2 && (size_t)1024 * N * K * sizeof(float) <= cosy_train_workspace_bytes();
-}
+int cosy_wgrad_tall_supported(long M, int N, int K) { (void)M; return N > 0 && K > 0; }
 int cosy_wgrad_tall(const float* dY, const float* X, long M, int N, int K, float* dW, void* workspace, cosy_stream_t stream) {
+    return cosy_wgrad(dY, X, M, N, K, dW, workspace, stream);
+}
+// dW (N,K) = dY^T (N,M) . X (M,K), any shape: grid = (row slabs, n tiles, k tiles); every workgroup streams its rows once through
+// the MFMA into TN x TK register tiles and writes a partial tile; a fixed-order combine pass adds the slabs (deterministic).
+int cosy_wgrad(const float* dY, const float* X, long M, int N, int K, float* dW, void* workspace, cosy_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
-    COSY_REQUIRE(dY && X && dW && workspace, "wgrad_tall: null argument");
-    COSY_REQUIRE(cosy_wgrad_tall_supported(M, N, K), "wgrad_tall: shape M=%ld N=%d K=%d not supported", M, N, K);
+    COSY_REQUIRE(dY && X && dW && workspace && M > 0 && N > 0 && K > 0, "wgrad: bad argument M=%ld N=%d K=%d", M, N, K);
     const int tk = cdiv(K, 16), tn = cdiv(N, 16);
     const int TN = (tn % 3 == 0 && tk <= 4) ? 3 : 2;      // n-tiles per workgroup; grid.y covers the rest
-    const int gy = cdiv(tn, TN);
-    int nwg = 1024;
+    const int TK = tk <= 4 ? tk : (tk == 9 || tk == 12) && (size_t)N * K <= 192 * 192 ? tk : 4;
+    const int gy = cdiv(tn, TN), gz = cdiv(tk, TK);
+    const size_t cap = cosy_train_workspace_bytes() / ((size_t)N * K * sizeof(float));
+    COSY_REQUIRE(cap >= 1, "wgrad: N x K = %d x %d exceeds the workspace", N, K);
+    int nwg = (int)std::min<size_t>(1024, cap);
+    if (gy * gz >= 64) nwg = std::min(nwg, 64);          // wide outputs: enough workgroups already, keep the combine short
     int rpw = (int)cdiv(M, (long)nwg * 4);
     rpw = cdiv(rpw, 8) * 8;
     nwg = (int)cdiv(M, (long)rpw * 4);
-    const dim3 grid(nwg, gy);
+    const dim3 grid(nwg, gy, gz);
     float* partial = (float*)workspace;
 #define WG(A, B_) hipLaunchKernelGGL((wgrad_tall_kernel<A, B_>), grid, dim3(256), 0, s, dY, X, M, N, K, rpw, partial)
-    if (TN == 3) { if (tk == 2) WG(3, 2); else if (tk == 3) WG(3, 3); else WG(3, 4); }
-    else { if (tk == 2) WG(2, 2); else if (tk == 3) WG(2, 3); else if (tk == 4) WG(2, 4); else if (tk == 9) WG(2, 9); else WG(2, 12); }
+    if (TN == 3) { if (TK == 1) WG(3, 1); else if (TK == 2) WG(3, 2); else if (TK == 3) WG(3, 3); else WG(3, 4); }
+    else { if (TK == 1) WG(2, 1); else if (TK == 2) WG(2, 2); else if (TK == 3) WG(2, 3); else if (TK == 4) WG(2, 4); else if (TK == 9) WG(2, 9); else WG(2, 12); }
 #undef WG
     COSY_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(combine_partials_kernel<float>, dim3(cdiv((long)N * K, 64)), dim3(1024), 0, s, (const float*)partial, nwg, (long)N * K,
                        (double*)nullptr, dW);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
+}
+
+// out (M,N) = A (M,K) . op(W) (+ add): op(W) = W^T for W stored (N,K) (a 1x1 convolution's forward), W for W stored (K,N)
+// (its data gradient: dX = dY . W).  fp32 MFMA through pw_gemm with an identity epilogue; K % 4 == 0 (16-byte rows).
+int cosy_train_gemm(const float* A, const float* W, int w_is_kn, long M, int K, int N, const float* add, float* out, void* workspace,
+                    cosy_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    COSY_REQUIRE(A && W && out && workspace && M > 0 && K > 0 && N > 0, "train_gemm: bad argument M=%ld K=%d N=%d", M, K, N);
+    COSY_REQUIRE(K % 4 == 0 && N % 4 == 0 && M < (1l << 31), "train_gemm: K=%d and N=%d must be multiples of 4", K, N);
+    const PwCfg cfg = pw_choose_cfg(N);
+    const size_t packed = pw_packed_elems(K, N, cfg, COSY_F32);
+    const int n_pad = cdiv(N, pw_bn(cfg)) * pw_bn(cfg);
+    COSY_REQUIRE((packed + 2 * (size_t)n_pad + 8) * sizeof(float) <= cosy_train_workspace_bytes(), "train_gemm: weights %d x %d exceed the workspace", N, K);
+    float* wp = (float*)workspace;
+    float* ones = wp + packed;
+    float* zeros = ones + n_pad;
+    const int nkb = (int)(packed / ((size_t)cdiv(N, pw_bn(cfg)) * cfg.NI * cfg.WN * 256));
+    const long total = (long)packed;
+    hipLaunchKernelGGL(pw_pack_f32_kernel, dim3(cdiv(std::max<long>(total, n_pad + 4), 256)), dim3(256), 0, s, W, K, N, w_is_kn, cfg.NI, cfg.WN, nkb,
+                       total, n_pad, wp, ones, zeros);
+    COSY_CHECK_HIP(hipGetLastError());
+    PwArgs a{};
+    a.A = A; a.Wp = wp; a.out = out; a.scale = ones; a.bias = zeros; a.res = add; a.gate = nullptr;
+    a.M = (int)M; a.K = K; a.N = N; a.HW = (int)M; a.silu = 0; a.zeros = zeros;
+    return launch_pw_gemm(a, cfg, COSY_F32, s);
 }
 
 static int rows_chunks(int B, int HW, int C, int* rows_per_chunk) {
@@ -865,12 +922,15 @@ int cosy_act_backward(const float* x, const float* dy, long n, int kind, float* 
     LAUNCH1D(act_bwd_kernel, n, (hipStream_t)stream, x, dy, n, kind, dx);
     return COSY_OK;
 }
-int cosy_stem_im2col(const float* x_nhwc8, int B, int H, int W, float* cols, cosy_stream_t stream) {
-    COSY_REQUIRE(x_nhwc8 && cols && B > 0, "stem_im2col: bad argument");
+int cosy_stem_im2col_ld(const float* x_nhwc8, int B, int H, int W, int ld, float* cols, cosy_stream_t stream) {
+    COSY_REQUIRE(x_nhwc8 && cols && B > 0 && ld >= 54, "stem_im2col: bad argument");
     const int Ho = (H + 1 - 3) / 2 + 1, Wo = (W + 1 - 3) / 2 + 1;   // static same padding of k=3,s=2: pad total 1, all after
     const long n = (long)B * Ho * Wo * 9;
-    LAUNCH1D(stem_im2col_kernel, n, (hipStream_t)stream, x_nhwc8, H, W, Ho, Wo, 0, n, cols);
+    LAUNCH1D(stem_im2col_kernel, n, (hipStream_t)stream, x_nhwc8, H, W, Ho, Wo, 0, n, ld, cols);
     return COSY_OK;
+}
+int cosy_stem_im2col(const float* x_nhwc8, int B, int H, int W, float* cols, cosy_stream_t stream) {
+    return cosy_stem_im2col_ld(x_nhwc8, B, H, W, 54, cols, stream);
 }
 
 int cosy_loss_refiner_disentangled_backward(const float* TCO_possible_gt, const float* TCO_input, const float* refiner_outputs,

@@ -122,15 +122,23 @@ SWISH, SIGMOID = 0, 1
 
 
 def wgrad(dY, X):
-    """dW (N,K) = dY^T X for dY (M,N), X (M,K): the streaming MFMA kernel for the tall-skinny products of the
-    high-resolution blocks, the library GEMM otherwise."""
+    """dW (N,K) = dY^T X for dY (M,N), X (M,K): the streaming fp32 MFMA kernel (cosy_wgrad), every shape."""
     M, N = dY.shape
     K = X.shape[1]
-    if lib().cosy_wgrad_tall_supported(M, N, K):
-        out = torch.empty(N, K, device=dY.device)
-        check(lib().cosy_wgrad_tall(ptr(dY), ptr(X), M, N, K, ptr(out), ptr(_workspace(dY.device)), stream()))
-        return out
-    return dY.t() @ X
+    out = torch.empty(N, K, device=dY.device)
+    check(lib().cosy_wgrad(ptr(dY), ptr(X), M, N, K, ptr(out), ptr(_workspace(dY.device)), stream()))
+    return out
+
+
+def gemm(A, W, w_is_kn=False, add=None):
+    """A (M,K) @ W^T for W (N,K)  [w_is_kn=False: a 1x1 convolution's forward]  or  A (M,K) @ W for W (K,N)  [w_is_kn=True: its
+    data gradient], plus `add` (M,N): the library's own fp32 MFMA GEMM (cosy_train_gemm), no rocBLAS."""
+    M, K = A.shape
+    N = W.shape[1] if w_is_kn else W.shape[0]
+    assert W.shape == ((K, N) if w_is_kn else (N, K)) and A.is_contiguous() and W.is_contiguous()
+    out = torch.empty(M, N, device=A.device)
+    check(lib().cosy_train_gemm(ptr(A), ptr(W), int(w_is_kn), M, K, N, ptr(add), ptr(out), ptr(_workspace(A.device)), stream()))
+    return out
 
 
 # ---------------------------------------------------------------------------------------------
@@ -191,10 +199,10 @@ class _Net:
         dev = x8.device
         # stem: im2col + GEMM, BN, Swish
         Ho, Wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
-        cols = torch.empty(B * Ho * Wo, 54, device=dev)
-        check(lib().cosy_stem_im2col(ptr(x8), B, H, W, ptr(cols), stream()))
-        w2d = P['backbone._conv_stem.weight'].permute(0, 2, 3, 1).reshape(arch.STEM_C, 54)
-        raw = cols @ w2d.t()
+        cols = torch.empty(B * Ho * Wo, 56, device=dev)                 # 54 patch values + 2 zero columns: 16-byte aligned rows
+        check(lib().cosy_stem_im2col_ld(ptr(x8), B, H, W, 56, ptr(cols), stream()))
+        w2d = torch.nn.functional.pad(P['backbone._conv_stem.weight'].permute(0, 2, 3, 1).reshape(arch.STEM_C, 54), (0, 2))
+        raw = gemm(cols, w2d)
         tape['stem'] = cols
         x = self._bn_f(tape, 'backbone._bn0', raw, B * Ho * Wo, arch.STEM_C, 1)
         H, W = Ho, Wo
@@ -203,7 +211,7 @@ class _Net:
             M, cmid = B * H * W, cin * e
             inp = x
             if e != 1:
-                raw = inp @ P[p + '_expand_conv.weight'].view(cmid, cin).t()
+                raw = gemm(inp, P[p + '_expand_conv.weight'].view(cmid, cin))
                 a0 = self._bn_f(tape, p + '_bn0', raw, M, cmid, 1)
             else:
                 a0 = inp
@@ -220,14 +228,14 @@ class _Net:
             g_pre = torch.addmm(P[p + '_se_expand.bias'], h, P[p + '_se_expand.weight'].view(cmid, cse).t())
             g = act_forward(g_pre, SIGMOID)
             a2 = rows_scale(a1, g, B, HWo, cmid)
-            raw = a2 @ P[p + '_project_conv.weight'].view(cout, cmid).t()
+            raw = gemm(a2, P[p + '_project_conv.weight'].view(cout, cmid))
             skip = s == 1 and cin == cout
             rowscale = drop.get(i) if (skip and drop) else None
             x = self._bn_f(tape, p + '_bn2', raw, Mo, cout, 0, rowscale, HWo, inp if skip else None)
             tape[p] = (inp, a0, wt, a1, pooled, h_pre, h, g_pre, g, a2, H, W, Ho, Wo)
             H, W = Ho, Wo
         M = B * H * W
-        raw = x @ P['backbone._conv_head.weight'].view(arch.HEAD_C, -1).t()
+        raw = gemm(x, P['backbone._conv_head.weight'].view(arch.HEAD_C, -1))
         a = self._bn_f(tape, 'backbone._bn1', raw, M, arch.HEAD_C, 1)
         feat = rows_mean(a, B, H * W, arch.HEAD_C)
         pose = torch.addmm(P['pose_fc.bias'], feat, P['pose_fc.weight'].t())
@@ -248,7 +256,7 @@ class _Net:
         draw = self._bn_b(tape, grads, 'backbone._bn1', da)
         wh = P['backbone._conv_head.weight']
         grads['backbone._conv_head.weight'] = wgrad(draw, x_head).view_as(wh)
-        dx = draw @ wh.view(arch.HEAD_C, -1)
+        dx = gemm(draw, wh.view(arch.HEAD_C, -1), w_is_kn=True)
         for i in reversed(range(len(arch.B3_BLOCKS))):
             k, s, e, cin, cout = arch.B3_BLOCKS[i]
             p = f'backbone._blocks.{i}.'
@@ -259,7 +267,7 @@ class _Net:
             draw = self._bn_b(tape, grads, p + '_bn2', dout)
             wp = P[p + '_project_conv.weight']
             grads[p + '_project_conv.weight'] = wgrad(draw, a2).view_as(wp)
-            da2 = draw @ wp.view(cout, cmid)
+            da2 = gemm(draw, wp.view(cout, cmid), w_is_kn=True)
             # squeeze-excite backward
             dg = rows_dot(da2, a1, B, HWo, cmid)
             dg_pre = act_backward(g_pre, dg, SIGMOID)
@@ -281,12 +289,12 @@ class _Net:
                 we = P[p + '_expand_conv.weight']
                 grads[p + '_expand_conv.weight'] = wgrad(draw, inp).view_as(we)
                 # the skip connection's gradient rides on the GEMM (C = dout + draw W) instead of a separate add
-                dx = torch.addmm(dout, draw, we.view(cmid, cin)) if skip else draw @ we.view(cmid, cin)
+                dx = gemm(draw, we.view(cmid, cin), w_is_kn=True, add=dout if skip else None)
             else:
                 dx = da0 + dout if skip else da0
         draw = self._bn_b(tape, grads, 'backbone._bn0', dx)
         cols = tape['stem']
-        grads['backbone._conv_stem.weight'] = wgrad(draw, cols).view(arch.STEM_C, 3, 3, 6).permute(0, 3, 1, 2).contiguous()
+        grads['backbone._conv_stem.weight'] = wgrad(draw, cols)[:, :54].reshape(arch.STEM_C, 3, 3, 6).permute(0, 3, 1, 2).contiguous()
         return grads
 
 

@@ -200,9 +200,16 @@ int cosy_dw_train_backward_data(const float* dy, const float* wt, int B, int H, 
                                 cosy_stream_t stream);
 int cosy_dw_train_backward_weight(const float* x, const float* dy, int B, int H, int W, int C, int k, int stride, float* dwt,
                                   void* workspace, cosy_stream_t stream);
-/* weight gradient of a 1x1 convolution over many rows and few channels: dW (N,K) = dY^T (N,M) . X (M,K), dY (M,N), X (M,K)
- * row-major.  cosy_wgrad_tall_supported says whether the MFMA streaming kernel is built for the shape (M >= 32768,
- * K in 16-column tiles of 2,3,4,9 or 12); other shapes are plain library GEMMs on the host side. */
+/* 1x1 convolutions of the training step on the library's own fp32 MFMA GEMMs (no rocBLAS on the path):
+ *   cosy_train_gemm: out (M,N) = A (M,K) . op(W) (+ add (M,N)); op(W) = W^T for W stored (N,K) [w_is_kn = 0: the forward of
+ *                    F.conv2d with a 1x1 kernel, efficientnet.py:81,90,188], W for W stored (K,N) [w_is_kn = 1: the data
+ *                    gradient dX = dY . W].  K and N multiples of 4.  The weights are packed on the device per call.
+ *   cosy_wgrad:      dW (N,K) = dY^T (N,M) . X (M,K), dY (M,N), X (M,K) row-major, any shape; deterministic (fixed-order
+ *                    combine of per-slab partial tiles).
+ * cosy_wgrad_tall / _supported are round 1's names for the same kernel (kept: every shape is supported now). */
+int cosy_train_gemm(const float* A, const float* W, int w_is_kn, long M, int K, int N, const float* add, float* out, void* workspace,
+                    cosy_stream_t stream);
+int cosy_wgrad(const float* dY, const float* X, long M, int N, int K, float* dW, void* workspace, cosy_stream_t stream);
 int cosy_wgrad_tall_supported(long M, int N, int K);
 int cosy_wgrad_tall(const float* dY, const float* X, long M, int N, int K, float* dW, void* workspace, cosy_stream_t stream);
 /* per-sample reductions / broadcasts over the HW pixels of a (B,HW,C) activation: mean (adaptive_avg_pool2d),
@@ -217,6 +224,9 @@ int cosy_act_forward(const float* x, long n, int kind, float* out, cosy_stream_t
 int cosy_act_backward(const float* x, const float* dy, long n, int kind, float* dx, cosy_stream_t stream);
 /* stem 3x3 stride-2 patches of the NHWC8 input as GEMM rows: cols (B*Ho*Wo, 54), column = (ky*3+kx)*6 + c */
 int cosy_stem_im2col(const float* x_nhwc8, int B, int H, int W, float* cols, cosy_stream_t stream);
+/* the same with a row stride ld >= 54 (columns 54..ld-1 are written as zeros): ld = 56 gives the 16-byte aligned rows
+ * cosy_train_gemm wants */
+int cosy_stem_im2col_ld(const float* x_nhwc8, int B, int H, int W, int ld, float* cols, cosy_stream_t stream);
 /* gradient of loss_refiner_CO_disentangled (cosypose_ops.py:49-82) wrt refiner_outputs, times the upstream dloss (B) */
 int cosy_loss_refiner_disentangled_backward(const float* TCO_possible_gt, const float* TCO_input, const float* refiner_outputs,
                                             const float* K_crop, const float* pts_table, const int* obj_id, int B, int S, int P,
