@@ -12,7 +12,8 @@ checks, for every wave kernel:
   3. no XREAD between an XLOAD and the next XWAIT in layout order (the row loop is laid out wait -> read -> ... -> load);
   4. the kernel allocates exactly its budget (the reserved range exists): vgpr_count == 256 / 168 / 128.
 
-Usage: check_wave_isa.py [-v] [file.s]   (without a file: compiles cosypose_amd/csrc/kernels_wave.hip)
+Usage: check_wave_isa.py [-v] [--tune] [file.s]   (without a file: compiles cosypose_amd/csrc/kernels_wave.hip with the
+shipping flags, or with -DCOSY_TUNE: the experiment build must be checked too before its timings are believed)
 Exit code 0 = clean.  tests/test_build_isa.py runs it.
 """
 import os
@@ -24,9 +25,11 @@ import tempfile
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def compile_to_isa(out):
+def compile_to_isa(out, tune=False):
     src = os.path.join(REPO, 'cosypose_amd', 'csrc', 'kernels_wave.hip')
     cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-S', '--cuda-device-only', '-o', out, src]
+    if tune:
+        cmd.insert(1, '-DCOSY_TUNE')
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 
 
@@ -89,7 +92,7 @@ def main():
         path = args[0]
     else:
         path = os.path.join(tempfile.mkdtemp(), 'wave.s')
-        compile_to_isa(path)
+        compile_to_isa(path, tune='--tune' in sys.argv)
     text = open(path).read().split('\n')
     problems, n, agprs = [], 0, {}
     # kernel bodies
