@@ -132,6 +132,10 @@ def all_gather_rows(local, max_rows=None, counts=None):
     if n:
         slab[head:head + n * wb] = rows.reshape(-1)
     out = torch.empty(world * slab.numel(), device=local.device, dtype=torch.uint8)
+    if local.is_cuda and dist.get_backend() == 'gloo':
+        # rehearsal only (several ranks on one GPU): gloo stages device tensors through the host; entering it with a deep
+        # queue of kernels from 3+ processes time-slicing one device was measured at seconds per call.  RCCL is stream-ordered.
+        torch.cuda.current_stream().synchronize()
     dist.all_gather_into_tensor(out, slab)
     out = out.view(world, -1)
     if counts is None:
@@ -219,6 +223,26 @@ def _subset_frames(images, K, im_ids):
     return images[sel], K[sel], inv.astype(np.asarray(im_ids).dtype)
 
 
+def _trace_begin():
+    """COSY_SHARD_TRACE=1: wall-clock split of a sharded call on stderr (synchronises the device: diagnostics only)"""
+    if not os.environ.get('COSY_SHARD_TRACE'):
+        return None
+    import time
+    torch.cuda.synchronize()
+    return time.perf_counter()
+
+
+def _trace_mark(t0, what, rank):
+    if t0 is None:
+        return None
+    import sys
+    import time
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    print(f'[shard trace] rank {rank}: {what} {1e3 * (t1 - t0):.1f} ms', file=sys.stderr, flush=True)
+    return t1
+
+
 def run_shard(predictor, images, K, table, ids, **kwargs):
     """predictor.get_predictions on the candidates `ids` of the global table (`detections` or `data_TCO_init`)."""
     sub = table[np.asarray(ids, dtype=np.int64)]
@@ -255,7 +279,9 @@ def get_predictions_sharded(predictor, images, K, detections=None, data_TCO_init
     plan = plan_shards(n, world, balance, costs=costs, counts=counts)
     shard_counts = [len(p) for p in plan]
     kw = dict(n_coarse_iterations=n_coarse_iterations, n_refiner_iterations=n_refiner_iterations)
+    _t0 = _trace_begin()
     final, preds = run_shard(predictor, images, K, table, plan[rank], **kw)
+    _t1 = _trace_mark(_t0, 'run_shard', rank)
     # what a call produces is known from the arguments alone (an empty rank has no collections to inspect)
     keys = ([f'coarse/iteration={i}' for i in range(1, n_coarse_iterations + 1)] if data_TCO_init is None else []) + \
            [f'refiner/iteration={i}' for i in range(1, n_refiner_iterations + 1)]
@@ -269,6 +295,7 @@ def get_predictions_sharded(predictor, images, K, detections=None, data_TCO_init
         full = gather_rows(rows, shard_counts)
     else:
         full = all_gather_rows(rows, counts=shard_counts)
+    _trace_mark(_t1, 'pack+all_gather', rank)
     # rank order -> original candidate order
     order = np.concatenate(plan) if n else np.zeros(0, np.int64)
     if n and not np.array_equal(order, np.arange(n)):

@@ -1,2 +1,3 @@
-python -m pytest tests -m gpu -x -q -k "train or wgrad or ddp or bn_ or dw_" 2>&1 | tail -8
-python bench_train.py --kernels 2>&1 | grep -E "time by family|^\{|gemm " | cut -c1-400
+export COSY_DIST_BACKEND=gloo
+timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29515 bench.py --gpus 4 --steps 2 --warmup 1 --no-cpu-baseline --no-profile --config 2 2>/dev/null | grep "^{" | cut -c1-230
+timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29516 bench.py --gpus 4 --steps 2 --warmup 1 --no-cpu-baseline --no-profile --config 3 2>/dev/null | grep "^{" | cut -c1-230
