@@ -296,20 +296,6 @@ __global__ __launch_bounds__(NWV * 64) void pw_gemm_dma_kernel(PwKArgs a) {
 
     constexpr bool HALF_GATE = sizeof(T) == 2 && !__is_same(T, bf16_t);   // fp16: the gate multiplies as packed halves
     int gsel = 0, grow[MI];
-    if constexpr (GATE) {
-        const int b_first = m0 / a.HW;
-        for (int i = tid; i < a.nsamp * Kpad; i += NWV * 64) {
-            const int sidx = i / Kpad, k = i - sidx * Kpad;
-            const long mrow = (long)(b_first + sidx) * a.HW;
-            const float g = (k < K && mrow < M) ? a.gate[(size_t)(b_first + sidx) * K + k] : 0.f;
-            if constexpr (HALF_GATE) ((f16_t*)gl)[i] = (f16_t)g; else gl[i] = g;
-        }
-        gsel = (m0 + wm * 16 * MI) / a.HW - b_first;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) grow[mi] = min((m0 + (wm * MI + mi) * 16 + row) / a.HW - b_first, a.nsamp - 1) * Kpad;
-        __syncthreads();
-    }
-
     // chunked A ([sample][K/16][HW][16]): element offset of this lane's row at k = 0, per DMA slot
     size_t achunk[L];
 #pragma unroll
@@ -346,6 +332,39 @@ __global__ __launch_bounds__(NWV * 64) void pw_gemm_dma_kernel(PwKArgs a) {
 
 #pragma unroll
     for (int s0 = 0; s0 < NS - 1; ++s0) issue(s0);
+    // Behind the first DMAs, in the same latency shadow: the residual rows this lane will add in the epilogue (2-byte types:
+    // 2 registers per 4 channels) and the SE gate rows.  Fetched in the epilogue / before the first DMA (round 1) each of them
+    // exposed one more full memory latency per tile -- a third of the time of the 1-2 k-block layers.  They are ordinary loads
+    // YOUNGER than the DMAs and are waited for with the vmcnt(0) of the barrier below, so no count spans both kinds.
+    typedef T rv4_t __attribute__((ext_vector_type(4)));
+    constexpr bool RES_PREFETCH = sizeof(T) == 2;
+    rv4_t rpre[RES_PREFETCH ? MI : 1][RES_PREFETCH ? NI : 1];
+    if constexpr (RES_PREFETCH) {
+        if (a.res) {
+            const int nl_ = n0 + wn * 16 * NI + kg * 4 * NI;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int m = min(m0 + (wm * MI + mi) * 16 + row, M - 1);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    rpre[mi][ni] = *(const rv4_t*)((const T*)a.res + (size_t)m * N + min(nl_ + ni * 4, N - 4));
+            }
+        }
+    }
+    if constexpr (GATE) {
+        const int b_first = m0 / a.HW;
+        for (int i = tid; i < a.nsamp * Kpad; i += NWV * 64) {
+            const int sidx = i / Kpad, k = i - sidx * Kpad;
+            const long mrow = (long)(b_first + sidx) * a.HW;
+            const float g = (k < K && mrow < M) ? a.gate[(size_t)(b_first + sidx) * K + k] : 0.f;
+            if constexpr (HALF_GATE) ((f16_t*)gl)[i] = (f16_t)g; else gl[i] = g;
+        }
+        gsel = (m0 + wm * 16 * MI) / a.HW - b_first;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) grow[mi] = min((m0 + (wm * MI + mi) * 16 + row) / a.HW - b_first, a.nsamp - 1) * Kpad;
+        __syncthreads();
+    }
+
     for (int kb = 0; kb < a.nkb_valid; ++kb) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * L) : "memory");  // k-block kb has landed (this wave's part)
         __builtin_amdgcn_s_barrier();                                          // ... and everybody's; stage (kb-1)%NS is free
@@ -437,7 +456,12 @@ __global__ __launch_bounds__(NWV * 64) void pw_gemm_dma_kernel(PwKArgs a) {
             for (int ni = 0; ni < NI; ++ni)
                 if (nl + ni * 4 < N) {
                     float rv[4];
-                    load4(res + o + ni * 4, rv);
+                    if constexpr (RES_PREFETCH) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) rv[r] = (float)rpre[mi][ni][r];
+                    } else {
+                        load4(res + o + ni * 4, rv);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[ni * 4 + r] += rv[r];
                 }

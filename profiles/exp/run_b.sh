@@ -1,11 +1,8 @@
-export COSY_TUNE_LIB=1
 run() { # tag env...
   tag=$1; shift
   env "$@" python bench.py --steps 3 --warmup 1 --no-cpu-baseline --layers > gpurun_out/rb_$tag.json 2> gpurun_out/rb_$tag.txt
   echo "== $tag: $(python -c "import json;print(json.load(open('gpurun_out/rb_$tag.json'))['value'])")"
-  grep -E "^ *(1[89]|2[0-5]) (mbconv|pw_gemm|dwconv)" gpurun_out/rb_$tag.txt | awk '{for(i=1;i<=NF;i++) if($i=="us/fwd") printf "%s:%s ", $1, $(i-1)} END {print ""}'
+  grep -E "^ *[0-9]+ pw_gemm" gpurun_out/rb_$tag.txt | awk '{for(i=1;i<=NF;i++) if($i=="us/fwd") printf "%s:%s ", $1, $(i-1)} END {print ""}'
 }
-run old COSY_WAVE_MASK=0x3fffc
-run new COSY_WAVE_MASK=0x3fffffc
-run n18 COSY_WAVE_MASK=0x3f7fffc
-COSY_TUNE_LIB= python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+run base X=0
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3
