@@ -1426,7 +1426,7 @@ int launch_se(const SeArgs& a, hipStream_t s) {
 // with 12 consecutive output channels of its pixel (80-byte NHWC rows are written completely by the 4 k-groups).
 // For fp32 the same scheme runs with 16-deep k-blocks (2 taps each) on v_mfma_f32_16x16x4_f32.
 // ==========================================================================================
-static constexpr int STEM_G = 4;   // 16-pixel groups per wave
+static constexpr int STEM_G = 8;   // 16-pixel groups per wave (4 / 8 / 16 / 32: 180 / 170 / 176 / 179 us at 256 crops)
 size_t stem_packed_elems(int dtype) { return (size_t)3 * (dtype == COSY_F32 ? 6 : 3) * 64 * (dtype == COSY_F32 ? 4 : 8); }
 // w: reference layout (40, 6, 3, 3) -> fragment blocks [ni 0..2][kb][lane][EPL], rows permuted so lane (i>>2 = kg') holds
 // channels kg'*12 + ni*4 + (i&3)
@@ -1449,7 +1449,7 @@ void stem_pack_weights(const float* w, int dtype, void* dst) {
 template <typename T>
 __global__ __launch_bounds__(256) void stem_kernel(const T* __restrict__ x, const T* __restrict__ wp, const float* __restrict__ scale,
                                                    const float* __restrict__ bias, T* __restrict__ out, int H, int W, int Ho, int Wo,
-                                                   long n_groups) {
+                                                   long n_groups, int gpw) {
     using raw_t = typename DT<T>::raw_t;
     constexpr int EPL = DT<T>::EPL;
     constexpr int KBN = sizeof(T) == 2 ? 3 : 6;          // k-blocks
@@ -1466,19 +1466,15 @@ __global__ __launch_bounds__(256) void stem_kernel(const T* __restrict__ x, cons
     float sc[12], bi[12];
 #pragma unroll
     for (int q = 0; q < 12; ++q) { sc[q] = n0 + q < 40 ? scale[n0 + q] : 0.f; bi[q] = n0 + q < 40 ? bias[n0 + q] : 0.f; }
-    const long g0 = ((long)blockIdx.x * 4 + wave) * STEM_G;
-#pragma unroll 1
-    for (int gi = 0; gi < STEM_G; ++gi) {
-        const long g = g0 + gi;
-        if (g >= n_groups) break;
-        const long pix = g * 16 + j;                 // linear output pixel over (b, oy, ox); Ho*Wo is a multiple of 16
+    const long g0 = ((long)blockIdx.x * 4 + wave) * gpw;
+    // input fragments of one 16-pixel group: 3 (6) independent 16-byte loads per lane.  The next group's are issued before the
+    // current group's MFMAs / epilogue / stores (the loop is not unrolled: without this every group exposed a full memory latency)
+    auto load_group = [&](long g, raw_t* xf) {
+        const long pix = min(g, n_groups - 1) * 16 + j;
         const int ox = (int)(pix % Wo);
         const long t2 = pix / Wo;
         const int oy = (int)(t2 % Ho), b = (int)(t2 / Ho);
         const T* xb = x + (size_t)b * H * W * 8;
-        f32x4 acc[3];
-#pragma unroll
-        for (int ni = 0; ni < 3; ++ni) acc[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < KBN; ++kb) {
             // this lane's k-range inside the block: kg*EPL .. +EPL  ->  tap and channel offset
@@ -1486,13 +1482,29 @@ __global__ __launch_bounds__(256) void stem_kernel(const T* __restrict__ x, cons
             const int tap = kb * TPB + kk / 8, ci0 = kk % 8;
             const int ky = tap / 3, kx = tap - ky * 3;
             const int iy = oy * 2 + ky, ix = ox * 2 + kx;
-            raw_t xf;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) xf[e] = 0;
-            if (tap < 9 && iy < H && ix < W) xf = *(const raw_t*)(xb + ((size_t)iy * W + ix) * 8 + ci0);
-#pragma unroll
-            for (int ni = 0; ni < 3; ++ni) mma(acc[ni], wf[ni][kb], xf);
+            for (int e = 0; e < EPL; ++e) xf[kb][e] = 0;
+            if (tap < 9 && iy < H && ix < W) xf[kb] = *(const raw_t*)(xb + ((size_t)iy * W + ix) * 8 + ci0);
         }
+    };
+    raw_t xcur[KBN], xnext[KBN];
+    if (g0 < n_groups) load_group(g0, xcur);
+#pragma unroll 1
+    for (int gi = 0; gi < gpw; ++gi) {
+        const long g = g0 + gi;
+        if (g >= n_groups) break;
+        if (gi + 1 < gpw) load_group(g + 1, xnext);
+        const long pix = g * 16 + j;                 // linear output pixel over (b, oy, ox); Ho*Wo is a multiple of 16
+        f32x4 acc[3];
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni) acc[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KBN; ++kb) {
+#pragma unroll
+            for (int ni = 0; ni < 3; ++ni) mma(acc[ni], wf[ni][kb], xcur[kb]);
+        }
+#pragma unroll
+        for (int kb = 0; kb < KBN; ++kb) xcur[kb] = xnext[kb];
         (void)LPT;
         float y[12];
 #pragma unroll
@@ -1516,8 +1528,9 @@ int launch_stem(const void* x, const void* wp, const float* scale, const float* 
     if (B == 0) return COSY_OK;
     COSY_REQUIRE((Ho * Wo) % 16 == 0, "stem: Ho*Wo=%d must be a multiple of 16", Ho * Wo);
     const long n_groups = (long)B * Ho * Wo / 16;
-    dim3 grid((unsigned)cdiv(n_groups, 4 * STEM_G));
-    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(stem_kernel<T>, grid, dim3(256), 0, s, (const T*)x, (const T*)wp, scale, bias, (T*)out, H, W, Ho, Wo, n_groups));
+    static const int gpw = tune_int("COSY_STEM_G", STEM_G);
+    dim3 grid((unsigned)cdiv(n_groups, 4 * gpw));
+    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(stem_kernel<T>, grid, dim3(256), 0, s, (const T*)x, (const T*)wp, scale, bias, (T*)out, H, W, Ho, Wo, n_groups, gpw));
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }
