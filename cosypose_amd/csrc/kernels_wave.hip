@@ -121,29 +121,9 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     const bool active = b < a.B;
     const int c0 = ch * 16 * NI;
 
-    // ---- parameters of the chunk -> wave-private LDS block [s0][b0][s1][b1][taps], 16*NI floats each
     float* P = smem_w + wave * PF;
-    if (active) {
-        for (int i = lane; i < PF / 4; i += 64) {
-            const int arr = i / (4 * NI), q4 = i - arr * (4 * NI);
-            const float* src = arr == 0 ? a.s0 : arr == 1 ? a.b0 : arr == 2 ? a.s1 : arr == 3 ? a.b1 : a.dww + (size_t)(arr - 4) * a.Cmid;
-            // The expansion's SiLU runs on t = log2(e) * v: t / (1 + 2^-t) = log2(e) * silu(v) -- one multiply fewer per expanded
-            // element (v_exp_f32 takes the negation as a source modifier).  log2(e) is folded into BN0 here and its inverse into
-            // the depthwise taps, which are the only consumers of the expanded values.
-            const float f = arr < 2 ? 1.4426950408889634f : arr >= 4 ? 0.6931471805599453f : 1.f;
-            *(f32x4*)(P + arr * 16 * NI + q4 * 4) = *(const f32x4*)(src + c0 + q4 * 4) * f;
-        }
-    }
-    __syncthreads();
-    if (!active) return;
 
-    const T* __restrict__ X = (const T*)a.X + (size_t)b * a.H * a.W * a.Cin;
-    raw_t wf[NI][KBN];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int kb = 0; kb < KBN; ++kb)
-            wf[ni][kb] = *(const raw_t*)((const T*)a.Wp + ((size_t)(ch * NI + ni) * a.nkb_total + kb) * 64 * EPL + lane * EPL);
+    const T* __restrict__ X = (const T*)a.X + (size_t)min(b, a.B - 1) * a.H * a.W * a.Cin;
     const float* Pl = P + kg * 4;            // this lane's channel quad inside every 16-float group
     const float* taps = Pl + 4 * 16 * NI;
 
@@ -190,7 +170,33 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     // this job's output rows [oy_a, oy_b) and the input rows they need (rows above a band are recomputed, KS-S of them)
     const int oy_a = band * a.rows_per, oy_b = min(a.Ho, oy_a + a.rows_per);
     const int iy_first = max(0, oy_a * S - LO), iy_last = (oy_b - 1) * S - LO + KS - 1;
-    load_row(iy_first);
+
+    // ---- everything a job needs from memory before its first row, issued back to back under ONE latency: the first input
+    // row (asm loads, oldest), the chunk's expand-weight fragments, the parameter block (staged to LDS: its wait is a vmcnt(0)
+    // that covers all three).  Issued one after the other they cost three memory latencies per job -- 15 % of a 16-row job.
+    raw_t wf[NI][KBN];
+    if (active) {
+        load_row(iy_first);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int kb = 0; kb < KBN; ++kb)
+                wf[ni][kb] = *(const raw_t*)((const T*)a.Wp + ((size_t)(ch * NI + ni) * a.nkb_total + kb) * 64 * EPL + lane * EPL);
+    }
+    // ---- parameters of the chunk -> wave-private LDS block [s0][b0][s1][b1][taps], 16*NI floats each
+    if (active) {
+        for (int i = lane; i < PF / 4; i += 64) {
+            const int arr = i / (4 * NI), q4 = i - arr * (4 * NI);
+            const float* src = arr == 0 ? a.s0 : arr == 1 ? a.b0 : arr == 2 ? a.s1 : arr == 3 ? a.b1 : a.dww + (size_t)(arr - 4) * a.Cmid;
+            // The expansion's SiLU runs on t = log2(e) * v: t / (1 + 2^-t) = log2(e) * silu(v) -- one multiply fewer per expanded
+            // element (v_exp_f32 takes the negation as a source modifier).  log2(e) is folded into BN0 here and its inverse into
+            // the depthwise taps, which are the only consumers of the expanded values.
+            const float f = arr < 2 ? 1.4426950408889634f : arr >= 4 ? 0.6931471805599453f : 1.f;
+            *(f32x4*)(P + arr * 16 * NI + q4 * 4) = *(const f32x4*)(src + c0 + q4 * 4) * f;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
 
     float acc[NOPEN][TO][NCH];               // output rows in flight (input-stationary accumulation)
 #pragma unroll
