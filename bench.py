@@ -129,7 +129,9 @@ def main():
     ap.add_argument('--crop', default='256x256', help='HxW of the crops: 256x256 (metric) or 240x320 (reference native)')
     ap.add_argument('--dtype', default=None, choices=['bf16', 'fp16', 'fp32'], help='default: bf16 (configs 1, 3), fp16 (config 2)')
     ap.add_argument('--detections', type=int, default=None, help='override the number of candidates (per GPU for config 1, total otherwise)')
-    ap.add_argument('--bsz-objects', type=int, default=256)
+    ap.add_argument('--bsz-objects', type=int, default=None,
+                    help='crops per forward: default 256 for config 1 (BASELINE configs[1] names batch=256), 512 for configs 2 and 3 '
+                         '(their batches are 1024 / 2048 candidates; 512 per forward measured +9 %% over 256, profiles/r02_batch_sweep.txt)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='skip the per-kernel HIP-event pass (no roofline object)')
     ap.add_argument('--layers', action='store_true', help='print the per-launch table to stderr')
@@ -192,6 +194,8 @@ def main():
         per_rank = [len(p) for p in plan_shards(D, world, **plan_kw)]
         desc = (f'BASELINE configs[3]: {D} candidates over 7 datasets (5x 640x480, 720x540, 1280x960 frames), {n_obj} objects, '
                 f'{args.split} shares {per_rank}')
+    if args.bsz_objects is None:
+        args.bsz_objects = 256 if cfg_i == 1 else 512
     cap = min(max(per_rank), args.bsz_objects)
     g = torch.Generator(device='cuda'); g.manual_seed(1 + rank)
     renders = [torch.rand(cap, 3, H, W, device='cuda', generator=g) for _ in range(5)]
