@@ -514,7 +514,8 @@ template <typename T, int NI, int WN, bool GATE>
 static int launch_pw_dma_cfg(const PwKArgs& k, int grid, hipStream_t s) {
     // short k-loops (<= 2 k-blocks: the streaming 1x1 convs of the high-resolution blocks) need no deep ring:
     // 2 stages keep the LDS footprint small so that more workgroups are resident per CU
-    if (k.nkb_valid <= 2) return launch_pw_dma_ns<T, NI, WN, GATE, 2>(k, grid, s);
+    static const int ns2 = tune_int("COSY_PW_NS2_MAXKB", 2);
+    if (k.nkb_valid <= ns2) return launch_pw_dma_ns<T, NI, WN, GATE, 2>(k, grid, s);
     static const int deep = tune_int("COSY_PW_NS", 3);
     if (deep >= 4 && k.nkb_valid >= 8) return launch_pw_dma_ns<T, NI, WN, GATE, 4>(k, grid, s);
     return launch_pw_dma_ns<T, NI, WN, GATE, 3>(k, grid, s);
