@@ -974,6 +974,25 @@ def test_roi_align_handmade_fixtures():
     assert np.abs(got2 - want).max() < 2e-6 * scale
 
 
+@pytest.mark.parametrize('M,K,N', [(4800, 24, 144), (1229, 136, 816), (76800, 40, 24), (333, 384, 1536), (5120, 1392, 232), (64, 56, 40)])
+def test_train_gemm_and_wgrad_vs_torch_fp64(M, K, N):
+    """The training step's own fp32 MFMA GEMMs (cosy_train_gemm: forward A.W^T, data gradient dY.W with the skip's gradient
+    riding on `add`; cosy_wgrad: dY^T.X for every shape) against float64 matrix products of the same operands.  Shapes of
+    F.conv2d(kernel 1) in efficientnet.py:81,90,188 at 64 crops, ragged M, the 56-column stem patches."""
+    from cosypose_amd import train_engine as te
+    g = torch.Generator(device='cuda').manual_seed(M + K + N)
+    A = torch.randn(M, K, device='cuda', generator=g)
+    W = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
+    dY = torch.randn(M, N, device='cuda', generator=g)
+    add = torch.randn(M, K, device='cuda', generator=g)
+    rel = lambda got, want: float((got.double() - want).abs().max() / want.abs().max())
+    assert rel(te.gemm(A, W), A.double() @ W.double().t()) < 2e-6                                    # forward
+    assert rel(te.gemm(dY, W, w_is_kn=True, add=add), dY.double() @ W.double() + add.double()) < 2e-6  # dgrad (+ skip)
+    dW = te.wgrad(dY, A)
+    assert dW.shape == (N, K) and rel(dW, dY.double().t() @ A.double()) < 1e-5                       # wgrad: M-long fp32 sums
+    assert torch.equal(dW, te.wgrad(dY, A))                                                           # fixed-order combine: deterministic
+
+
 def test_training_loop_checkpoint_and_resume(tmp_path, golden_sd):
     """the loop around the step (cosypose/training/train_pose.py:282-343): warm-up ramp + step decay applied to
     the optimizer, one reference-format checkpoint per epoch ({'state_dict', 'epoch'}, loadable strict=True into the
