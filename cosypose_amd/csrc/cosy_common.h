@@ -78,7 +78,8 @@ int launch_scatter_argmin(const float* dists, const int* ids, int M, int n_seg, 
 // crop + render pack into the NHWC8 network input (T = float or bf16_t), see kernels_geom.hip
 int launch_frames_to_nhwc4(const float* images, float* out, int N, int h, int w, hipStream_t s);
 int launch_crop_pack(void* x_nhwc8, int dtype, const float* frames_nhwc4, const int* im_id, const float* boxes,
-                     const float* renders, int B, int N, int h, int w, int H, int W, hipStream_t s);
+                     const float* renders, int B, int N, int h, int w, int H, int W, void* taps_ws, hipStream_t s);
+size_t crop_taps_bytes(int B, int H, int W);    // scratch of the per-crop roi_align tap tables (taps_ws above; may be null)
 int launch_pack_nchw(void* x_nhwc8, int dtype, const float* x_nchw6, int B, int H, int W, hipStream_t s);
 
 }  // namespace cosy

@@ -83,6 +83,7 @@ struct cosy_net {
     hipStream_t side[2];
     hipEvent_t ev_fork, ev_join[2];
     void* zeros;
+    void* crop_taps;   // roi_align tap tables of cosy_crop_pack (maxB x (H + W) entries)
     void* wbase; void* abase;
     size_t wbytes, abytes;
     // profiling ring: PROF_SEGS forwards x (PROF_SLOTS+1) events
@@ -256,6 +257,7 @@ static void layout_ws(cosy_net* n, Bump& b, cosy_net::WS& w, size_t B) {
 static void layout_workspace(cosy_net* n, Bump& b) {
     n->X = b.take((size_t)n->maxB * n->H * n->W * 8 * n->esz);
     n->zeros = b.take(256);   // stays zero: the workspace is memset at creation and nothing writes here
+    n->crop_taps = b.take(crop_taps_bytes(n->maxB, n->H, n->W));
     layout_ws(n, b, n->ws[0], n->maxB);
     if (n->nstreams == 2) layout_ws(n, b, n->ws[1], (n->maxB + 1) / 2);
 }
@@ -554,7 +556,7 @@ int cosy_crop_pack(cosy_net_t* n, const float* images, const int* im_id, const f
     if (B == 0) return COSY_OK;   // an empty batch carries null data pointers (an empty device tensor has none)
     COSY_REQUIRE(images && boxes_crop && renders, "crop_pack: null argument");
     COSY_REQUIRE(B >= 0 && B <= n->maxB, "crop_pack: batch %d exceeds max_batch %d", B, n->maxB);
-    return launch_crop_pack(n->X, n->dtype, images, im_id, boxes_crop, renders, B, N, h, w, n->H, n->W, (hipStream_t)stream);
+    return launch_crop_pack(n->X, n->dtype, images, im_id, boxes_crop, renders, B, N, h, w, n->H, n->W, n->crop_taps, (hipStream_t)stream);
 }
 
 int cosy_render_crop_pack(cosy_net_t* n, const cosy_mesh_t* mesh, const cosy_shade_t* shade, const int* obj_id, const float* TCO,

@@ -313,10 +313,91 @@ __device__ __forceinline__ void roi_pixel_nhwc4(const f32x4* __restrict__ img, i
     acc[0] = a0 / 16.f; acc[1] = a1 / 16.f; acc[2] = a2 / 16.f;
 }
 
+// Per-crop tap tables: the roi_align taps of an output pixel are separable, and along one axis they depend on the output
+// row (or column) only -- 256 + 256 entries per crop instead of 65,536 x 2 evaluations of ~200 instructions each (the crop
+// kernel was VALU-bound: ~400 instructions per pixel, three quarters of them this arithmetic).  Entry = first frame pixel of
+// the window, its extent, and the summed weights of the window's 4 positions (same functions, same values as the on-the-fly
+// path); entries with an extent > 4 (bins above ~2.6 frame pixels) send the pixel to the on-the-fly path.
+struct CropTap { int first, span; float w[4]; int pad[2]; };      // span = last - first; -1: no valid sample
+static_assert(sizeof(CropTap) == 32, "one tap entry = two 16-byte loads");
+__global__ __launch_bounds__(256) void crop_taps_kernel(const float* __restrict__ boxes, int B, int h, int w, int PH, int PW,
+                                                        CropTap* __restrict__ taps) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * (PH + PW)) return;
+    const int b = i / (PH + PW), q = i - b * (PH + PW);
+    const float* bx = boxes + (size_t)b * 4;
+    const float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
+    const float roi_w = fmaxf(x2 - x1, 1.f), roi_h = fmaxf(y2 - y1, 1.f);
+    const bool yaxis = q < PH;
+    AxisTaps t;
+    if (yaxis) axis_taps(y1, roi_h / (float)PH, q, h, t); else axis_taps(x1, roi_w / (float)PW, q - PH, w, t);
+    CropTap o;
+    o.first = t.last < 0 ? 0 : t.first;
+    o.span = t.last < 0 ? -1 : t.last - t.first;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o.w[d] = (t.last >= 0 && o.span < 4) ? axis_weight(t, t.first + d) : 0.f;
+    o.pad[0] = o.pad[1] = 0;
+    taps[i] = o;
+}
+// the 4x4-window path of roi_pixel_nhwc4 driven by two table entries; returns false when the pixel needs the general path
+__device__ __forceinline__ bool roi_pixel_table(const f32x4* __restrict__ img, int h, int w, const CropTap& ty, const CropTap& tx, float* acc) {
+    if (ty.span >= 4 || tx.span >= 4) return false;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (ty.span >= 0 && tx.span >= 0) {
+        int ox[4], oy[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { ox[d] = min(tx.first + d, w - 1); oy[d] = min(ty.first + d, h - 1) * w; }
+        // rows / columns of the window that ANY lane of the wave needs (wave-uniform: whole gather instructions drop out; a
+        // crop that magnifies its box has 2-3 pixel windows, not 4).  Skipped positions carry weight 0.
+        const int rows = __ballot(ty.span > 2) ? 4 : __ballot(ty.span > 1) ? 3 : 2;
+        const int cols = __ballot(tx.span > 2) ? 4 : __ballot(tx.span > 1) ? 3 : 2;
+        f32x4 p[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < rows) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    if (d < cols) p[r][d] = img[oy[r] + ox[d]];
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < rows) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    if (d < cols) {
+                        const float wgt = ty.w[r] * tx.w[d];
+                        a0 += wgt * p[r][d][0]; a1 += wgt * p[r][d][1]; a2 += wgt * p[r][d][2];
+                    }
+            }
+    }
+    acc[0] = a0 / 16.f; acc[1] = a1 / 16.f; acc[2] = a2 / 16.f;
+    return true;
+}
+// observed-crop channels of one output pixel: table-driven when a table is given, else (or for huge bins) on the fly
+__device__ __forceinline__ void crop_pixel(const f32x4* __restrict__ img, const float* __restrict__ bx, const CropTap* __restrict__ taps, int b,
+                                           int h, int w, int PH, int PW, int ph, int pw, float* v) {
+    if (taps) {
+        const CropTap* tb = taps + (size_t)b * (PH + PW);
+        const CropTap ty = tb[ph], tx = tb[PH + pw];
+        if (roi_pixel_table(img, h, w, ty, tx, v)) return;
+    }
+    const float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
+    const float roi_w = fmaxf(x2 - x1, 1.f), roi_h = fmaxf(y2 - y1, 1.f);
+    roi_pixel_nhwc4(img, h, w, x1, y1, roi_h / (float)PH, roi_w / (float)PW, ph, pw, v);
+}
+int launch_crop_taps(const float* boxes, int B, int h, int w, int H, int W, void* taps, hipStream_t s) {
+    if (B == 0) return COSY_OK;
+    hipLaunchKernelGGL(crop_taps_kernel, dim3(cdiv((long)B * (H + W), 256)), dim3(256), 0, s, boxes, B, h, w, H, W, (CropTap*)taps);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+size_t crop_taps_bytes(int B, int H, int W) { return (size_t)B * (H + W) * sizeof(CropTap); }
+
 template <typename T>
 __global__ __launch_bounds__(256) void crop_pack_kernel(T* __restrict__ x, const float* __restrict__ frames4,
                                                         const int* __restrict__ im_id, const float* __restrict__ boxes,
-                                                        const float* __restrict__ renders, int B, int h, int w, int PH, int PW) {
+                                                        const float* __restrict__ renders, const CropTap* __restrict__ taps, int B, int h,
+                                                        int w, int PH, int PW) {
     // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2.  All pixel blocks of
     // one crop get ids of the same residue, so the frame region under a crop's box is fetched into ONE L2, once
     // (crop-major ids had every XCD fetch every region: 1.2 GB of L2 fills per launch for 0.36 GB of distinct data).
@@ -326,13 +407,9 @@ __global__ __launch_bounds__(256) void crop_pack_kernel(T* __restrict__ x, const
     const int pix = (j % bpc) * 256 + threadIdx.x;
     if (pix >= PH * PW) return;
     const int ph = pix / PW, pw = pix % PW;
-    const float* bx = boxes + (size_t)b * 4;
-    const float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
-    const float roi_w = fmaxf(x2 - x1, 1.f), roi_h = fmaxf(y2 - y1, 1.f);
-    const float bin_h = roi_h / (float)PH, bin_w = roi_w / (float)PW;
     const f32x4* img = (const f32x4*)frames4 + (size_t)(im_id ? im_id[b] : b) * h * w;
     float v[6];
-    roi_pixel_nhwc4(img, h, w, x1, y1, bin_h, bin_w, ph, pw, v);
+    crop_pixel(img, boxes + (size_t)b * 4, taps, b, h, w, PH, PW, ph, pw, v);
     const float* r = renders + (size_t)b * 3 * PH * PW + pix;
     v[3] = r[0]; v[4] = r[(size_t)PH * PW]; v[5] = r[(size_t)2 * PH * PW];
     store_px8<T>(x + ((size_t)b * PH * PW + pix) * 8, v);
@@ -344,20 +421,17 @@ __global__ __launch_bounds__(256) void render_crop_pack_kernel(T* __restrict__ x
                                                                const int* __restrict__ im_id, const float* __restrict__ boxes,
                                                                const unsigned long long* __restrict__ zbuf, const float* __restrict__ uvz,
                                                                MeshView m, const int* __restrict__ obj, const float* __restrict__ TCO,
-                                                               ShadeParams sp, int B, int h, int w, int PH, int PW) {
+                                                               ShadeParams sp, const CropTap* __restrict__ taps, int B, int h, int w, int PH,
+                                                               int PW) {
     const int id = blockIdx.x, xcd = id & 7, bpc = (PH * PW + 255) / 256;
     const int j = id >> 3, b = (j / bpc) * 8 + xcd;
     if (b >= B) return;
     const int pix = (j % bpc) * 256 + threadIdx.x;
     if (pix >= PH * PW) return;
     const int ph = pix / PW, pw = pix % PW;
-    const float* bx = boxes + (size_t)b * 4;
-    const float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
-    const float roi_w = fmaxf(x2 - x1, 1.f), roi_h = fmaxf(y2 - y1, 1.f);
-    const float bin_h = roi_h / (float)PH, bin_w = roi_w / (float)PW;
     const f32x4* img = (const f32x4*)frames4 + (size_t)(im_id ? im_id[b] : b) * h * w;
     float v[6], zo;
-    roi_pixel_nhwc4(img, h, w, x1, y1, bin_h, bin_w, ph, pw, v);
+    crop_pixel(img, boxes + (size_t)b * 4, taps, b, h, w, PH, PW, ph, pw, v);
     resolve_pixel(zbuf[(size_t)b * PH * PW + pix], uvz + (size_t)b * m.V * 3, m, obj[b], TCO + (size_t)b * 16, pw, ph, sp, v + 3, zo);
     store_px8<T>(x + ((size_t)b * PH * PW + pix) * 8, v);
 }
@@ -368,19 +442,26 @@ int launch_render_crop_pack(void* x, int dtype, const float* frames4, const int*
     if (B == 0) return COSY_OK;
     const unsigned long long* zbuf = (const unsigned long long*)scratch;
     const float* uvz = (const float*)(zbuf + (size_t)B * H * W);
+    CropTap* taps = (CropTap*)(uvz + (((size_t)B * m.V * 3 + 7) & ~(size_t)7));      // behind [zbuf | uvz], 32-byte aligned
+    int rc;
+    if ((rc = launch_crop_taps(boxes, B, h, w, H, W, taps, s))) return rc;
     dim3 grid((unsigned)(cdiv(H * W, 256) * cdiv(B, 8) * 8));
     COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(render_crop_pack_kernel<T>, grid, dim3(256), 0, s, (T*)x, frames4, im_id, boxes, zbuf, uvz, m,
-                                                 obj, TCO, sp, B, h, w, H, W));
+                                                 obj, TCO, sp, (const CropTap*)taps, B, h, w, H, W));
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }
 
+// taps_ws: crop_taps_bytes(B, H, W) bytes of scratch for the tap tables, or null (taps are then evaluated per pixel)
 int launch_crop_pack(void* x, int dtype, const float* frames4, const int* im_id, const float* boxes, const float* renders,
-                     int B, int N, int h, int w, int H, int W, hipStream_t s) {
+                     int B, int N, int h, int w, int H, int W, void* taps_ws, hipStream_t s) {
     (void)N;
     if (B == 0) return COSY_OK;
+    int rc;
+    if (taps_ws && (rc = launch_crop_taps(boxes, B, h, w, H, W, taps_ws, s))) return rc;
     dim3 grid((unsigned)(cdiv(H * W, 256) * cdiv(B, 8) * 8));
-    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(crop_pack_kernel<T>, grid, dim3(256), 0, s, (T*)x, frames4, im_id, boxes, renders, B, h, w, H, W));
+    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(crop_pack_kernel<T>, grid, dim3(256), 0, s, (T*)x, frames4, im_id, boxes, renders,
+                                                 (const CropTap*)taps_ws, B, h, w, H, W));
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }

@@ -111,7 +111,8 @@ using namespace cosy;
 extern "C" {
 
 size_t cosy_render_scratch_bytes(int B, int V, int H, int W) {
-    return (size_t)B * H * W * sizeof(unsigned long long) + (size_t)B * V * 3 * sizeof(float);
+    // [z-buffer | projected vertices (padded to 32 bytes) | roi_align tap tables of the fused render + crop kernel]
+    return (size_t)B * H * W * sizeof(unsigned long long) + (((size_t)B * V * 3 + 7) & ~(size_t)7) * sizeof(float) + crop_taps_bytes(B, H, W);
 }
 
 }  // extern "C"

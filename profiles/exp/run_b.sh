@@ -1,11 +1,4 @@
-export COSY_TUNE_LIB=1
-run() { # tag env...
-  tag=$1; shift
-  env "$@" python bench.py --steps 3 --warmup 1 --no-cpu-baseline --layers > gpurun_out/rb_$tag.json 2> gpurun_out/rb_$tag.txt
-  echo "== $tag: $(python -c "import json;print(json.load(open('gpurun_out/rb_$tag.json'))['value'])")"
-  grep -E "^ *([2-9]|1[0-7]) (mbconv)" gpurun_out/rb_$tag.txt | awk '{for(i=1;i<=NF;i++) if($i=="us/fwd") printf "%s:%s ", $1, $(i-1)} END {print ""}'
-}
-run tail COSY_SE_TAIL=0x3fffc
-run notail COSY_SE_TAIL=0
-python profiles/exp/det.py 2>&1 | grep -v amdgpu | tail -3 | cut -c1-160
-COSY_TUNE_LIB= python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile | cut -c1-150
+export TMPDIR=/tmp
+rocprofv3 -M --kernel-trace --stats -f csv -d gpurun_out/px -o t -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2>&1
+grep -E "crop_" gpurun_out/px/t_kernel_stats.csv | cut -c1-120
