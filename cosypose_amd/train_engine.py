@@ -35,9 +35,12 @@ _ws = {}
 
 
 def _workspace(dev):
-    w = _ws.get(dev)
+    """Scratch of the reduction / GEMM kernels: one buffer per (device, stream) -- kernels on one stream use it one after the
+    other, two streams (or two models stepped concurrently) never share one."""
+    key = (torch.device(dev).index, stream())
+    w = _ws.get(key)
     if w is None:
-        w = _ws[dev] = torch.empty(lib().cosy_train_workspace_bytes(), dtype=torch.uint8, device=dev)
+        w = _ws[key] = torch.empty(lib().cosy_train_workspace_bytes(), dtype=torch.uint8, device=dev)
     return w
 
 
