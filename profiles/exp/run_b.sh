@@ -1,4 +1,10 @@
-python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile | cut -c1-150
-export TMPDIR=/tmp
-rocprofv3 -M --kernel-trace --stats -f csv -d gpurun_out/px -o t -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2>&1
-grep -E "crop_" gpurun_out/px/t_kernel_stats.csv | cut -c1-120
+export COSY_TUNE_LIB=1
+run() { # tag env...
+  tag=$1; shift
+  env "$@" python bench.py --steps 3 --warmup 1 --no-cpu-baseline --layers > gpurun_out/rb_$tag.json 2> gpurun_out/rb_$tag.txt
+  echo "== $tag: $(python -c "import json;print(json.load(open('gpurun_out/rb_$tag.json'))['value'])")"
+  grep -E "^ *(1[89]|2[0-6]) pw_gemm" gpurun_out/rb_$tag.txt | awk '{for(i=1;i<=NF;i++) if($i=="us/fwd") printf "%s:%s ", $1, $(i-1)} END {print ""}'
+}
+run ns3 COSY_PW8_NS=3
+run ns6 COSY_PW8_NS=6
+COSY_TUNE_LIB= python -m pytest tests -m gpu -x -q 2>&1 | tail -3
