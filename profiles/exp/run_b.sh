@@ -3,8 +3,8 @@ run() { # tag env...
   tag=$1; shift
   env "$@" python bench.py --steps 3 --warmup 1 --no-cpu-baseline --layers > gpurun_out/rb_$tag.json 2> gpurun_out/rb_$tag.txt
   echo "== $tag: $(python -c "import json;print(json.load(open('gpurun_out/rb_$tag.json'))['value'])")"
-  grep -E "^ *(1[89]|2[0-6]) pw_gemm" gpurun_out/rb_$tag.txt | awk '{for(i=1;i<=NF;i++) if($i=="us/fwd") printf "%s:%s ", $1, $(i-1)} END {print ""}'
+  grep -E "^ *(1[89]|2[0-6]) pw_" gpurun_out/rb_$tag.txt | awk '{for(i=1;i<=NF;i++) if($i=="us/fwd") printf "%s:%s ", $1, $(i-1)} END {print ""}'
 }
-run ns3 COSY_PW8_NS=3
-run ns6 COSY_PW8_NS=6
-COSY_TUNE_LIB= python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+run pf2 COSY_PW_WAVE=1 COSY_PW_WAVE_PF=2
+run pf3 COSY_PW_WAVE=1 COSY_PW_WAVE_PF=3
+run pf4 COSY_PW_WAVE=1 COSY_PW_WAVE_PF=4
