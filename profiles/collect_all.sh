@@ -26,7 +26,7 @@ cp -r gpurun_out/prof_$TAG/summary.txt gpurun_out/prof_$TAG/pmc_traffic.json $OU
 cp gpurun_out/prof_$TAG/stats/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 # 5. batch sweep: throughput and matrix-core utilisation of the GEMM kernels at 256..2048 crops per forward
 for B in 256 512 1024 2048; do
-  python bench.py --steps 3 --warmup 1 --detections $B --bsz-objects $B --no-cpu-baseline --no-profile > $OUT/sweep_B$B.json 2> /dev/null
+  python bench.py --steps 4 --warmup 2 --detections $B --bsz-objects $B --no-cpu-baseline --no-profile > $OUT/sweep_B$B.json 2> /dev/null
   rocprofv3 -M --kernel-trace --pmc MfmaUtil SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES -f csv -d $OUT/sweep_pmc_B$B -o t -- \
       python bench.py --steps 1 --warmup 1 --detections $B --bsz-objects $B --no-cpu-baseline --no-profile > /dev/null 2> $OUT/sweep_pmc_B$B.err
 done
