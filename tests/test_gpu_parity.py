@@ -946,6 +946,15 @@ def test_crop_pack_all_window_paths(oracle):
     assert (got[5, :, :, :3] == 0).all() and (got[6, :, :, :3] == 0).all()          # outside / NaN box: no valid sample
     assert np.array_equal(got[..., 3:6].transpose(0, 3, 1, 2), renders)              # render channels copied exactly
     assert (got[..., 6:] == 0).all()                                                 # the two padding channels
+    # the same boxes through the TABLE-driven pixel path (per-crop tap tables: what cosy_crop_pack(net, ...) and the fused
+    # render + crop kernel run; entries wider than 4 pixels fall back to the per-pixel evaluation): identical bits
+    labels, meshes, renderer = _textured_setup()
+    TCO = dev(syn.make_TCO(5, B, z_range=(0.5, 0.9), xy=0.04))
+    Kc = dev(np.tile(np.array([[300., 0, W / 2], [0, 300., H / 2], [0, 0, 1]], np.float32), (B, 1, 1)))
+    x8t = torch.full((B, H, W, 8), -7.0, device='cuda')
+    renderer.render_crop_pack([dict(name=labels[i % len(labels)]) for i in range(B)], TCO, Kc, frames4, im_d, boxes_d, (H, W), x8=x8t, dtype=COSY_F32)
+    torch.cuda.synchronize()
+    assert torch.equal(x8t[..., :3].contiguous().view(torch.int32), x8[..., :3].contiguous().view(torch.int32))
 
 
 def test_roi_align_handmade_fixtures():
