@@ -339,7 +339,8 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         a.A = Dbuf; a.Wp = b.proj.Wp; a.out = out; a.scale = b.proj.scale; a.bias = b.proj.bias;
         a.res = b.skip ? in : nullptr; a.gate = w.gate;
         a.M = Bc * b.Ho * b.Wo; a.K = b.cmid; a.N = b.d.cout; a.HW = b.Ho * b.Wo; a.silu = 0; a.zeros = n->zeros;
-        a.a_chunked = b.wave;     // the wave front writes D as [sample][Cmid/16][HW][16]
+        // the wave front (and the row-mapped 8x8 kernel) write D as [sample][Cmid/16][HW][16]
+        a.a_chunked = b.wave || (b.fused && !b.rows && !b.wave && fuse_writes_chunked(b.d.cin, b.cmid, b.H, b.W, b.Ho, b.Wo, b.d.k, b.d.s, n->dtype));
         if ((rc = launch_pw_gemm(a, b.proj.cfg, n->dtype, s))) return rc;
         pw_name(b.proj, a);
         return mark(kn, i, pw_bytes(a, Bc), 2.0 * a.M * a.K * a.N);

@@ -61,6 +61,7 @@ struct FuseArgs {
 bool fuse_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W);
 int fuse_num_tiles(int Cin, int Ho, int Wo, int k, int s, int dtype);
 int launch_mbconv_front(const FuseArgs& a, int dtype, hipStream_t s);
+bool fuse_writes_chunked(int Cin, int Cmid, int H, int W, int Ho, int Wo, int k, int s, int dtype);   // D layout of launch_mbconv_front
 // row-streaming variant for the high-resolution blocks (kernels_mbconv.hip): same arguments, partial has ONE tile per sample
 bool rows_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W, int Ho, int Wo);
 void rows_kernel_name(int Cin, int Cmid, int k, int s, int dtype, int H, int W, int Ho, int Wo, char* buf, size_t n);

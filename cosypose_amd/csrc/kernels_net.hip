@@ -1075,7 +1075,7 @@ struct FuseSKArgs {
     unsigned rcp_w;   // ceil(2^16 / W): p / W == (p * rcp_w) >> 16 for p < MBr*16 (checked on the host)
 };
 
-template <typename T, int KS, int S, int R, int KBN, int MPW>
+template <typename T, int KS, int S, int R, int KBN, int MPW, bool ROWMAP = false>
 __global__ __launch_bounds__(512) void mbconv_small_kernel(FuseSKArgs a) {
     using raw_t = typename DT<T>::raw_t;
     constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
@@ -1140,9 +1140,14 @@ __global__ __launch_bounds__(512) void mbconv_small_kernel(FuseSKArgs a) {
     const int nyq = (a.Ho + R - 1) / R;
     const int units = NG * a.Wo * nyq;           // <= threads: every thread owns at most ONE (4-channel, column, R rows) unit
     const int stride = (nthr / NG) * NG;
-    const int cq = tid % NG;
-    const bool has_unit = tid < units && !COSY_DBG(a.dbg & 1);
-    const int uq = tid / NG, ux = uq % a.Wo, uyq = uq / a.Wo;
+    // Unit mapping.  Default: channel quads fastest (a pixel's 12 quads are 12 neighbouring lanes).  ROWMAP (8x8 maps: exactly 16
+    // spatial units per channel quad): the 16 units of a quad are the 16 lanes of one DPP row -- the squeeze sums reduce with
+    // 4 row shifts (no LDS pass, no barrier), the depthwise reads of 8 consecutive lanes hit 8 different pixels (pitch 208 B:
+    // all 32 banks once, conflict-free; quad-fastest had 2-way conflicts on every second half-row), and with D in the chunked
+    // layout a wave's store covers 16 pixels x 32 bytes contiguously.
+    const int cq = ROWMAP ? tid >> 4 : tid % NG;
+    const bool has_unit = (ROWMAP ? tid < 16 * NG : tid < units) && !COSY_DBG(a.dbg & 1);
+    const int uq = ROWMAP ? (tid & 15) : tid / NG, ux = uq % a.Wo, uyq = uq / a.Wo;
     // Global stores count in vmcnt on this ISA and retire in order with the loads: a wait for the NEXT chunk's DMA issued
     // after this chunk's output stores would also wait for the stores' acknowledgements (~2-3 us per chunk, measured).
     // So per chunk: [barrier] expand -> [barrier] issue DMA(ch+1) -> depthwise COMPUTE -> wait DMA -> output stores.
@@ -1232,19 +1237,38 @@ __global__ __launch_bounds__(512) void mbconv_small_kernel(FuseSKArgs a) {
                     if (uyq * R + r < a.Ho) sum[c] += v;
                 }
         }
+        if constexpr (ROWMAP) {
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) red[tid * CPT + c] = sum[c];
+            for (int c = 0; c < CPT; ++c) {     // fixed-order tree over the 16 lanes of the row; lane 15 holds the total
+                float v = sum[c];
+                v += dpp_row_shr0<1>(v); v += dpp_row_shr0<2>(v); v += dpp_row_shr0<4>(v); v += dpp_row_shr0<8>(v);
+                sum[c] = v;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) red[tid * CPT + c] = sum[c];
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // DMA(ch+1) landed (issued before any store of this chunk)
         if (has_unit) {
-            T* __restrict__ out = (T*)a.D + (size_t)b * a.Ho * a.Wo * a.Cmid + ch * CC + cq * CPT;
+            if constexpr (ROWMAP) {          // chunked D: [sample][Cmid/16][HW][16]
+                T* __restrict__ out = (T*)a.D + ((size_t)(b * (a.Cmid >> 4) + ch * (CC / 16) + (cq >> 2)) * a.Ho * a.Wo) * 16 + (cq & 3) * CPT;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int oy = uyq * R + r;
-                if (oy < a.Ho) store4(out + ((size_t)oy * a.Wo + ux) * a.Cmid, yv[r]);
+                for (int r = 0; r < R; ++r) {
+                    const int oy = uyq * R + r;
+                    if (oy < a.Ho) store4(out + ((size_t)oy * a.Wo + ux) * 16, yv[r]);
+                }
+                if ((tid & 15) == 15) *(f32x4*)(a.partial + (size_t)b * a.Cmid + ch * CC + cq * CPT) = f32x4{sum[0], sum[1], sum[2], sum[3]};
+            } else {
+                T* __restrict__ out = (T*)a.D + (size_t)b * a.Ho * a.Wo * a.Cmid + ch * CC + cq * CPT;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int oy = uyq * R + r;
+                    if (oy < a.Ho) store4(out + ((size_t)oy * a.Wo + ux) * a.Cmid, yv[r]);
+                }
             }
         }
         __syncthreads();   // red complete; everybody's DMA(ch+1) landed; all Et / parameter reads of this chunk are done
-        reduce_squeeze_sums(red, stride, NG, CPT, tid, nthr, a.partial + (size_t)b * a.Cmid + ch * CC);
+        if constexpr (!ROWMAP) reduce_squeeze_sums(red, stride, NG, CPT, tid, nthr, a.partial + (size_t)b * a.Cmid + ch * CC);
     }
 }
 
@@ -1275,16 +1299,24 @@ static FuseSmallPlan fuse_small_plan(int Cin, int Cmid, int H, int W, int Ho, in
 }
 static int fuse_small_enabled() { static const int v = tune_int("COSY_FUSE_SMALL", 1); return v; }
 
+// 8x8 maps: 16 spatial units per channel quad -> the row-mapped variant, which writes D in the chunked layout
+static bool fuse_small_rowmap(int Ho, int Wo, int threads) {
+    static const int on = tune_int("COSY_SMALL_ROWMAP", 1);
+    return on && Wo * cdiv(Ho, 4) == 16 && Ho % 4 == 0 && threads >= 192;
+}
 template <typename T, int KS, int KBN>
 static int launch_fuse_small_m(const FuseSmallPlan& p, const FuseSKArgs& k, int B, hipStream_t s) {
     const dim3 grid((unsigned)(B * k.ncg)), block(p.threads);
     static bool attr_set = false;
     if (!attr_set) {
-        COSY_CHECK_HIP(hipFuncSetAttribute((const void*)mbconv_small_kernel<T, KS, 1, 4, KBN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        COSY_CHECK_HIP(hipFuncSetAttribute((const void*)mbconv_small_kernel<T, KS, 1, 4, KBN, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024));
+        COSY_CHECK_HIP(hipFuncSetAttribute((const void*)mbconv_small_kernel<T, KS, 1, 4, KBN, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((mbconv_small_kernel<T, KS, 1, 4, KBN, 1>), grid, block, p.lds, s, k);
+    if (fuse_small_rowmap(k.Ho, k.Wo, p.threads)) hipLaunchKernelGGL((mbconv_small_kernel<T, KS, 1, 4, KBN, 1, true>), grid, block, p.lds, s, k);
+    else hipLaunchKernelGGL((mbconv_small_kernel<T, KS, 1, 4, KBN, 1, false>), grid, block, p.lds, s, k);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }
@@ -1314,6 +1346,12 @@ static bool fuse_use_small(int Cin, int Cmid, int H, int W, int Ho, int Wo, int 
     return fuse_small_plan(Cin, Cmid, H, W, Ho, Wo, k, s, 2).ok;
 }
 
+// does launch_mbconv_front write D in the chunked layout [sample][Cmid/16][HW][16] for this shape? (the project GEMM must know)
+bool fuse_writes_chunked(int Cin, int Cmid, int H, int W, int Ho, int Wo, int k, int s, int dtype) {
+    if (!fuse_use_small(Cin, Cmid, H, W, Ho, Wo, k, s, dtype)) return false;
+    const FuseSmallPlan p = fuse_small_plan(Cin, Cmid, H, W, Ho, Wo, k, s, 2);
+    return fuse_small_rowmap(Ho, Wo, p.threads);
+}
 int launch_mbconv_front(const FuseArgs& a, int dtype, hipStream_t s) {
     if (a.B == 0) return COSY_OK;
     if (fuse_use_small(a.Cin, a.Cmid, a.H, a.W, a.Ho, a.Wo, a.k, a.s, dtype)) return COSY_DISPATCH_T(dtype, launch_fuse_small_t<T>(a, s));

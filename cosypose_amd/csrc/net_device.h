@@ -70,6 +70,11 @@ __device__ __forceinline__ void load4(const bf16_t* p, float* v) {
     bf16x4 a = *(const bf16x4*)p; v[0] = (float)a[0]; v[1] = (float)a[1]; v[2] = (float)a[2]; v[3] = (float)a[3];
 }
 
+// lane i <- lane i-N of its 16-lane DPP row; lanes without a source read 0 (bound_ctrl:0)
+template <int N> __device__ __forceinline__ float dpp_row_shr0(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, true));
+}
+
 // Fixed-order (deterministic) reduction of per-thread squeeze sums parked in LDS as red[thread][CPT]: output (g, e) =
 // sum over the threads t = g, g + NG, ... < stride of red[t][e].  Spread over up to 4 threads per output (each sums
 // every 4th contribution, two xor-shuffles combine them) instead of one thread walking all of them: the serial walk
