@@ -27,6 +27,9 @@ __global__ void k(float* out, float seed) {
             }
             if (OP == 6) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c0));
             if (OP == 7) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(f32x2{c0, c0}));
+            if (OP == 8) asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(0x3f803f80u), "v"(0x3c003c00u));   // acc += a.lo*b.lo + a.hi*b.hi (bf16 pairs)
+            if (OP == 9) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(0x3c003c00u), "v"(0x20002000u));
+            if (OP == 10) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(a[i]) : "v"(0x3f803f80u), "v"(0x3c003c00u));
         }
     }
     float s = 0;
@@ -55,5 +58,6 @@ static void run(const char* name, int per_it) {
 int main() {
     run<0>("v_fma_f32", 1); run<6>("v_mul_f32", 1); run<1>("v_pk_fma_f32", 1); run<7>("v_pk_mul_f32", 1); run<2>("v_exp_f32", 1); run<3>("v_rcp_f32", 1);
     run<4>("v_cvt_pk_bf16_f32", 1); run<5>("silu chain (5 instr)", 5);
+    run<8>("v_dot2_f32_bf16", 1); run<9>("v_dot2_f32_f16", 1); run<10>("v_dot2c_f32_bf16", 1);
     return 0;
 }
