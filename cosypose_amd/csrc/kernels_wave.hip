@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
 // across batch sizes.
 #define COSY_WAVE_VARIANTS(X)                                                                                      \
     X(3, 2, 1, 8, 1, true, 2, 4) X(3, 1, 1, 4, 1, true, 3, 2) X(5, 2, 1, 4, 1, true, 3, 1) X(5, 1, 2, 2, 1, true, 3, 2)      \
-    X(3, 2, 2, 2, 1, true, 4, 1) X(3, 1, 3, 1, 1, true, 4, 1) X(5, 1, 3, 1, 1, true, 4, 1) X(5, 1, 5, 1, 1, true, 3, 1)      \
+    X(3, 2, 2, 2, 1, true, 4, 2) X(3, 1, 3, 1, 1, true, 4, 1) X(5, 1, 3, 1, 1, true, 4, 1) X(5, 1, 5, 1, 1, true, 3, 1)      \
     X(3, 1, 1, 5, 1, true, 2, 2) X(5, 2, 1, 6, 1, false, 2, 1) X(5, 1, 2, 3, 1, false, 2, 2) X(3, 2, 2, 4, 1, false, 3, 1)   \
     X(3, 1, 3, 2, 1, false, 3, 1) X(5, 1, 3, 2, 1, false, 2, 1) X(5, 1, 5, 2, 1, false, 2, 1)
 enum { WAVE_MAX_RSPLIT = 4 };
