@@ -3,7 +3,7 @@
 
 A "step" = one pass of the hot path over one batch of synthetic input.  --config selects the BASELINE.json workload:
   1 (default, the metric's config): D=256 detections per GPU over 16 frames 512x512, 21 objects, coarse 1 + refiner 4
-    iterations = 1280 pose-iterations per GPU per step, 256x256 crops, bf16 backbone; weak scaling (each rank its own 256);
+    iterations = 1280 pose-iterations per GPU per step, 256x256 crops, 16-bit backbone; weak scaling (each rank its own 256);
   2: T-LESS shape: 1024 candidates over 64 frames 540x720, 30 objects, refiner-only 4 iterations from given poses, fp16;
      STRONG scaling: the 1024 candidates are sharded over the ranks (get_predictions_sharded);
   3: BOP mix: 2048 candidates over 7 frame sizes (5x 640x480, 720x540, 1280x960), coarse 1 + refiner 4, bf16, strong
@@ -11,11 +11,19 @@ A "step" = one pass of the hot path over one batch of synthetic input.  --config
 Everything (frames, intrinsics, detections, mesh table, weights, the synthetic renderer's images) is resident in HBM
 before the timed region.  The refined poses of all ranks are exchanged by ONE RCCL all-gather per step.
 
+Storage type.  BASELINE configs[1] names bf16 AND north_star demands <= 1e-4 relative pose deviation; measured, bf16 storage
+(8 significant bits on every stored activation and weight) cannot meet that bound (3-6e-4 per parameter group) while fp16
+(11 bits, same bytes, same MFMA rate, saturating converts) does (<= 5e-5).  Parity is the first gate, so the headline
+`value` is measured in fp16; the same timed loop is repeated in bf16 and fp32 and reported beside it (`other_dtypes`), and
+`pose_deviation` is measured live: the benched dtype's refined poses against the fp32 HIP path (itself held to the reference
+at <= 1e-4 by the parity tests) on this very workload, per parameter group (rotation entries absolute, translation relative
+to each pose's own translation).
+
 One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel FAMILY of the backbone (all instantiations of one
 kernel template together; the dominant single instantiation is reported beside it), timed live with HIP events recorded on
 the launch stream after every launch (cosy_effnet_b3_set_profiling) in a second pass over the same steps right after the
 timed region (an event per kernel costs ~6 % of throughput, so not inside it).  `roofline.traffic` (HBM bytes per launch
-from PMC counters) cannot be measured from inside this process: it is taken from profiles/r02_pmc_traffic.json ONLY when
+from PMC counters) cannot be measured from inside this process: it is taken from profiles/r03_pmc_traffic.json ONLY when
 that file was collected for the same kernel sources (its `csrc_sha` matches the tree); otherwise null.
 `cpu_baseline` is the CPU oracle (a port of the reference's PyTorch-CPU arithmetic) on a bounded sample: warm-up, then the
 median of 5 repeats, at 1 thread (the reference pins OMP_NUM_THREADS=1) and at N threads.
@@ -72,40 +80,62 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(crop, n_det=8, repeats=5):
-    """The oracle (torch-CPU port of the reference arithmetic + C geometry/roi_align) on a bounded sample: one warm-up
-    batch, then the median of `repeats` (bop_predictions.py:132-134 times the reference the same way), at 1 thread (the
-    reference sets OMP_NUM_THREADS=1, cosypose/__init__.py:1-4) and at N threads."""
+def host_cpu():
+    model = ''
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                model = ln.split(':', 1)[1].strip(); break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 1
+
+
+def cpu_baseline(crop, repeats=3):
+    """The oracle (torch-CPU port of the reference arithmetic + C geometry/roi_align) on a bounded sample (~25 s): one
+    iteration of the loop at B = 1, 16, 64 detections (64 = the reference's bsz_objects) for the benched crop size and the
+    other one beside it, one warm-up then the median of `repeats` (bop_predictions.py:132-134 times the reference the same
+    way), at N threads; at 1 thread (the reference pins OMP_NUM_THREADS=1, cosypose/__init__.py:1-4) for B = 16.
+    `value` = the best rate at the benched crop size."""
     sys.path.insert(0, os.path.join(REPO, 'oracle'))
     import torch
     import cosy_oracle as O
     from cosypose_amd import synthetic as syn
-    H, W = crop
-    h, w = (512, 512) if H == W else (480, 640)
     sd = syn.golden_state_dict(0)
     tr = O.TorchRef(sd)
     pts = syn.make_mesh_points(7, 21, 2500)[:, np.random.RandomState(0).choice(2500, 2000, replace=False)]
-    obj, im, boxes = syn.make_detections(1, n_det, 2, 21, h, w)
-    frames = syn.make_frames(2, 2, h, w)[im]
-    K = syn.make_K(n_det, h, w)
-    TCO = O.tco_init_from_boxes(boxes, K)
-    rend = syn.make_renders(3, n_det, H, W)
-    run = lambda: O.pose_predictor_forward(frames, K, obj, TCO, pts, None, lambda i, t, k: rend, 1, (H, W), backbone=tr.net_forward)
     # the stock torch-CPU convolutions stop scaling at ~16 threads on the GPU box's 256-core host
     # (measured: 1 thread 10.3, 16 threads 17.3, 64 threads 10.6, 128 threads 3.7 crops/s at B=16)
     many = min(os.cpu_count() or 1, 16)
-    rates = {}
-    for cores in (1, many):
+
+    def rate(H, W, n_det, cores):
+        h, w = (512, 512) if H == W else (480, 640)
+        obj, im, boxes = syn.make_detections(1, n_det, 2, 21, h, w)
+        frames = syn.make_frames(2, 2, h, w)[im]
+        K = syn.make_K(n_det, h, w)
+        TCO = O.tco_init_from_boxes(boxes, K)
+        rend = syn.make_renders(3, n_det, H, W)
+        run = lambda: O.pose_predictor_forward(frames, K, obj, TCO, pts, None, lambda i, t, k: rend, 1, (H, W), backbone=tr.net_forward)
         torch.set_num_threads(cores)
         O.set_threads(cores)
         run()  # warm-up
         ts = []
         for _ in range(repeats):
             t0 = time.time(); run(); ts.append(time.time() - t0)
-        rates[cores] = n_det / float(np.median(ts))
-    return dict(value=round(rates[many], 3), unit='pose-iterations/s', cores=many, kind='port', value_1_thread=round(rates[1], 3),
-                sample=f'{n_det} detections x 1 iteration, {H}x{W} crops, fp32, torch-CPU backbone + C geometry/roi_align oracle; '
-                       f'warm-up then median of {repeats} at 1 and at {many} threads')
+        return round(n_det / float(np.median(ts)), 3)
+    sizes = [tuple(crop)] + [c for c in ((256, 256), (240, 320)) if c != tuple(crop)]
+    table = {}
+    for (H, W) in sizes:
+        key = f'{H}x{W}'
+        table[key] = {f'B={b}': rate(H, W, b, many) for b in (1, 16, 64)}
+        table[key]['B=16, 1 thread'] = rate(H, W, 16, 1)
+    key = '%dx%d' % tuple(crop)
+    model, ncpu = host_cpu()
+    return dict(value=max(table[key][f'B={b}'] for b in (1, 16, 64)), unit='pose-iterations/s', cores=many, kind='port',
+                value_1_thread=table[key]['B=16, 1 thread'], table=table, host=f'{model} ({ncpu} logical CPUs)',
+                sample=f'1 iteration of the loop at B = 1 / 16 / 64 detections, {key} crops (and the other crop size beside it), fp32, torch-CPU '
+                       f'backbone + C geometry/roi_align oracle; warm-up then median of {repeats}, {many} threads (and 1 thread at B = 16); '
+                       f'host rates on this pool vary by +-40 % between boxes')
 
 
 def make_scene(syn, torch, tc, pd, labels, seed, D, n_frames, h, w, n_obj, with_poses=False):
@@ -127,12 +157,13 @@ def main():
     ap.add_argument('--config', type=int, default=1, choices=[1, 2, 3], help='BASELINE.json configs[i] (see the module docstring)')
     ap.add_argument('--split', default='skewed', choices=['skewed', 'balanced'], help='config 3: how candidates are shared out')
     ap.add_argument('--crop', default='256x256', help='HxW of the crops: 256x256 (metric) or 240x320 (reference native)')
-    ap.add_argument('--dtype', default=None, choices=['bf16', 'fp16', 'fp32'], help='default: bf16 (configs 1, 3), fp16 (config 2)')
+    ap.add_argument('--dtype', default=None, choices=['bf16', 'fp16', 'fp32'], help='storage type of the backbone; default fp16 (see the module docstring)')
     ap.add_argument('--detections', type=int, default=None, help='override the number of candidates (per GPU for config 1, total otherwise)')
     ap.add_argument('--bsz-objects', type=int, default=None,
                     help='crops per forward: default 256 for config 1 (BASELINE configs[1] names batch=256), 512 for configs 2 and 3 '
                          '(their batches are 1024 / 2048 candidates; 512 per forward measured +9 %% over 256, profiles/r02_batch_sweep.txt)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-dtypes', action='store_true', help='skip the bf16 / fp32 repeats of the timed loop and the deviation pass')
     ap.add_argument('--no-profile', action='store_true', help='skip the per-kernel HIP-event pass (no roofline object)')
     ap.add_argument('--layers', action='store_true', help='print the per-launch table to stderr')
     ap.add_argument('--renderer', default='pregenerated', choices=['pregenerated', 'hip'],
@@ -158,7 +189,7 @@ def main():
     torch.cuda.set_device(local_device_index())
     H, W = (int(v) for v in args.crop.split('x'))
     cfg_i = args.config
-    dtype = args.dtype or ('fp16' if cfg_i == 2 else 'bf16')
+    dtype = args.dtype or 'fp16'
     n_obj = 30 if cfg_i == 2 else 21
     n_coarse, n_refine = (0, 4) if cfg_i == 2 else (1, 4)
     labels = np.array([f'obj_{i:06d}' for i in range(1, n_obj + 1)])
@@ -209,15 +240,14 @@ def main():
     predictor = CoarseRefinePosePredictor(coarse_model=coarse, refiner_model=refiner, bsz_objects=args.bsz_objects)
     iters_total = total * (n_coarse + n_refine)
     gather_us = []
+    use_dist = dist.is_available() and dist.is_initialized()     # world > 1, or a forced 1-rank RCCL group (COSY_FORCE_DIST=1)
 
-    def step():
-        t_g = None
+    def step(local_only=False):
         if cfg_i == 1:
             frames, K, det = scenes[0]
             final, _ = predictor.get_predictions(frames, K, detections=det, n_coarse_iterations=n_coarse, n_refiner_iterations=n_refine)
             poses = final.poses
-            if world > 1:
-                torch.cuda.synchronize(); t_g = time.perf_counter()
+            if use_dist and not local_only:
                 poses = all_gather_rows(poses, counts=per_rank)   # ONE collective: refined poses of all ranks, rank order
         elif cfg_i == 2:
             frames, K, init = scenes[0]
@@ -225,8 +255,6 @@ def main():
             poses = final.poses
         else:
             poses, _ = get_predictions_sharded_scenes(predictor, scenes, n_coarse, n_refine, **plan_kw)
-        if t_g is not None:
-            torch.cuda.synchronize(); gather_us.append((time.perf_counter() - t_g) * 1e6)
         return poses
 
     def sync():
@@ -256,6 +284,13 @@ def main():
         t = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # the collective alone, timed in its own pass (device events around the call; nothing is drained inside the timed region)
+    if use_dist and cfg_i == 1:
+        local = step(local_only=True)
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); all_gather_rows(local, counts=per_rank); e1.record(); e1.synchronize()
+            gather_us.append(e0.elapsed_time(e1) * 1e3)
     # Per-kernel timing for `roofline`: the SAME steps again with a HIP event recorded on the launch stream after every
     # backbone launch.  Kept out of the timed region on purpose: one event per kernel serialises back-to-back
     # launches and costs ~6 % of the headline value (measured 34.4k vs 32.3k pose-iter/s).
@@ -313,18 +348,63 @@ def main():
         roofline = line(inst_name, inst)                       # the dominant instantiation of the dominant family
         roofline['family'] = line(fam_name, fam)               # ... and the whole family (every instantiation together)
         roofline['traffic'] = None
-        tfile = os.path.join(REPO, 'profiles', 'r02_pmc_traffic.json')
+        tfile = os.path.join(REPO, 'profiles', 'r03_pmc_traffic.json')
         note = 'HBM counters need rocprofv3 (separate process): see profiles/collect.sh'
-        if os.path.exists(tfile) and cfg_i == 1 and args.crop == '256x256' and dtype == 'bf16' and (args.detections or 256) == 256:
+        if os.path.exists(tfile) and cfg_i == 1 and args.crop == '256x256' and (args.detections or 256) == 256:
             tj = json.load(open(tfile))
-            if tj.get('csrc_sha') == csrc_sha() and inst_name in tj.get('kernels', {}):
+            if tj.get('csrc_sha') == csrc_sha() and tj.get('dtype', 'bf16') == dtype and inst_name in tj.get('kernels', {}):
                 t = tj['kernels'][inst_name]
                 roofline['traffic'] = round(t['read_bytes'] + t['write_bytes'])
-                note = f"profiles/r02_pmc_traffic.json (PMC passes of this command on kernel sources {tj['csrc_sha']})"
+                note = f"profiles/r03_pmc_traffic.json (PMC passes of this command on kernel sources {tj['csrc_sha']})"
             else:
-                note = 'profiles/r02_pmc_traffic.json was collected for other kernel sources: not reported'
+                note = 'profiles/r03_pmc_traffic.json was collected for other kernel sources: not reported'
         roofline['traffic_source'] = note
         roofline['backbone_ms_per_forward'] = round(total_ms / max(n_fw, 1), 3)
+
+    # ---- the same timed loop in the other storage types, and the benched type's pose deviation from the fp32 HIP path
+    other, deviation = {}, None
+    if not args.no_other_dtypes and args.renderer == 'pregenerated':
+        def run_first(models):
+            for m in models:
+                m.renderer.i = 0          # same synthetic renders for every dtype
+            return step(local_only=True).clone()
+        ref_models = None
+        got_main = run_first([coarse, refiner])
+        for od in [d for d in ('bf16', 'fp16', 'fp32') if d != dtype]:
+            for m in (coarse, refiner):
+                m.compute_dtype = od
+            got = run_first([coarse, refiner])
+            if od == 'fp32':
+                ref_models = got
+            for _ in range(max(1, min(args.warmup, 1))):
+                step()
+            k_steps = max(2, min(args.steps, 6))
+            sync(); t1 = time.perf_counter()
+            for _ in range(k_steps):
+                step()
+            sync(); d1 = time.perf_counter() - t1
+            if world > 1:
+                tt = torch.tensor([d1], device='cuda', dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); d1 = float(tt.item())
+            other[od] = dict(value=round(iters_total * k_steps / d1, 1), ms_per_step=round(1e3 * d1 / k_steps, 3), steps=k_steps, poses=got)
+        for m in (coarse, refiner):
+            m.compute_dtype = dtype
+
+        def dev_of(a, b):
+            a = a.double().cpu().numpy().reshape(-1, 4, 4); b = b.double().cpu().numpy().reshape(-1, 4, 4)
+            rot = float(np.abs(a[:, :3, :3] - b[:, :3, :3]).max())
+            tn = np.maximum(np.abs(b[:, :3, 3]).max(axis=1), 1e-12)
+            return dict(rotation_abs=float('%.3g' % rot), translation_rel=float('%.3g' % (np.abs(a[:, :3, 3] - b[:, :3, 3]).max(axis=1) / tn).max()))
+        ref = ref_models if dtype != 'fp32' else got_main
+        if ref is not None:
+            if dtype != 'fp32':
+                deviation = dict(dev_of(got_main, ref), vs='fp32 HIP path, same workload, refined poses after all iterations, worst of '
+                                 f'{got_main.shape[0]} candidates', bound=1e-4)
+            for od, v in other.items():
+                p_ = v.pop('poses')
+                if od != 'fp32':
+                    v['pose_deviation'] = dev_of(p_, ref)
+        for v in other.values():
+            v.pop('poses', None)
 
     if rank == 0:
         value = iters_total * args.steps / dt
@@ -335,11 +415,14 @@ def main():
             'value': round(value, 1), 'unit': 'pose-iterations/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
             'dtype': dtype, 'data': 'synthetic',
+            'dtype_note': 'BASELINE configs[1] names bf16; bf16 storage misses north_star\'s 1e-4 pose bound, fp16 (same bytes, same MFMA '
+                          'rate) meets it: the headline is fp16, bf16 / fp32 are timed beside it in other_dtypes',
+            'pose_deviation': deviation, 'other_dtypes': other or None,
             'config': {'workload': desc + f', coarse {n_coarse} + refiner {n_refine} iterations, {H}x{W} crops, ' +
                                    ('synthetic on-device renders' if args.renderer == 'pregenerated' else
                                     'renders by the on-device HIP rasteriser (6k-triangle meshes) inside the loop'),
                        'pose_iterations_per_step': iters_total, 'candidates_per_rank': per_rank, 'bsz_objects': args.bsz_objects,
-                       'parallelism': f'candidate-sharded x{world}, 1 all-gather of refined poses per step',
+                       'parallelism': f'candidate-sharded x{world}, 1 all-gather of refined poses per step' + (' (RCCL, forced 1-rank group)' if use_dist and world == 1 else ''),
                        'all_gather_us': round(float(np.median(gather_us)), 1) if gather_us else None},
             'roofline': roofline,
             'path_hbm_frac': round(value / world * mb * 1e6 / (HBM_PEAK_GBS * 1e9), 5) if mb else None,

@@ -23,6 +23,8 @@ _SIGNATURES = {
     'cosy_effnet_b3_workspace_bytes': ([_P], _SZ),
     'cosy_effnet_b3_set_input_nchw': ([_P, _P, _I, _P], _I),
     'cosy_effnet_b3_features_nchw': ([_P, _I, _P, _P], _I),
+    'cosy_effnet_b3_set_probe': ([_P, _I, _P], _I),
+    'cosy_effnet_b3_block_info': ([_P, _I, _c.POINTER(_I)], _I),
     'cosy_effnet_b3_set_profiling': ([_P, _I], _I),
     'cosy_effnet_b3_profile_read': ([_P, _P, _I, _c.POINTER(_I)], _I),
     'cosy_frames_to_nhwc4': ([_P, _P, _I, _I, _I, _P], _I),

@@ -57,9 +57,13 @@ static long param_count() {
 
 struct PwLayer { int K = 0, N = 0; PwCfg cfg{4, 2}; void* Wp = nullptr; float* scale = nullptr; float* bias = nullptr; };
 struct Block {
-    BlkDef d; int cmid, cse, H, W, Ho, Wo, pad_lo, n_tiles; bool skip, fused, rows, wave;
+    BlkDef d; int cmid, cse, H, W, Ho, Wo, pad_lo, n_tiles;
+    bool skip;
+    bool wave;            // front = mbconv_wave_kernel (kernels_wave.hip)
+    bool small;           // front = mbconv_small_kernel (whole-image kernel of the late blocks)
+    bool fused;           // wave || small: the expanded tensor never reaches HBM; otherwise pw_gemm_dma -> E -> dwconv
     PwLayer exp, proj;
-    void* exp_wp_fused;   // expand weights packed in 48-channel tiles for mbconv_front_kernel
+    void* exp_wp_fused;   // expand weights packed in 16- (wave) or 48-channel (small) tiles for the fused front
     float *dw_w, *dw_scale, *dw_bias, *se_wr, *se_br, *se_we, *se_be;
 };
 
@@ -73,9 +77,10 @@ struct cosy_net {
     cosy::PwLayer head;
     void* X;
     int chunk, fuse;
-    unsigned fuse_mask;   // bit i: MBConv block i runs the fused expand+depthwise front kernel
-    unsigned rows_mask;   // bit i: ... in its row-streaming form (mbconv_rows_kernel) where the shape allows
-    unsigned wave_mask;   // bit i: ... in its wave-autonomous form (mbconv_wave_kernel) where the shape allows (wins over rows)
+    unsigned small_mask;  // bit i: MBConv block i may run the fused whole-image front kernel (mbconv_small_kernel)
+    unsigned wave_mask;   // bit i: ... the wave-autonomous front kernel (mbconv_wave_kernel); both only where the shape is built
+    int probe_layer;      // test probe (cosy_effnet_b3_set_probe): -2 = off
+    float* probe_out;
     // activation workspaces: ws[0] holds max_batch samples; ws[1] (half size) serves the second half-batch when the
     // forward is split over two internal streams so that VALU-bound and MFMA/bandwidth-bound kernels co-reside
     struct WS { void *act[2], *E, *D, *Hd, *actc[2], *Ec, *Dc; float *partial, *gate, *featbuf; } ws[2];
@@ -157,17 +162,16 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         int hi; static_pad(b.d.k, b.d.s, &b.pad_lo, &hi);
         b.skip = (b.d.s == 1 && b.d.cin == b.d.cout);  // id_skip, efficientnet.py:94
         b.n_tiles = dw_num_tiles(b.cmid, b.Ho, b.Wo, b.d.k);
-        // selected blocks (default 2-5 and 8): expand + depthwise fused, the expanded tensor stays in LDS
-        b.fused = n->fuse && b.d.e != 1 && ((n->fuse_mask >> i) & 1) && fuse_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
-        b.rows = n->fuse && b.d.e != 1 && ((n->rows_mask >> i) & 1) && rows_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W, b.Ho, b.Wo);
+        // fused fronts exist for the shapes of the two supported crop sizes (256x256, 240x320) in the 2-byte types; every other
+        // shape (and fp32) runs the generic unfused kernels, which are shape-agnostic
         b.wave = n->fuse && b.d.e != 1 && ((n->wave_mask >> i) & 1) && wave_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
-        if (b.wave) b.rows = false;
-        if (b.rows || b.wave) b.fused = true;
+        b.small = !b.wave && n->fuse && b.d.e != 1 && ((n->small_mask >> i) & 1) && small_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
+        b.fused = b.wave || b.small;
         b.exp_wp_fused = nullptr;
         if (b.d.e != 1) {
             mk_pw(b.exp, p, b.d.cin, b.cmid, p + (size_t)b.cmid * b.d.cin, b.H * b.W, false);
             if (b.fused) {
-                const PwCfg c48 = b.wave ? PwCfg{1, 1} : PwCfg{3, 1};   // 16-channel tiles for the wave kernel, 48 otherwise
+                const PwCfg c48 = b.wave ? PwCfg{1, 1} : PwCfg{3, 1};   // 16-channel tiles for the wave kernel, 48 for the small kernel
                 const size_t ne = pw_packed_elems(b.d.cin, b.cmid, c48, n->dtype);
                 b.exp_wp_fused = bump.take(ne * n->esz);
                 if (fill) {
@@ -176,7 +180,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
                     hipError_t e2 = hipMemcpy(b.exp_wp_fused, tmp.data(), tmp.size(), hipMemcpyHostToDevice);
                     if (e2 != hipSuccess) *herr = e2;
                 }
-                b.n_tiles = b.wave ? wave_max_tiles() : b.rows ? 1 : fuse_num_tiles(b.d.cin, b.Ho, b.Wo, b.d.k, b.d.s, n->dtype);
+                b.n_tiles = b.wave ? wave_max_tiles() : 1;
             }
             p += (size_t)b.cmid * b.d.cin + 4 * b.cmid;
         }
@@ -290,8 +294,14 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         if (!taps) return COSY_OK;
         return launch_taps(act, Bc, HW, C, n->dtype, taps + (size_t)b0 * 9 * 16, idx, s);
     };
+    // test probe: the whole activation `layer` as fp32 NCHW (layer -1 stem, 0..25 block outputs, 26 head, 100+i depthwise output
+    // D of block i, 200+i SE gate of block i as (B, Cmid))
+    auto probe = [&](int layer, const void* act, int Bc, int b0, int HW, int C, int chunked) -> int {
+        if (n->probe_layer != layer || !n->probe_out) return COSY_OK;
+        return launch_nhwc_to_nchw(act, Bc, HW, C, n->dtype, n->probe_out + (size_t)b0 * HW * C, s, chunked);
+    };
     // one MBConv block on Bc samples: [expand 1x1] -> depthwise (+squeeze partials) -> SE gate -> project 1x1 (+residual)
-    auto run_block = [&](int i, const void* in, void* out, int Bc, void* Ebuf, void* Dbuf) -> int {
+    auto run_block = [&](int i, const void* in, void* out, int Bc, void* Ebuf, void* Dbuf, int b0) -> int {
         const Block& b = n->blk[i];
         const void* src = in;
         int se_tiles = b.n_tiles;     // partial-sum tiles per sample the front kernel writes (the wave kernel decides per launch)
@@ -300,10 +310,9 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
             f.X = in; f.Wp = b.exp_wp_fused; f.s0 = b.exp.scale; f.b0 = b.exp.bias; f.dww = b.dw_w; f.s1 = b.dw_scale; f.b1 = b.dw_bias;
             f.D = Dbuf; f.partial = w.partial; f.zeros = n->zeros;
             f.B = Bc; f.H = b.H; f.W = b.W; f.Cin = b.d.cin; f.Cmid = b.cmid; f.Ho = b.Ho; f.Wo = b.Wo; f.k = b.d.k; f.s = b.d.s; f.pad_lo = b.pad_lo;
-            if ((rc = b.wave ? launch_mbconv_wave(f, n->dtype, &se_tiles, s) : b.rows ? launch_mbconv_rows(f, n->dtype, s) : launch_mbconv_front(f, n->dtype, s))) return rc;
+            if ((rc = b.wave ? launch_mbconv_wave(f, n->dtype, &se_tiles, s) : launch_mbconv_small(f, n->dtype, s))) return rc;
             if (b.wave) wave_kernel_name(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W, kn, sizeof(kn));
-            else if (b.rows) rows_kernel_name(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W, b.Ho, b.Wo, kn, sizeof(kn));
-            else fuse_kernel_name(b.d.cin, b.d.k, b.d.s, n->dtype, b.H, b.W, kn, sizeof(kn));
+            else small_kernel_name(b.d.cin, b.d.k, b.d.s, n->dtype, b.H, b.W, kn, sizeof(kn));
             if ((rc = mark(kn, i, ((double)Bc * b.H * b.W * b.d.cin + (double)Bc * b.Ho * b.Wo * b.cmid + (double)b.d.cin * b.cmid) * esz_d,
                            2.0 * Bc * b.H * b.W * b.d.cin * b.cmid + 2.0 * Bc * b.Ho * b.Wo * b.cmid * b.d.k * b.d.k))) return rc;
         } else {
@@ -340,10 +349,14 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         a.res = b.skip ? in : nullptr; a.gate = w.gate;
         a.M = Bc * b.Ho * b.Wo; a.K = b.cmid; a.N = b.d.cout; a.HW = b.Ho * b.Wo; a.silu = 0; a.zeros = n->zeros;
         // the wave front (and the row-mapped 8x8 kernel) write D as [sample][Cmid/16][HW][16]
-        a.a_chunked = b.wave || (b.fused && !b.rows && !b.wave && fuse_writes_chunked(b.d.cin, b.cmid, b.H, b.W, b.Ho, b.Wo, b.d.k, b.d.s, n->dtype));
+        a.a_chunked = b.wave || (b.small && small_writes_chunked(b.d.cin, b.cmid, b.H, b.W, b.Ho, b.Wo, b.d.k, b.d.s, n->dtype));
+        if ((rc = probe(100 + i, Dbuf, Bc, b0, b.Ho * b.Wo, b.cmid, a.a_chunked))) return rc;
+        if (n->probe_layer == 200 + i && n->probe_out)
+            COSY_CHECK_HIP(hipMemcpyAsync(n->probe_out + (size_t)b0 * b.cmid, w.gate, (size_t)Bc * b.cmid * sizeof(float), hipMemcpyDeviceToDevice, s));
         if ((rc = launch_pw_gemm(a, b.proj.cfg, n->dtype, s))) return rc;
         pw_name(b.proj, a);
-        return mark(kn, i, pw_bytes(a, Bc), 2.0 * a.M * a.K * a.N);
+        if ((rc = mark(kn, i, pw_bytes(a, Bc), 2.0 * a.M * a.K * a.N))) return rc;
+        return probe(i, out, Bc, b0, b.Ho * b.Wo, b.d.cout, 0);
     };
     auto stage_tap_index = [&](int i) -> int { for (int q = 0; q < 7; ++q) if (STAGE_END[q] == i) return q + 1; return -1; };
 
@@ -358,11 +371,12 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         snprintf(kn, sizeof(kn), "stem_kernel<%s>", dt_name(n->dtype));
         if ((rc = mark(kn, -1, ((double)Bc * n->H * n->W * 8 + (double)Bc * n->Hs * n->Ws * STEM_C) * esz_d, 2.0 * Bc * n->Hs * n->Ws * STEM_C * IN_C * 9))) return rc;
         if ((rc = tap(w.actc[0], Bc, b0, n->Hs * n->Ws, STEM_C, 0))) return rc;
+        if ((rc = probe(-1, w.actc[0], Bc, b0, n->Hs * n->Ws, STEM_C, 0))) return rc;
         int cur = 0;
         for (int i = 0; i < EARLY_BLOCKS; ++i) {
             const Block& b = n->blk[i];
             void* out = (i == EARLY_BLOCKS - 1) ? (void*)((char*)w.act[0] + (size_t)b0 * handover) : w.actc[cur ^ 1];
-            if ((rc = run_block(i, w.actc[cur], out, Bc, w.Ec, w.Dc))) return rc;
+            if ((rc = run_block(i, w.actc[cur], out, Bc, w.Ec, w.Dc, b0))) return rc;
             cur ^= 1;
             const int ti = stage_tap_index(i);
             if (ti >= 0 && (rc = tap(out, Bc, b0, b.Ho * b.Wo, b.d.cout, ti))) return rc;
@@ -372,7 +386,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
     int cur = 0;
     for (int i = EARLY_BLOCKS; i < 26; ++i) {
         const Block& b = n->blk[i];
-        if ((rc = run_block(i, w.act[cur], w.act[cur ^ 1], B, w.E, w.D))) return rc;
+        if ((rc = run_block(i, w.act[cur], w.act[cur ^ 1], B, w.E, w.D, 0))) return rc;
         cur ^= 1;
         const int ti = stage_tap_index(i);
         if (ti >= 0 && (rc = tap(w.act[cur], B, 0, b.Ho * b.Wo, b.d.cout, ti))) return rc;
@@ -384,6 +398,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
     pw_name(n->head, a);
     if ((rc = mark(kn, 26, pw_bytes(a, B), 2.0 * a.M * a.K * a.N))) return rc;
     if ((rc = tap(w.Hd, B, 0, n->Hf * n->Wf, HEAD_C, 8))) return rc;
+    if ((rc = probe(26, w.Hd, B, 0, n->Hf * n->Wf, HEAD_C, 0))) return rc;
     if ((rc = launch_pool_fc(w.Hd, n->fc_w, n->fc_b, feat, w.featbuf, pose, B, n->Hf * n->Wf, n->dtype, s))) return rc;
     snprintf(kn, sizeof(kn), "pool_kernel<%s>+fc9_kernel", dt_name(n->dtype));
     if ((rc = mark(kn, 26, (double)B * n->Hf * n->Wf * HEAD_C * esz_d, 2.0 * B * HEAD_C * (n->Hf * n->Wf + N_POSE)))) return rc;
@@ -393,7 +408,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
 
 // Whole-batch entry: one stream, or two half-batches on two internal streams (fork/join with events; capturable).
 static int net_forward_top(cosy_net* n, int B, float* feat, float* pose, float* taps, hipStream_t s) {
-    const bool dual = n->nstreams == 2 && B >= 32 && !taps && !n->prof_on;
+    const bool dual = n->nstreams == 2 && B >= 32 && !taps && !n->prof_on && n->probe_layer == -2;
     n->last_split = dual ? (B + 1) / 2 : B;
     if (!dual) return net_forward(n, n->ws[0], 0, B, feat, pose, taps, s, true);
     const int B0 = n->last_split, B1 = B - B0;
@@ -431,7 +446,13 @@ int cosy_effnet_b3_out_hw(int H, int W, int* oh, int* ow) {
 int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, int H, int W, int max_batch, cosy_net_t** out) {
     COSY_REQUIRE(host_params && out, "create: null argument");
     COSY_REQUIRE(dtype == COSY_F32 || dtype == COSY_BF16 || dtype == COSY_F16, "create: dtype %d not supported (0=f32, 1=bf16, 2=f16)", dtype);
-    COSY_REQUIRE(H >= 32 && W >= 32 && max_batch >= 1, "create: bad shape H=%d W=%d max_batch=%d", H, W, max_batch);
+    // Supported crop sizes.  The fused fronts are built for the maps of 256x256 and 240x320 (the metric's and the reference's
+    // crop size); any other size runs the shape-agnostic kernels (pw_gemm_dma / dwconv), which need: even sides (the stem's
+    // stride-2 output is H/2 x W/2), a stem map that is a whole number of 16-pixel groups, and final maps of >= 16 pixels
+    // (the gate rows of the samples under one GEMM tile must fit the LDS).  Anything else fails here, not later.
+    COSY_REQUIRE(max_batch >= 1, "create: bad max_batch=%d", max_batch);
+    COSY_REQUIRE(H >= 128 && W >= 128 && H <= 1024 && W <= 1024 && H % 16 == 0 && W % 16 == 0,
+                 "create: crop size %dx%d not supported (sides must be multiples of 16 in [128, 1024])", H, W);
     if ((long)n_floats != param_count()) {
         set_error("create: parameter blob has %zu floats, expected %ld", n_floats, param_count());
         return COSY_ESIZE;
@@ -439,15 +460,13 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
     cosy_net* n = (cosy_net*)calloc(1, sizeof(cosy_net));
     if (!n) { set_error("create: host allocation failed"); return COSY_ENOMEM; }
     n->dtype = dtype; n->H = H; n->W = W; n->maxB = max_batch; n->esz = dtype == COSY_F32 ? 4 : 2;
+    n->probe_layer = -2; n->probe_out = nullptr;
     n->Hs = out_dim(H, 3, 2); n->Ws = out_dim(W, 3, 2);
     {   // schedule knobs: fixed in the shipping build, env-overridable only under -DCOSY_TUNE (cosy_common.h)
         const int c = tune_int("COSY_EARLY_CHUNK", 0);   // measured: chunking the early segment is slower (kernels are issue-bound)
         n->chunk = c <= 0 ? max_batch : c;
         n->fuse = tune_int("COSY_FUSE", 1);
-        // measured per block (256^2, bf16): the tiled kernel wins for blocks 2-5 and 8 and loses for the k=5 stride-1 blocks
-        // 6/7 (halo recompute x1.9); blocks 19-25 (8x8 maps) run the whole-image kernel (mbconv_small_kernel)
-        n->fuse_mask = (unsigned)tune_int("COSY_FUSE_MASK", 0x3f8013c);
-        n->rows_mask = (unsigned)tune_int("COSY_ROWS_MASK", 0x1fc);     // blocks 2-8: the maps that are >= 32 pixels wide
+        n->small_mask = (unsigned)tune_int("COSY_SMALL_MASK", 0x3f80000);   // blocks 19-25 (8x8 / 7x10 maps): whole-image kernel
         n->wave_mask = (unsigned)tune_int("COSY_WAVE_MASK", 0x3fffc);   // blocks 2-17: maps 16..128 pixels wide, stride per shape table
         n->nstreams = tune_int("COSY_STREAMS", 1) == 2 && max_batch >= 32 ? 2 : 1;   // measured: 2 streams x half batches is ~10 % slower
     }
@@ -520,6 +539,22 @@ int cosy_effnet_b3_profile_read(cosy_net_t* n, cosy_prof_rec_t* recs, int cap, i
     for (int i = 0; i < ns; ++i) recs[i].ms_avg /= (float)recs[i].n;
     *n_out = ns;
     n->prof_seg = 0;
+    return COSY_OK;
+}
+
+int cosy_effnet_b3_set_probe(cosy_net_t* n, int layer, float* out) {
+    COSY_REQUIRE(n, "set_probe: null net");
+    COSY_REQUIRE(layer == -2 || out, "set_probe: null output");
+    COSY_REQUIRE(layer >= -2 && layer < 226, "set_probe: bad layer %d", layer);
+    n->probe_layer = layer; n->probe_out = layer == -2 ? nullptr : out;
+    return COSY_OK;
+}
+
+int cosy_effnet_b3_block_info(const cosy_net_t* n, int i, int* dims) {
+    COSY_REQUIRE(n && dims && i >= 0 && i < 26, "block_info: bad arguments");
+    const Block& b = n->blk[i];
+    const int v[10] = {b.H, b.W, b.Ho, b.Wo, b.d.cin, b.cmid, b.d.cout, b.wave ? 1 : b.small ? 2 : 0, b.d.k, b.d.s};
+    for (int q = 0; q < 10; ++q) dims[q] = v[q];
     return COSY_OK;
 }
 

@@ -26,12 +26,12 @@ struct PwArgs {
     const float* gate;   // (B,K) SE gate applied to A rows, or null
     int M, K, N, HW;     // HW = rows per sample (for the gate)
     int silu;
-    const void* zeros;   // >= 16 zero bytes (global): source of padded rows/k for the LDS-DMA pipeline; null -> classic kernel
-    int a_chunked;       // 1: A is laid out [sample][K/16][HW][16] (what the wave front writes: a wave's row is one contiguous run); DMA kernel only
+    const void* zeros;   // >= 16 zero bytes (global): source of padded rows/k for the LDS-DMA pipeline
+    int a_chunked;       // 1: A is laid out [sample][K/16][HW][16] (what the wave front writes: a wave's row is one contiguous run)
 };
 int launch_pw_gemm(const PwArgs& a, PwCfg cfg, int dtype, hipStream_t s);
 void pw_kernel_name(const PwArgs& a, PwCfg c, int dtype, char* buf, size_t n);
-void fuse_kernel_name(int Cin, int k, int s, int dtype, int H, int W, char* buf, size_t n);
+void small_kernel_name(int Cin, int k, int s, int dtype, int H, int W, char* buf, size_t n);
 
 struct DwArgs {
     const void* in;      // (B,H,W,C)
@@ -46,10 +46,10 @@ struct DwArgs {
 int dw_num_tiles(int C, int Ho, int Wo, int k);
 int launch_dwconv(const DwArgs& a, int dtype, hipStream_t s);
 
-// fused expand(1x1, MFMA) + depthwise front half of an MBConv block (the expanded tensor stays in LDS)
+// fused expand(1x1, MFMA) + depthwise front half of an MBConv block (the expanded tensor never leaves the CU)
 struct FuseArgs {
     const void* X;       // (B,H,W,Cin) block input
-    const void* Wp;      // expand weights packed with PwCfg{3,1} (48-channel tiles)
+    const void* Wp;      // expand weights packed with PwCfg{3,1} (48-channel tiles; small kernel) / PwCfg{1,1} (wave kernel)
     const float* s0; const float* b0;   // folded BN0 (Cmid)
     const float* dww;    // (k*k, Cmid) fp32 depthwise taps
     const float* s1; const float* b1;   // folded BN1 (Cmid)
@@ -58,14 +58,10 @@ struct FuseArgs {
     const void* zeros;
     int B, H, W, Cin, Cmid, Ho, Wo, k, s, pad_lo;
 };
-bool fuse_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W);
-int fuse_num_tiles(int Cin, int Ho, int Wo, int k, int s, int dtype);
-int launch_mbconv_front(const FuseArgs& a, int dtype, hipStream_t s);
-bool fuse_writes_chunked(int Cin, int Cmid, int H, int W, int Ho, int Wo, int k, int s, int dtype);   // D layout of launch_mbconv_front
-// row-streaming variant for the high-resolution blocks (kernels_mbconv.hip): same arguments, partial has ONE tile per sample
-bool rows_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W, int Ho, int Wo);
-void rows_kernel_name(int Cin, int Cmid, int k, int s, int dtype, int H, int W, int Ho, int Wo, char* buf, size_t n);
-int launch_mbconv_rows(const FuseArgs& a, int dtype, hipStream_t s);
+// whole-image variant for the small maps of the late blocks (kernels_net.hip: mbconv_small_kernel); partial has ONE tile per sample
+bool small_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W);
+int launch_mbconv_small(const FuseArgs& a, int dtype, hipStream_t s);
+bool small_writes_chunked(int Cin, int Cmid, int H, int W, int Ho, int Wo, int k, int s, int dtype);   // D layout of launch_mbconv_small
 // wave-autonomous variant (kernels_wave.hip): expanded rows in registers, no LDS ring / barriers; expand weights packed with
 // PwCfg{1,1} (16-channel tiles, natural row order); partial has ONE tile per sample
 bool wave_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W);
@@ -91,7 +87,7 @@ int launch_stem(const void* x_nhwc8, const void* w_packed, const float* scale, c
                 int B, int H, int W, int Ho, int Wo, int dtype, hipStream_t s);
 int launch_pool_fc(const void* head /*(B,HW,1536)*/, const float* fc_w /*(9,1536)*/, const float* fc_b, float* feat_or_null,
                    float* feat_scratch, float* pose, int B, int HW, int dtype, hipStream_t s);
-int launch_nhwc_to_nchw(const void* act /*(B,HW,C)*/, int B, int HW, int C, int dtype, float* out, hipStream_t s);
+int launch_nhwc_to_nchw(const void* act /*(B,HW,C)*/, int B, int HW, int C, int dtype, float* out, hipStream_t s, int chunked = 0);
 int launch_taps(const void* act /*(B,HW,C)*/, int B, int HW, int C, int dtype, float* taps /*(B,9,16)*/, int tap_index,
                 hipStream_t s);
 

@@ -89,8 +89,6 @@ void pw_pack_weights(const float* w, int K, int N, PwCfg c, int dtype, void* dst
                     }
 }
 
-static bool pw_use_dma(const PwArgs& a);
-static int fuse_et_f32();
 // samples an m-tile of bm rows can touch when a sample has hw rows
 static inline int pw_gate_nsamp(int bm, int hw) { return (bm + hw - 2) / hw + 1; }
 struct PwKArgs {
@@ -100,163 +98,6 @@ struct PwKArgs {
     int nsamp, rowgate;   // DMA kernel gate: samples under one m-tile; 1 = gate the activation fragments per row
     int a_chunked;        // A is [sample][K/16][HW][16] (see PwArgs)
 };
-
-template <typename T, int NI, int WN>
-__global__ __launch_bounds__(256) void pw_gemm_kernel(PwKArgs a) {
-    using D = DT<T>;
-    using raw_t = typename D::raw_t;
-    constexpr int EPL = D::EPL, KB = D::KB;
-    constexpr int WM = 4 / WN, MI = 4, BM = 64 * WM, BN = 16 * NI * WN;
-    constexpr int NA = BM / 16, NW = NI * WN;  // fragment blocks per k-block
-    constexpr int NLA = 2 * NA / 4;            // A loads per thread per k-tile (2 k-blocks)
-    constexpr int NLW = (2 * NW + 3) / 4;
-    __shared__ __attribute__((aligned(16))) char lds[(NA + NW) * 2 * 1024];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    // XCD-aware tile order: workgroup id%8 selects the XCD; all n-tiles of one m-tile run on one XCD so
-    // the activation rows are fetched into a single L2.
-    const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
-    const int mt = (jj / a.NT) * 8 + xcd, nt = jj % a.NT;
-    if (mt >= a.MT) return;
-    const int m0 = mt * BM, n0 = nt * BN;
-    const T* __restrict__ A = (const T*)a.A;
-    const T* __restrict__ Wp = (const T*)a.Wp;
-    const int K = a.K, M = a.M, N = a.N;
-
-    // ---- per-thread staging coordinates (wave w stages A row-blocks [w*NA/4, (w+1)*NA/4) x 2 k-blocks)
-    const int row = lane & 15, kg = lane >> 4;
-    const int mthr = m0 + wave * (NA / 4) * 16 + row;
-    const T* Athr = A + (size_t)mthr * K + kg * EPL;
-    int gofs[NLA / 2];
-#pragma unroll
-    for (int i = 0; i < NLA / 2; ++i) {
-        const int m = mthr + i * 16;
-        gofs[i] = (a.gate && m < M) ? (m / a.HW) * K : 0;
-    }
-    raw_t ra[NLA], rw[NLW];
-
-    auto load_tile = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < NLA; ++i) {
-            const int mb = i >> 1, kbi = i & 1;
-            const int m = mthr + mb * 16, k = (kt * 2 + kbi) * KB + kg * EPL;
-            raw_t v;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) v[e] = 0;
-            if (m < M && k < K) {
-                v = *(const raw_t*)(Athr + (size_t)mb * 16 * K + (kt * 2 + kbi) * KB);
-                if (a.gate) {
-                    float f[EPL], g[EPL];
-                    to_f32(v, f);
-                    const float* gp = a.gate + gofs[mb] + k;
-#pragma unroll
-                    for (int e = 0; e < EPL; e += 4) load4(gp + e, g + e);
-#pragma unroll
-                    for (int e = 0; e < EPL; ++e) f[e] *= g[e];
-                    from_f32(v, f);
-                }
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < NLW; ++i) {
-            const int wb = i * 4 + wave;
-            if (wb < 2 * NW) {
-                const int kbi = wb / NW, nb = wb % NW;
-                rw[i] = *(const raw_t*)(Wp + ((size_t)(nt * NW + nb) * a.nkb_total + kt * 2 + kbi) * 64 * EPL + lane * EPL);
-            }
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < NLA; ++i) {
-            const int mb = wave * (NA / 4) + (i >> 1), kbi = i & 1;
-            *(raw_t*)(lds + (kbi * NA + mb) * 1024 + lane * 16) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NLW; ++i) {
-            const int wb = i * 4 + wave;
-            if (wb < 2 * NW) {
-                const int kbi = wb / NW, nb = wb % NW;
-                *(raw_t*)(lds + (2 * NA + kbi * NW + nb) * 1024 + lane * 16) = rw[i];
-            }
-        }
-    };
-
-    f32x4 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nkt = (a.nkb_valid + 1) >> 1;
-    load_tile(0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < nkt) load_tile(kt + 1);
-        const int nv = a.nkb_valid - kt * 2 < 2 ? a.nkb_valid - kt * 2 : 2;
-        for (int kbi = 0; kbi < nv; ++kbi) {
-            raw_t fw[NI], fa[MI];
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) fw[ni] = *(const raw_t*)(lds + (2 * NA + kbi * NW + wn * NI + ni) * 1024 + lane * 16);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) fa[mi] = *(const raw_t*)(lds + (kbi * NA + wm * MI + mi) * 1024 + lane * 16);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], fw[ni], fa[mi]);
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue: lane holds, for pixel row m, the 4*NI consecutive channels starting at nl
-    const int nl = n0 + wn * 16 * NI + kg * 4 * NI;
-    float sc[NI][4], bi[NI][4];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        load4(a.scale + nl + ni * 4, sc[ni]);
-        load4(a.bias + nl + ni * 4, bi[ni]);
-    }
-    T* __restrict__ out = (T*)a.out;
-    const T* __restrict__ res = (const T*)a.res;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + (wm * MI + mi) * 16 + row;
-        if (m >= M) continue;
-        float y[NI * 4];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[mi][ni][r] * sc[ni][r] + bi[ni][r];
-                if (a.silu) v = v * sigmoid_t<T>(v);
-                y[ni * 4 + r] = v;
-            }
-        const size_t o = (size_t)m * N + nl;
-        if (res) {
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                if (nl + ni * 4 < N) {
-                    float rv[4];
-                    load4(res + o + ni * 4, rv);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) y[ni * 4 + r] += rv[r];
-                }
-        }
-        if constexpr (sizeof(T) == 2 && NI % 2 == 0) {
-            // two adjacent 4-channel groups -> one 16-byte store (nl and N are multiples of 8)
-#pragma unroll
-            for (int ni = 0; ni < NI; ni += 2)
-                if (nl + ni * 4 < N) store8(out + o + ni * 4, y + ni * 4);
-        } else {
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                if (nl + ni * 4 < N) store4(out + o + ni * 4, y + ni * 4);
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // Pipelined variant: both operands arrive by asynchronous global->LDS DMA (global_load_lds, 16 B/lane, one
@@ -427,7 +268,7 @@ __global__ __launch_bounds__(NWV * 64) void pw_gemm_dma_kernel(PwKArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- epilogue (same as pw_gemm_kernel)
+    // ---- epilogue: lane holds, for pixel row m, the 4*NI consecutive channels starting at nl
     const int nl = n0 + wn * 16 * NI + kg * 4 * NI;
     float sc[NI][4], bi[NI][4];
 #pragma unroll
@@ -486,6 +327,7 @@ static int launch_pw_dma_mi(PwKArgs k, hipStream_t s) {
     k.rowgate = GATE && (k.HW % 64 != 0);
     k.nsamp = k.rowgate ? pw_gate_nsamp(16 * MI * WM, k.HW) : 2;
     const size_t lds = (size_t)NS * NB * 1024 + 1024 + (GATE ? (size_t)k.nsamp * k.nkb_total * DT<T>::KB * 4 : 0);
+    COSY_REQUIRE(lds <= 160 * 1024, "pw_gemm_dma: the gate rows of %d samples x K=%d do not fit the LDS (map of %d pixels too small)", k.nsamp, k.K, k.HW);
     static bool attr_set = false;
     if (!attr_set) {
         COSY_CHECK_HIP(hipFuncSetAttribute((const void*)pw_gemm_dma_kernel<T, NI, WN, NS, GATE, MI, NWV>,
@@ -553,47 +395,25 @@ static int launch_pw_t(const PwArgs& a, PwCfg c, int dtype, hipStream_t s) {
     k.nkb_total = pw_nkb_total(a.K, dtype); k.nkb_valid = cdiv(a.K, pw_kb(dtype));
     const int grid = cdiv(k.MT, 8) * 8 * k.NT;
     k.zeros = a.zeros; k.nsamp = 2; k.rowgate = 0;
-    if (a.a_chunked && (!pw_use_dma(a) || a.K % 16)) { set_error("pw_gemm: the chunked activation layout needs the DMA kernel and K %% 16 == 0 (K=%d)", a.K); return COSY_EINVAL; }
-    if (pw_use_dma(a)) return a.gate ? launch_pw_dma<T, true>(k, c, grid, s) : launch_pw_dma<T, false>(k, c, grid, s);
-    if (c.NI == 4 && c.WN == 2) hipLaunchKernelGGL((pw_gemm_kernel<T, 4, 2>), dim3(grid), dim3(256), 0, s, k);
-    else if (c.NI == 3 && c.WN == 2) hipLaunchKernelGGL((pw_gemm_kernel<T, 3, 2>), dim3(grid), dim3(256), 0, s, k);
-    else if (c.NI == 3 && c.WN == 1) hipLaunchKernelGGL((pw_gemm_kernel<T, 3, 1>), dim3(grid), dim3(256), 0, s, k);
-    else if (c.NI == 2 && c.WN == 1) hipLaunchKernelGGL((pw_gemm_kernel<T, 2, 1>), dim3(grid), dim3(256), 0, s, k);
-    else { set_error("pw_gemm: unsupported tile config NI=%d WN=%d", c.NI, c.WN); return COSY_EINVAL; }
-    COSY_CHECK_HIP(hipGetLastError());
-    return COSY_OK;
+    COSY_REQUIRE(a.zeros, "pw_gemm: the zero page is missing");
+    if (a.a_chunked && a.K % 16) { set_error("pw_gemm: the chunked activation layout needs K %% 16 == 0 (K=%d)", a.K); return COSY_EINVAL; }
+    return a.gate ? launch_pw_dma<T, true>(k, c, grid, s) : launch_pw_dma<T, false>(k, c, grid, s);
 }
 
 static const char* tname(int dtype) { return dtype == COSY_F32 ? "float" : dtype == COSY_BF16 ? "__bf16" : "_Float16"; }
-static bool pw_use_dma(const PwArgs& a) {
-    static const int use_dma = tune_int("COSY_PW_DMA", 1);
-    // gate rows of every sample under a 128-row m-tile sit in LDS: bound them (tiny maps fall back to pw_gemm_kernel)
-    return use_dma && a.zeros && (!a.gate || a.HW % 64 == 0 || pw_gate_nsamp(128, a.HW) <= 4);
-}
 // the kernel symbol (as rocprofv3 demangles it) that launch_pw_gemm will run for these arguments
 void pw_kernel_name(const PwArgs& a, PwCfg c, int dtype, char* buf, size_t n) {
-    if (pw_use_dma(a)) {
-        const int nkb = cdiv(a.K, pw_kb(dtype));
-        static const int deep = tune_int("COSY_PW_NS", 3);
-        static const int mi_env = tune_int("COSY_PW_MI", 4);
-        const int mi = (mi_env == 2 && nkb > 2 && (!a.gate || a.HW % 64 == 0)) ? 2 : 4;
-        if (c.WV == 8) snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, 3, %s, 4, 8>", tname(dtype), c.NI, c.WN, a.gate ? "true" : "false");
-        else snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, %d, %s, %d>", tname(dtype), c.NI, c.WN,
-                 nkb <= 2 ? 2 : (deep >= 4 && nkb >= 8 ? 4 : 3), a.gate ? "true" : "false", mi);
-    } else {
-        snprintf(buf, n, "pw_gemm_kernel<%s, %d, %d>", tname(dtype), c.NI, c.WN);
-    }
+    const int nkb = cdiv(a.K, pw_kb(dtype));
+    static const int deep = tune_int("COSY_PW_NS", 3);
+    static const int mi_env = tune_int("COSY_PW_MI", 4);
+    const int mi = (mi_env == 2 && nkb > 2 && (!a.gate || a.HW % 64 == 0)) ? 2 : 4;
+    if (c.WV == 8) snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, 3, %s, 4, 8>", tname(dtype), c.NI, c.WN, a.gate ? "true" : "false");
+    else snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, %d, %s, %d>", tname(dtype), c.NI, c.WN,
+                  nkb <= 2 ? 2 : (deep >= 4 && nkb >= 8 ? 4 : 3), a.gate ? "true" : "false", mi);
 }
-void fuse_kernel_name(int Cin, int k, int s, int dtype, int H, int W, char* buf, size_t n) {
-    const int esz = dtype == COSY_F32 ? 4 : 2;
-    if (cdiv(Cin, esz == 2 ? 32 : 16) > 2) {   // the whole-image kernel of the small maps
-        const int mbr = cdiv(H * W, 16), mpw = cdiv(mbr, (mbr <= 4 ? 256 : 512) / 64);
-        snprintf(buf, n, "mbconv_small_kernel<%s, %d, %d, %d, %d, %d>", tname(dtype), k, s, s == 1 ? 4 : 2, cdiv(Cin, 32), mpw);
-        return;
-    }
-    const int et32 = esz == 4 ? 1 : fuse_et_f32();
-    snprintf(buf, n, "mbconv_front_kernel<%s, %s, %d, %d, %d, %d>", tname(dtype), et32 ? "float" : tname(dtype), k, s, s == 1 ? 4 : 2,
-             cdiv(Cin, esz == 2 ? 32 : 16));
+void small_kernel_name(int Cin, int k, int s, int dtype, int H, int W, char* buf, size_t n) {
+    const int mbr = cdiv(H * W, 16), mpw = cdiv(mbr, (mbr <= 4 ? 256 : 512) / 64);
+    snprintf(buf, n, "mbconv_small_kernel<%s, %d, %d, %d, %d, %d>", tname(dtype), k, s, s == 1 ? 4 : 2, cdiv(Cin, 32), mpw);
 }
 
 int launch_pw_gemm(const PwArgs& a, PwCfg cfg, int dtype, hipStream_t s) {
@@ -805,255 +625,20 @@ int launch_dwconv(const DwArgs& a, int dtype, hipStream_t s) {
 }
 
 // ==========================================================================================
-// Fused MBConv front: expand 1x1 (MFMA) + BN + SiLU -> LDS -> depthwise kxk + BN + SiLU + squeeze partials.
-//
-// The 6x-expanded tensor never touches HBM.  A workgroup owns one (sample, TH x TW output tile):
-//   1. the halo'd input tile ((TH-1)s+k) x ((TW-1)s+k) pixels x Cin is DMA'd once into LDS in MFMA-fragment order
-//      (1 KiB blocks = 16 pixels x 32 k, lane-linear: one global_load_lds per block, zero page for padding);
-//   2. per chunk of 48 expanded channels: every wave runs the 1x1 expansion of a few 16-pixel blocks on the matrix
-//      cores (weights = MFMA A operand, so a lane ends up with 12 contiguous channels of one pixel), applies BN+SiLU,
-//      ZEROES pixels outside the image (the depthwise conv's padding acts on the expanded tensor) and parks the
-//      result in an LDS tile Et[pixel][48] (row pitch +16 B: conflict-free 16-byte writes);
-//   3. depthwise from Et exactly as dwconv_kernel (sliding window over rows), BN+SiLU, NHWC store, squeeze sums.
-// Cost: the expansion is recomputed on the halo (x1.2-1.4), on MFMA units that are otherwise idle here.
+// Fused MBConv front for the SMALL maps of the late blocks (H*W <= 320 pixels, Cin up to 384):
+// expand 1x1 (MFMA) + BN + SiLU -> LDS -> depthwise kxk + BN + SiLU + squeeze sums; the 6x-expanded tensor never touches HBM.
+// (The larger maps run the wave-autonomous kernel of kernels_wave.hip; shapes neither kernel is built for run unfused:
+// pw_gemm_dma -> E -> dwconv.)
 // ==========================================================================================
 // Bytes per pixel row of the LDS tile of expanded activations: +16 keeps the expand epilogue's 16-byte writes (16 pixels
-// per instruction, one pitch apart) conflict-free.  Measured alternative: pitches that make the depthwise READS
-// contiguous (192 / 224 B) were slower (b2 562 -> 735 us, b3 343 -> 358 us) although SQ_LDS_BANK_CONFLICT reads 0.56-0.69
-// of busy cycles for these kernels.
+// per instruction, one pitch apart) conflict-free.
 constexpr int et_pitch(int elem_size, int stride) { (void)stride; return 48 * elem_size + 16; }
-struct FusePlan { int TH, TW, THin, TWin, MB, kbn, threads, ntx, nty, et_f32; size_t lds; };
-static int fuse_et_f32() { static const int v = tune_int("COSY_FUSE_ET32", 1); return v; }
-static FusePlan fuse_plan(int Cin, int Ho, int Wo, int k, int s, int esz) {
-    FusePlan p;
-    const int R = s == 1 ? 4 : 2;
-    p.et_f32 = esz == 4 ? 1 : fuse_et_f32();       // element type of the LDS tile that holds the expanded activations
-    const int ees = p.et_f32 ? 4 : 2;
-    if (s == 1) { p.TH = esz == 2 ? 8 : 4; p.TW = 16; }
-    else { p.TH = 4; p.TW = 8; }
-    if (p.TW > Wo) p.TW = Wo;
-    p.THin = (p.TH - 1) * s + k; p.TWin = (p.TW - 1) * s + k;
-    p.MB = (p.THin * p.TWin + 15) / 16;
-    p.kbn = cdiv(Cin, esz == 2 ? 32 : 16);
-    const int cpt = 16 / ees, units = (48 / cpt) * p.TW * (p.TH / R);
-    p.threads = ((units < 384 ? units : 384) + 63) / 64 * 64;
-    {   // enough waves for the expand phase too: at most 2 sixteen-pixel blocks per wave (COSY_FUSE_MBW, experiments)
-        static const int mbw = tune_int("COSY_FUSE_MBW", 0);
-        if (mbw > 0) { int t = cdiv(p.MB, mbw) * 64; if (t > 384) t = 384; if (t > p.threads) p.threads = t; }
-    }
-    p.lds = (size_t)p.MB * p.kbn * 1024 + (size_t)p.MB * 16 * et_pitch(ees, s) + (size_t)k * k * 48 * 4 + (size_t)p.threads * 8 * 4;
-    p.ntx = cdiv(Wo, p.TW); p.nty = cdiv(Ho, p.TH);
-    return p;
-}
-int fuse_num_tiles(int Cin, int Ho, int Wo, int k, int s, int dtype) {
-    if (cdiv(Cin, dtype == COSY_F32 ? 16 : 32) > 2) return 1;   // the whole-image kernel of the small maps
-    FusePlan p = fuse_plan(Cin, Ho, Wo, k, s, dtype == COSY_F32 ? 4 : 2);
-    return p.ntx * p.nty;
-}
 static bool fuse_use_small(int Cin, int Cmid, int H, int W, int Ho, int Wo, int k, int s, int dtype);
 static int conv_out(int in, int k, int s) { return s == 1 ? in : (in - 2) / 2 + 1; }   // static same padding (image_size 300)
-// H, W = the block's input map (0 = unknown: only the tiled kernel is considered)
-bool fuse_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W) {
-    const int kbn = cdiv(Cin, dtype == COSY_F32 ? 16 : 32);
-    const bool tiled = Cmid % 48 == 0 && kbn <= 2 && (k == 3 || k == 5) && (s == 1 || s == 2);
-    if (tiled || H <= 0) return tiled;
+// H, W = the block's input map
+bool small_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W) {
+    if (H <= 0) return false;
     return fuse_use_small(Cin, Cmid, H, W, conv_out(H, k, s), conv_out(W, k, s), k, s, dtype);
-}
-
-struct FuseKArgs {
-    const void* X; const void* Wp; const float* s0; const float* b0; const float* dww; const float* s1; const float* b1;
-    void* D; float* partial; const void* zeros;
-    int H, W, Cin, Cmid, Ho, Wo, lo, TH, TW, THin, TWin, MB, ntx, n_tiles, nkb_total, dbg;
-    unsigned rcp_tw;   // ceil(2^16 / TWin): p / TWin == (p * rcp_tw) >> 16 for the tile's pixel range (checked on the host)
-};
-
-// T = storage type of X/D (and of the MFMA operands), ET = element type of the LDS tile of expanded activations
-template <typename T, typename ET, int KS, int S, int R, int KBN>
-__global__ __launch_bounds__(384) void mbconv_front_kernel(FuseKArgs a) {
-    using raw_t = typename DT<T>::raw_t;
-    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
-    constexpr int NI = 3, CC = 48;
-    constexpr int PITCH = et_pitch((int)sizeof(ET), S);  // bytes per Et pixel row: conflict-free depthwise reads
-    constexpr int CPT = 16 / (int)sizeof(ET);         // channels per depthwise thread (one 16-byte Et read)
-    constexpr int NG = CC / CPT;                      // channel groups per chunk
-    constexpr int NROW = (R - 1) * S + KS;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int TWin = a.TWin, Pin = a.THin * a.TWin, MB = a.MB;
-    char* Xt = smem;
-    char* Et = Xt + (size_t)MB * KBN * 1024;
-    float* wl = (float*)(Et + (size_t)MB * 16 * PITCH);
-    float* red = wl + KS * KS * CC;
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthr >> 6;
-    const int job = blockIdx.x, tile_id = job % a.n_tiles, b = job / a.n_tiles;
-    const int tx = tile_id % a.ntx, ty = tile_id / a.ntx;
-    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
-    const int iy0 = oy0 * S - a.lo, ix0 = ox0 * S - a.lo;
-    const int prow = lane & 15, kg = lane >> 4;
-
-    // ---- 1. DMA the input tile into LDS in fragment order
-    {
-        const T* __restrict__ X = (const T*)a.X + (size_t)b * a.H * a.W * a.Cin;
-        for (int blk = wave; blk < MB * KBN; blk += nwaves) {
-            const int mb = blk / KBN, kb = blk - mb * KBN;
-            const int p = mb * 16 + prow, k = kb * KB + kg * EPL;
-            const int yy = (int)(((unsigned)p * a.rcp_tw) >> 16), xx = p - yy * TWin, iy = iy0 + yy, ix = ix0 + xx;
-            const bool ok = p < Pin && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && k < a.Cin;
-            const void* src = ok ? (const void*)(X + ((size_t)iy * a.W + ix) * a.Cin + k) : a.zeros;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(Xt + (size_t)blk * 1024), 16, 0, 0);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    const int nchunks = a.Cmid / CC;
-    const int nyq = a.TH / R;
-    const int units = NG * a.TW * nyq;
-    const int stride = (nthr / NG) * NG;
-    const int cq = tid % NG;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        // taps of this chunk -> LDS
-        for (int i = tid; i < KS * KS * (CC / 4); i += nthr) {
-            const int tap = i / (CC / 4), q = i - tap * (CC / 4);
-            *(f32x4*)(wl + tap * CC + q * 4) = *(const f32x4*)(a.dww + (size_t)tap * a.Cmid + ch * CC + q * 4);
-        }
-        // ---- 2. expansion on the matrix cores -> Et
-        {
-            raw_t wf[NI][KBN];
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int kb = 0; kb < KBN; ++kb)
-                    wf[ni][kb] = *(const raw_t*)((const T*)a.Wp + ((size_t)(ch * NI + ni) * a.nkb_total + kb) * 64 * EPL + lane * EPL);
-            const int n0 = ch * CC + kg * 4 * NI;   // this lane's 12 consecutive expanded channels
-            float sc[NI * 4], bi[NI * 4];
-#pragma unroll
-            for (int q = 0; q < NI; ++q) { load4(a.s0 + n0 + q * 4, sc + q * 4); load4(a.b0 + n0 + q * 4, bi + q * 4); }
-            for (int mb = wave; mb < (COSY_DBG(a.dbg & 2) ? 0 : MB); mb += nwaves) {
-                f32x4 acc[NI];
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kb = 0; kb < KBN; ++kb) {
-                    const raw_t xf = *(const raw_t*)(Xt + (size_t)(mb * KBN + kb) * 1024 + lane * 16);
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) mma(acc[ni], wf[ni][kb], xf);
-                }
-                const int p = mb * 16 + prow;
-                const int yy = (int)(((unsigned)p * a.rcp_tw) >> 16), xx = p - yy * TWin, iy = iy0 + yy, ix = ix0 + xx;
-                const bool inside = p < Pin && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-                float y[NI * 4];
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = acc[ni][r] * sc[ni * 4 + r] + bi[ni * 4 + r];
-                        v = v * sigmoid_t<T>(v);
-                        y[ni * 4 + r] = inside ? v : 0.f;
-                    }
-                ET* dst = (ET*)(Et + (size_t)p * PITCH) + kg * 4 * NI;
-                if constexpr (sizeof(ET) == 2) { store8(dst, y); store4(dst + 8, y + 8); }
-                else { store4(dst, y); store4(dst + 4, y + 4); store4(dst + 8, y + 8); }
-            }
-        }
-        __syncthreads();
-        // ---- 3. depthwise from Et
-        float sum[CPT];
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) sum[c] = 0.f;
-        if (tid < stride && !COSY_DBG(a.dbg & 1)) {
-            const int c0 = ch * CC + cq * CPT;
-            float sc[CPT], bi[CPT];
-#pragma unroll
-            for (int c = 0; c < CPT; c += 4) { load4(a.s1 + c0 + c, sc + c); load4(a.b1 + c0 + c, bi + c); }
-            T* __restrict__ out = (T*)a.D + (size_t)b * a.Ho * a.Wo * a.Cmid + c0;
-#pragma unroll 1
-            for (int u = tid; u < units; u += stride) {
-                const int q = u / NG, x = q % a.TW, yq = q / a.TW;
-                const int ox = ox0 + x, oyb = oy0 + yq * R;
-                if (ox >= a.Wo || oyb >= a.Ho) continue;
-                float acc[R][CPT];
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int c = 0; c < CPT; ++c) acc[r][c] = 0.f;
-#pragma unroll 1
-                for (int kx = 0; kx < KS; ++kx) {
-                    float wc[KS][CPT];
-#pragma unroll
-                    for (int ky = 0; ky < KS; ++ky)
-#pragma unroll
-                        for (int c = 0; c < CPT; c += 4) load4(wl + (ky * KS + kx) * CC + cq * CPT + c, wc[ky] + c);
-                    const char* col = Et + ((size_t)(yq * R * S) * TWin + x * S + kx) * PITCH + cq * 16;
-#pragma unroll
-                    for (int rr = 0; rr < NROW; ++rr) {
-                        float v[CPT];
-                        if constexpr (sizeof(ET) == 2) lds_ld8((const ET*)(col + (size_t)rr * TWin * PITCH), v);
-                        else load4((const float*)(col + (size_t)rr * TWin * PITCH), v);
-#pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            const int ky = rr - r * S;
-                            if (ky >= 0 && ky < KS) {
-#pragma unroll
-                                for (int c = 0; c < CPT; ++c) acc[r][c] += wc[ky][c] * v[c];
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int oy = oyb + r;
-                    if (oy < a.Ho) {
-                        float y[CPT];
-#pragma unroll
-                        for (int c = 0; c < CPT; ++c) {
-                            float v = acc[r][c] * sc[c] + bi[c];
-                            v = v * sigmoid_t<T>(v);
-                            y[c] = v;
-                            sum[c] += v;
-                        }
-                        T* o = out + ((size_t)oy * a.Wo + ox) * a.Cmid;
-                        if constexpr (CPT == 8) store8(o, y); else store4(o, y);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) red[tid * CPT + c] = sum[c];
-        __syncthreads();
-        reduce_squeeze_sums(red, stride, NG, CPT, tid, nthr, a.partial + ((size_t)b * a.n_tiles + tile_id) * a.Cmid + ch * CC);
-        // next chunk: its Et writes happen after this barrier's readers are done (all Et reads precede the barrier above);
-        // `red` is rewritten only after the next chunk's first barrier.
-    }
-}
-
-template <typename T, typename ET, int KBN>
-static int launch_fuse_k(const FuseArgs& a, const FusePlan& p, const FuseKArgs& k, hipStream_t s) {
-    dim3 grid((unsigned)(k.n_tiles * a.B)), block(p.threads);
-    if (a.k == 3 && a.s == 1) hipLaunchKernelGGL((mbconv_front_kernel<T, ET, 3, 1, 4, KBN>), grid, block, p.lds, s, k);
-    else if (a.k == 3 && a.s == 2) hipLaunchKernelGGL((mbconv_front_kernel<T, ET, 3, 2, 2, KBN>), grid, block, p.lds, s, k);
-    else if (a.k == 5 && a.s == 1) hipLaunchKernelGGL((mbconv_front_kernel<T, ET, 5, 1, 4, KBN>), grid, block, p.lds, s, k);
-    else if (a.k == 5 && a.s == 2) hipLaunchKernelGGL((mbconv_front_kernel<T, ET, 5, 2, 2, KBN>), grid, block, p.lds, s, k);
-    else { set_error("mbconv_front: unsupported k=%d s=%d", a.k, a.s); return COSY_EINVAL; }
-    COSY_CHECK_HIP(hipGetLastError());
-    return COSY_OK;
-}
-template <typename T>
-static int launch_fuse_t(const FuseArgs& a, hipStream_t s) {
-    const FusePlan p = fuse_plan(a.Cin, a.Ho, a.Wo, a.k, a.s, sizeof(T));
-    FuseKArgs k;
-    k.X = a.X; k.Wp = a.Wp; k.s0 = a.s0; k.b0 = a.b0; k.dww = a.dww; k.s1 = a.s1; k.b1 = a.b1; k.D = a.D; k.partial = a.partial;
-    k.zeros = a.zeros; k.H = a.H; k.W = a.W; k.Cin = a.Cin; k.Cmid = a.Cmid; k.Ho = a.Ho; k.Wo = a.Wo; k.lo = a.pad_lo;
-    k.TH = p.TH; k.TW = p.TW; k.THin = p.THin; k.TWin = p.TWin; k.MB = p.MB; k.ntx = p.ntx; k.n_tiles = p.ntx * p.nty;
-    k.nkb_total = pw_nkb_total(a.Cin, sizeof(T) == 4 ? COSY_F32 : COSY_BF16);   // k-block geometry depends on the element size only
-    k.rcp_tw = (65536u + p.TWin - 1) / p.TWin;
-    static const int dbg = tune_int("COSY_FUSE_DBG", 0);   // phase knock-out, timing experiments only
-    k.dbg = dbg;
-    for (int q = 0; q < p.MB * 16; ++q)
-        if ((int)(((unsigned)q * k.rcp_tw) >> 16) != q / p.TWin) { set_error("mbconv_front: reciprocal division inexact"); return COSY_EINVAL; }
-    if (p.kbn == 1) return p.et_f32 ? launch_fuse_k<T, float, 1>(a, p, k, s) : launch_fuse_k<T, T, 1>(a, p, k, s);
-    return p.et_f32 ? launch_fuse_k<T, float, 2>(a, p, k, s) : launch_fuse_k<T, T, 2>(a, p, k, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1346,17 +931,17 @@ static bool fuse_use_small(int Cin, int Cmid, int H, int W, int Ho, int Wo, int 
     return fuse_small_plan(Cin, Cmid, H, W, Ho, Wo, k, s, 2).ok;
 }
 
-// does launch_mbconv_front write D in the chunked layout [sample][Cmid/16][HW][16] for this shape? (the project GEMM must know)
-bool fuse_writes_chunked(int Cin, int Cmid, int H, int W, int Ho, int Wo, int k, int s, int dtype) {
+// does launch_mbconv_small write D in the chunked layout [sample][Cmid/16][HW][16] for this shape? (the project GEMM must know)
+bool small_writes_chunked(int Cin, int Cmid, int H, int W, int Ho, int Wo, int k, int s, int dtype) {
     if (!fuse_use_small(Cin, Cmid, H, W, Ho, Wo, k, s, dtype)) return false;
     const FuseSmallPlan p = fuse_small_plan(Cin, Cmid, H, W, Ho, Wo, k, s, 2);
     return fuse_small_rowmap(Ho, Wo, p.threads);
 }
-int launch_mbconv_front(const FuseArgs& a, int dtype, hipStream_t s) {
+int launch_mbconv_small(const FuseArgs& a, int dtype, hipStream_t s) {
     if (a.B == 0) return COSY_OK;
-    if (fuse_use_small(a.Cin, a.Cmid, a.H, a.W, a.Ho, a.Wo, a.k, a.s, dtype)) return COSY_DISPATCH_T(dtype, launch_fuse_small_t<T>(a, s));
-    COSY_REQUIRE(fuse_supported(a.Cin, a.Cmid, a.k, a.s, dtype, 0, 0), "mbconv_front: unsupported shape Cin=%d Cmid=%d", a.Cin, a.Cmid);
-    return COSY_DISPATCH_T(dtype, launch_fuse_t<T>(a, s));
+    COSY_REQUIRE(fuse_use_small(a.Cin, a.Cmid, a.H, a.W, a.Ho, a.Wo, a.k, a.s, dtype), "mbconv_small: unsupported shape Cin=%d Cmid=%d %dx%d",
+                 a.Cin, a.Cmid, a.H, a.W);
+    return COSY_DISPATCH_T(dtype, launch_fuse_small_t<T>(a, s));
 }
 
 // ==========================================================================================
@@ -1612,19 +1197,21 @@ int launch_pool_fc(const void* head, const float* fc_w, const float* fc_b, float
     return COSY_OK;
 }
 
-// NHWC (T) -> NCHW fp32 export of an activation (API parity for backbone(x); not on the hot path)
+// NHWC (T) -> NCHW fp32 export of an activation (API parity for backbone(x) and the test probes; not on the hot path).
+// chunked = 1: the source is in the fused fronts' D layout [sample][C/16][HW][16].
 template <typename T>
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ act, int HW, int C, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ act, int HW, int C, float* __restrict__ out, int chunked) {
     const int b = blockIdx.y;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // index in (C,HW)
     if (i >= (size_t)HW * C) return;
     const size_t c = i / HW, p = i % HW;
-    out[(size_t)b * HW * C + i] = (float)act[((size_t)b * HW + p) * C + c];
+    const size_t src = chunked ? ((size_t)b * (C >> 4) + (c >> 4)) * HW * 16 + p * 16 + (c & 15) : ((size_t)b * HW + p) * C + c;
+    out[(size_t)b * HW * C + i] = (float)act[src];
 }
-int launch_nhwc_to_nchw(const void* act, int B, int HW, int C, int dtype, float* out, hipStream_t s) {
+int launch_nhwc_to_nchw(const void* act, int B, int HW, int C, int dtype, float* out, hipStream_t s, int chunked) {
     if (B == 0) return COSY_OK;
     dim3 grid(cdiv((long)HW * C, 256), B);
-    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, grid, dim3(256), 0, s, (const T*)act, HW, C, out));
+    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, grid, dim3(256), 0, s, (const T*)act, HW, C, out, chunked));
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }

@@ -6,8 +6,8 @@ rank) and its file-system gather (cosypose/utils/tensor_collection.py:142-163: r
 barrier, rank 0 torch.load + concatenate).  Each candidate crop is independent across the whole coarse->refiner chain, so
 there is no data-path collective inside the loop; the only exchange is the gather of the results.
 
-The payload is tiny (<= 2048 candidates x ~1 KB), i.e. latency-bound: everything a call produces travels in ONE padded
-`all_gather_into_tensor` of BYTES (so integer and float64 fields survive exactly), never a ring of point-to-point sends.
+The payload is tiny (196 B per candidate and iteration: <= 2048 candidates x 5 iterations = 2 MB), i.e. latency-bound:
+everything a call produces travels in ONE padded `all_gather_into_tensor` of BYTES (so integer and float64 fields survive exactly), never a ring of point-to-point sends.
 Shard sizes follow from (number of detections, world size, balance rule) alone, so no count exchange is needed on the
 sharded-predictor path.
 """
@@ -33,13 +33,20 @@ def local_device_index():
     return int(os.environ.get('LOCAL_RANK', '0')) % n if n else 0
 
 
-def init_distributed_mode(backend=None):
+def init_distributed_mode(backend=None, force=None):
     """torchrun-style env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).  One visible GPU per rank:
     the rank binds LOCAL_RANK's device (reference: cosypose/utils/distributed.py:55-69 uses SLURM vars + file store).
-    COSY_DIST_BACKEND overrides the backend (RCCL refuses two ranks on one GPU; gloo does not)."""
+    COSY_DIST_BACKEND overrides the backend (RCCL refuses two ranks on one GPU; gloo does not).
+    A single process normally needs no process group; force=True (or COSY_FORCE_DIST=1) creates a 1-rank group anyway,
+    so that the collectives of this module run through RCCL on a 1-GPU box exactly as they do on 8."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world <= 1 or dist.is_initialized():
+    if force is None:
+        force = os.environ.get('COSY_FORCE_DIST', '0') == '1'
+    if dist.is_initialized() or (world <= 1 and not force):
         return get_rank(), get_world_size()
+    if world <= 1:
+        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1'); os.environ.setdefault('LOCAL_RANK', '0')
+        os.environ.setdefault('MASTER_PORT', str(29500 + os.getpid() % 2000))
     backend = os.environ.get('COSY_DIST_BACKEND', backend)
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
@@ -112,11 +119,15 @@ def all_gather_rows(local, max_rows=None, counts=None):
     valid on every rank, is given (then each slab's first 8 bytes carry its row count as int64); otherwise the bound is
     agreed with one extra tiny all_reduce(MAX)."""
     world = get_world_size()
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return local
     tail = tuple(local.shape[1:])
     rows = _as_byte_rows(local)
     n, wb = rows.shape
+    if wb == 0:             # nothing to move (a row schema without fields): no collective
+        total = int(sum(counts)) if counts is not None else None
+        assert total is not None, 'all_gather_rows: zero-width rows need the per-rank counts'
+        return local.new_zeros((total,) + tail)
     if counts is not None:
         assert counts[get_rank()] == n
         max_rows = max(max(counts), 1)
@@ -126,9 +137,10 @@ def all_gather_rows(local, max_rows=None, counts=None):
         max_rows = max(int(m.item()), 1)
     assert n <= max_rows
     head = 8 if counts is None else 0
-    slab = torch.zeros(head + max_rows * wb, device=local.device, dtype=torch.uint8)
+    # the slab's padding is never read back (only counts[r] rows of rank r are), so it is not cleared
+    slab = torch.empty(head + max_rows * wb, device=local.device, dtype=torch.uint8)
     if head:
-        slab[:8] = torch.tensor([n], dtype=torch.int64).view(torch.uint8).to(local.device)
+        slab[:8] = torch.tensor([n], dtype=torch.int64).view(torch.uint8).to(local.device, non_blocking=True)
     if n:
         slab[head:head + n * wb] = rows.reshape(-1)
     out = torch.empty(world * slab.numel(), device=local.device, dtype=torch.uint8)
@@ -285,6 +297,8 @@ def get_predictions_sharded(predictor, images, K, detections=None, data_TCO_init
     # what a call produces is known from the arguments alone (an empty rank has no collections to inspect)
     keys = ([f'coarse/iteration={i}' for i in range(1, n_coarse_iterations + 1)] if data_TCO_init is None else []) + \
            [f'refiner/iteration={i}' for i in range(1, n_refiner_iterations + 1)]
+    if not keys:            # external coarse poses and no refiner iteration: nothing was computed, nothing to exchange
+        return data_TCO_init, {'external_coarse': data_TCO_init}
     fields = (('poses', (4, 4)), ('poses_input', (4, 4)), ('K_crop', (3, 3)), ('boxes_rend', (4,)), ('boxes_crop', (4,)))
     packer = RowPacker([(f'{k}|{f}', shape, torch.float32) for k in keys for f, shape in fields])
     device = images.device

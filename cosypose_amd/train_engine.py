@@ -444,10 +444,15 @@ class FlatAdam:
         return self.norm_coef[0]
 
 
-def allreduce_gradients(flat_grad):
-    """DDP's gradient averaging as ONE all-reduce of the flat gradient buffer (42.8 MB fp32 for this network)."""
+def allreduce_gradients(flat_grad, force=False):
+    """DDP's gradient averaging as ONE all-reduce of the flat gradient buffer (42.8 MB fp32 for this network).
+    `flat_grad`: the buffer, or a FlatAdam (gradients that were detached from its buffer are collected first, so that
+    what is reduced is what the step will use).  force=True runs the collective in a 1-rank group too (RCCL smoke test)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if isinstance(flat_grad, FlatAdam):
+        flat_grad._collect_stray_gradients()
+        flat_grad = flat_grad.grad
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
         flat_grad.div_(dist.get_world_size())
     return flat_grad

@@ -119,13 +119,24 @@ def train_loop(model, mesh_db, cfg, batches, n_epochs, save_dir=None, start_epoc
         optimizer = train_engine.FlatAdam(model.module if is_ddp else model, lr=cfg.lr, weight_decay=getattr(cfg, 'weight_decay', 0.0),
                                           clip_grad_norm=cfg.clip_grad_norm)
     flat = isinstance(optimizer, train_engine.FlatAdam)
+    if world > 1 and not is_ddp and not flat:
+        raise ValueError('train_loop: %d ranks, but the model is not DistributedDataParallel and the optimizer is not FlatAdam: '
+                         'the ranks would train independently (wrap the model in DDP or use train_engine.FlatAdam)' % world)
+    if start_epoch > 0 and faithful_schedule:
+        import warnings
+        warnings.warn('train_loop: resuming with faithful_schedule=True reproduces the reference\'s resume behaviour '
+                      '(train_pose.py:283-298: the warm-up LambdaLR is rebuilt on resume): the learning rate restarts at '
+                      'lr / n_warm_batches and never recovers; pass faithful_schedule=False for the intended schedule')
+    bpe = getattr(cfg, 'batches_per_epoch', None)      # the reference's warm-up length: epoch_size // batch_size (train_pose.py:296)
+    if bpe is None and getattr(cfg, 'epoch_size', None) and getattr(cfg, 'batch_size', None):
+        bpe = cfg.epoch_size // cfg.batch_size
     history = {}
     schedule = None
     for epoch in range(start_epoch, n_epochs):
         it = batches(epoch) if callable(batches) else batches
         items = list(it) if schedule is None and not hasattr(it, '__len__') else it
         if schedule is None:
-            schedule = LRSchedule(cfg.lr, cfg.n_epochs_warmup, len(items), cfg.lr_epoch_decay, start_epoch=start_epoch, faithful=faithful_schedule)
+            schedule = LRSchedule(cfg.lr, cfg.n_epochs_warmup, bpe or len(items), cfg.lr_epoch_decay, start_epoch=start_epoch, faithful=faithful_schedule)
         model.train()
         meters = defaultdict(_Mean)
         for b, sample in enumerate(items):
@@ -136,7 +147,7 @@ def train_loop(model, mesh_db, cfg, batches, n_epochs, save_dir=None, start_epoc
             loss.backward()
             if flat:
                 if world > 1 and not is_ddp:
-                    train_engine.allreduce_gradients(optimizer.grad)
+                    train_engine.allreduce_gradients(optimizer)      # collects detached .grad tensors first
                 meters['grad_norm'].add(float(optimizer.step()))
             else:
                 params = (model.module if is_ddp else model).parameters()

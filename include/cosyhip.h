@@ -87,6 +87,16 @@ int cosy_effnet_b3_forward(cosy_net_t* net, int B, float* feat, float* pose9, fl
  * (B,1536,h,w) fp32 NCHW (what EfficientNet.forward yields, efficientnet.py:192-204). */
 int cosy_effnet_b3_features_nchw(cosy_net_t* net, int B, float* out, cosy_stream_t stream);
 
+/* ---- test probes (parity tests of the fused kernels; never on the hot path) -----------------
+ * cosy_effnet_b3_set_probe: the NEXT forwards also copy one whole activation out as fp32 NCHW into `out`
+ * (caller-allocated, B x C x HW floats): layer -1 = stem output, 0..25 = output of MBConv block i
+ * (MBConvBlock.forward's return value, cosypose/models/efficientnet.py:71-98), 26 = head activation,
+ * 100+i = depthwise output of block i (after _bn1 + swish, :83), 200+i = squeeze-excite gate of block i as (B, Cmid)
+ * (sigmoid(_se_expand(...)), :85-88); layer -2 switches the probe off.
+ * cosy_effnet_b3_block_info: dims[10] = {H, W, Ho, Wo, Cin, Cmid, Cout, front kernel (0 unfused, 1 wave, 2 small), k, s}. */
+int cosy_effnet_b3_set_probe(cosy_net_t* net, int layer, float* out);
+int cosy_effnet_b3_block_info(const cosy_net_t* net, int block, int* dims);
+
 /* ---- measurement hook ---------------------------------------------------------------------
  * With profiling enabled every launch of cosy_effnet_b3_forward is bracketed by HIP events recorded on the
  * launch stream (no synchronisation, one hipEventRecord per kernel; up to 24 forwards are retained).

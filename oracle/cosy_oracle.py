@@ -438,6 +438,79 @@ class TorchRef:
         return f.numpy(), pose.numpy()
 
 
+    # ---- storage emulation (test infrastructure for the 16-bit throughput modes) ----------------------------------------
+    # The same network with every value rounded to the 16-bit storage type exactly where the HIP path stores one:
+    # network input, stem output, block inputs / outputs, the depthwise output D, the expanded tensor E of the UNFUSED blocks
+    # (the fused fronts keep E in fp32 registers / LDS), the head activation; the 1x1-conv and stem weights; and the
+    # squeeze-excite gate where the project GEMM applies it -- to the weight fragments (maps with Ho*Wo % 64 == 0:
+    # bf16 round(w * g), fp16 w * half(g) in half arithmetic) or to the activation rows (other maps).  Accumulation, BatchNorm,
+    # SiLU, the depthwise taps, the squeeze sums (taken BEFORE D is rounded) and the SE FCs are fp32, as on the device.
+    # What is left between this and the device result is fp32 summation order and the transcendental approximations,
+    # i.e. ~1e-6 before rounding -> a small fraction of values one storage ulp apart.
+    def _rnd(self, t, storage):
+        torch = self.torch
+        if storage == 'bf16':
+            return t.bfloat16().float()
+        if storage == 'fp16':
+            return t.clamp(-65504.0, 65504.0).half().float()
+        return t
+
+    def extract_features_emulated(self, x, storage, fused, probes=None):
+        """x (B,6,H,W) fp32; storage 'bf16' | 'fp16'; fused[i] truthy = block i runs a fused front (E never stored).
+        probes: dict filled with {-1: stem, i: block output, 100+i: D of block i, 200+i: gate (B,Cmid), 26: head}."""
+        torch = self.torch; sd = self.sd
+        R = lambda t: self._rnd(t, storage)
+        sw = lambda t: t * torch.sigmoid(t)
+        put = (lambda k, v: probes.__setitem__(k, v.clone())) if probes is not None else (lambda k, v: None)
+        x = R(x)
+        x = R(sw(self._bn(self._conv(x, R(sd['backbone._conv_stem.weight']), 3, 2), 'backbone._bn0')))
+        put(-1, x)
+        for i, (k, s, e, cin, cout) in enumerate(B3_BLOCKS):
+            p = f'backbone._blocks.{i}.'
+            inp = x
+            if e != 1:
+                x = sw(self._bn(self._conv(x, R(sd[p + '_expand_conv.weight']), 1, 1), p + '_bn0'))
+                if not fused[i]:
+                    x = R(x)
+            d32 = sw(self._bn(self._conv(x, sd[p + '_depthwise_conv.weight'], k, s, groups=x.shape[1]), p + '_bn1'))
+            q = d32.mean((2, 3), keepdim=True)
+            q = self._conv(sw(self._conv(q, sd[p + '_se_reduce.weight'], 1, 1, bias=sd[p + '_se_reduce.bias'])),
+                           sd[p + '_se_expand.weight'], 1, 1, bias=sd[p + '_se_expand.bias'])
+            g = torch.sigmoid(q)[:, :, 0, 0]                       # (B, Cmid)
+            D = R(d32)
+            put(100 + i, D); put(200 + i, g)
+            W = R(sd[p + '_project_conv.weight'])[:, :, 0, 0]        # (Cout, Cmid)
+            hw = D.shape[2] * D.shape[3]
+            if hw % 64 == 0:                                         # gate folded into the weight fragments, per sample
+                if storage == 'fp16':
+                    Wg = (W.half()[None] * g.half()[:, None, :]).float()
+                else:
+                    Wg = R(W[None] * g[:, None, :])
+                y = torch.einsum('bnk,bkhw->bnhw', Wg, D)
+            else:                                                    # gate applied to the activation rows
+                if storage == 'fp16':
+                    Dg = (D.half() * g.half()[:, :, None, None]).float()
+                else:
+                    Dg = R(D * g[:, :, None, None])
+                y = torch.einsum('nk,bkhw->bnhw', W, Dg)
+            x = self._bn(y, p + '_bn2')
+            if s == 1 and cin == cout:
+                x = x + inp
+            x = R(x)
+            put(i, x)
+        x = R(sw(self._bn(self._conv(x, R(sd['backbone._conv_head.weight']), 1, 1), 'backbone._bn1')))
+        put(26, x)
+        return x
+
+    def net_forward_emulated(self, x, storage, fused, probes=None):
+        torch = self.torch
+        with torch.no_grad():
+            x = torch.as_tensor(np.asarray(x, np.float32)) if not torch.is_tensor(x) else x
+            f = self.extract_features_emulated(x, storage, fused, probes).flatten(2).mean(-1)
+            pose = torch.nn.functional.linear(f, self.sd['pose_fc.weight'], self.sd['pose_fc.bias'])
+        return f.numpy(), pose.numpy()
+
+
     # ---- training step (SURVEY 8a-13): train-mode forward, disentangled loss, backward -- torch-CPU autograd over the
     # functional restatement above; pinned against the reference's own loss / gradients (tests/golden/*train*)
     @staticmethod

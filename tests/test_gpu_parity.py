@@ -172,39 +172,153 @@ def test_backbone_fp32_vs_oracle_ragged_batches(model, oracle, golden_sd, B):
     assert rel_err(feat, f2) < NET_TOL and rel_err(pose, p2) < NET_TOL
 
 
-def test_backbone_bf16_deviation(model, golden):
-    x = np.random.RandomState(22).random_sample((2, 6, 256, 256)).astype(np.float32)
-    feat, pose, taps = _run_net(model, x, 'bf16')
-    fe, pe = rel_err(feat, golden['bb_256x256_feat']), rel_err(pose, golden['bb_256x256_pose'])
-    print(f'bf16 deviation vs reference fp32: features {fe:.3e}, pose params {pe:.3e}')
-    assert fe < BF16_FEAT_TOL and pe < 1.6e-4     # pose parameters: <= 3x the measured 5.1e-5
+def _block_plan(model, hw, dtype, B=2):
+    """front kernel of every MBConv block for this (crop size, storage type): 0 unfused, 1 wave, 2 small (cosy_effnet_b3_block_info)"""
+    import ctypes
+    from cosypose_amd._lib import lib, check
+    model.compute_dtype = dtype
+    model.render_size = tuple(hw)
+    h = model._net(B, torch.device('cuda'))
+    plan = []
+    for i in range(26):
+        dims = (ctypes.c_int * 10)()
+        check(lib().cosy_effnet_b3_block_info(h, i, dims))
+        plan.append(list(dims))
+    return h, plan
+
+
+def _probe(model, h, x, layer, shape):
+    """one forward with the test probe on `layer`; -> fp32 array of `shape` (the whole activation, NCHW)"""
+    from cosypose_amd._lib import lib, check, ptr, stream
+    B = x.shape[0]
+    out = torch.empty(shape, device='cuda')
+    pose = torch.empty(B, 9, device='cuda')
+    check(lib().cosy_effnet_b3_set_probe(h, layer, ptr(out)))
+    try:
+        check(lib().cosy_effnet_b3_forward(h, B, None, ptr(pose), None, stream()))
+        torch.cuda.synchronize()
+    finally:
+        check(lib().cosy_effnet_b3_set_probe(h, -2, None))
+    return out.cpu().numpy()
+
+
+# storage ulp relative to a value: bf16 has 8 significant bits, fp16 11
+ULP = {'bf16': 2.0 ** -7, 'fp16': 2.0 ** -10}
+
+
+@pytest.mark.parametrize('hw', [(256, 256), (240, 320), (192, 256)], ids=['256x256', '240x320', '192x256'])
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_fused_kernels_vs_storage_emulation(model, oracle, golden_sd, dtype, hw):
+    """The kernels that set the headline (mbconv_wave_kernel, mbconv_small_kernel, the gated pw_gemm_dma, stem, dwconv in their
+    16-bit instantiations) against an oracle that rounds to the storage type exactly where the device stores
+    (TorchRef.extract_features_emulated): EVERY block's output, depthwise output D and squeeze-excite gate, the stem and the
+    head activation, as whole tensors.  What may remain is fp32 summation order / transcendental approximation before a
+    rounding, i.e. isolated values one storage ulp apart: asserted as (1) relative L2 error per tensor <= 2e-4 (bf16) /
+    3e-5 (fp16) -- a one-pixel halo or padding slip in any variant shows up as >= 1e-2 -- and (2) no element further than
+    3 storage ulps (of the tensor's scale) away.  256x256 and 240x320 reach every fused variant (FULLW and !FULLW wave
+    kernels, row-mapped and plain small kernels, weight- and row-side gates); 192x256 is a size no fused kernel is built
+    for and runs the generic unfused schedule (pw_gemm_dma -> E -> dwconv)."""
+    B = 3
+    x = np.random.RandomState(40 + hw[0]).random_sample((B, 6) + tuple(hw)).astype(np.float32)
+    h, plan = _block_plan(model, hw, dtype, B)
+    kinds = [p[7] for p in plan]
+    if hw == (192, 256):
+        assert not any(kinds), kinds
+    else:
+        assert all(k == 1 for k in kinds[2:18]) and all(k == 2 for k in kinds[19:26]) and kinds[18] == 0, kinds
+    from cosypose_amd._lib import lib, check, ptr, stream
+    check(lib().cosy_effnet_b3_set_input_nchw(h, ptr(dev(x)), B, stream()))
+    want = {}
+    tr = oracle.TorchRef(golden_sd)
+    f_emu, p_emu = tr.net_forward_emulated(x, dtype, kinds, want)
+    l2_tol = 2e-4 if dtype == 'bf16' else 3e-5
+    worst = (0.0, None); worst_ulp = (0.0, None)
+    Hs, Ws = hw[0] // 2, hw[1] // 2
+    layers = [(-1, (B, 40, Hs, Ws))]
+    for i, (H_, W_, Ho, Wo, cin, cmid, cout, kind, k, s_) in enumerate(plan):
+        layers += [(100 + i, (B, cmid, Ho, Wo)), (200 + i, (B, cmid)), (i, (B, cout, Ho, Wo))]
+    layers.append((26, (B, 1536, plan[25][2], plan[25][3])))
+    for layer, shape in layers:
+        got = _probe(model, h, x, layer, shape)
+        w = want[layer].numpy().reshape(shape)
+        assert np.isfinite(got).all(), layer
+        l2 = float(np.linalg.norm((got - w).ravel()) / max(np.linalg.norm(w.ravel()), 1e-30))
+        if 200 <= layer < 300:                      # the gate is fp32 on both sides
+            assert l2 < 2e-5, (layer, l2)
+            continue
+        ulps = float(np.abs(got - w).max() / (ULP[dtype] * np.abs(w).max()))
+        if l2 > worst[0]: worst = (l2, layer)
+        if ulps > worst_ulp[0]: worst_ulp = (ulps, layer)
+        assert l2 < l2_tol, (layer, l2, kinds[layer % 100] if layer >= 0 and layer != 26 else None)
+        assert ulps < 3.0, (layer, ulps)
+    feat, pose, _ = _run_net(model, x, dtype)
+    fe, pe = rel_err(feat, f_emu), rel_err(pose, p_emu)
+    print(f'{dtype} {hw}: worst tensor L2 {worst[0]:.2e} (layer {worst[1]}), worst element {worst_ulp[0]:.2f} storage ulps (layer {worst_ulp[1]}); '
+          f'features vs emulation {fe:.2e}, pose9 {pe:.2e}')
+    assert fe < (6e-4 if dtype == 'bf16' else 8e-5) and pe < (2e-5 if dtype == 'bf16' else 3e-6)
+    if hw != (192, 256):
+        name = '%dx%d' % hw
+        # and where the storage type itself puts the result relative to the reference's fp32 (informative; bound = 3x measured)
+        x2 = np.random.RandomState(21 if hw == (240, 320) else 22).random_sample((2, 6) + tuple(hw)).astype(np.float32)
+        feat2, pose2, _ = _run_net(model, x2, dtype)
+        golden = dict(np.load(os.path.join(os.path.dirname(__file__), 'golden', 'reference_golden.npz')))
+        fe2, pe2 = rel_err(feat2, golden[f'bb_{name}_feat']), rel_err(pose2, golden[f'bb_{name}_pose'])
+        print(f'{dtype} {hw}: deviation from the reference fp32: features {fe2:.2e}, pose9 {pe2:.2e}')
+        assert fe2 < (1.7e-2 if dtype == 'bf16' else 2.6e-3) and pe2 < (1.6e-4 if dtype == 'bf16' else 3e-5)
     model.compute_dtype = 'fp32'; model.render_size = (240, 320)
 
 
-def test_backbone_fp16_deviation(model, golden):
-    """BASELINE configs[2] names fp16: same kernels with _Float16 storage (saturating converts)."""
-    x = np.random.RandomState(22).random_sample((2, 6, 256, 256)).astype(np.float32)
-    feat, pose, taps = _run_net(model, x, 'fp16')
-    fe, pe = rel_err(feat, golden['bb_256x256_feat']), rel_err(pose, golden['bb_256x256_pose'])
-    print(f'fp16 deviation vs reference fp32: features {fe:.3e}, pose params {pe:.3e}')
-    assert fe < 2.6e-3 and pe < 3e-5     # <= 3x the measured 8.4e-4 / 9e-6 (11-bit mantissa)
-    model.compute_dtype = 'fp32'; model.render_size = (240, 320)
+@pytest.mark.parametrize('hw', [(192, 256), (128, 128)], ids=['192x256', '128x128'])
+def test_backbone_fp32_third_crop_size_vs_oracle(model, oracle, golden_sd, hw):
+    """a crop size neither fused schedule is built for runs the generic kernels: fp32 <= 1e-4 vs the oracle on the per-stage
+    probes, the features and the pose output (128x128 = the smallest supported size: 4x4 final maps, 10 samples' gate rows
+    under one GEMM tile)"""
+    x = np.random.RandomState(77).random_sample((3, 6) + tuple(hw)).astype(np.float32)
+    feat, pose, taps = _run_net(model, x, 'fp32')
+    tr = oracle.TorchRef(golden_sd)
+    f2, p2 = tr.net_forward(x)
+    assert rel_err(feat, f2) < NET_TOL and rel_err(pose, p2) < NET_TOL
+    model.render_size = (240, 320)
 
 
-@pytest.mark.parametrize('dtype,tol', [('bf16', 2.3e-4), ('fp16', 5e-5)])     # <= 3x the measured 7.4e-5 / 1.6e-5
-def test_refiner_loop_low_precision(model, golden, labels21, dtype, tol):
-    """configs[1]/[2] style run (4 refiner iterations, 16-bit backbone) stays close to the fp32 reference poses."""
+def test_unsupported_crop_size_fails_loudly(model):
+    from cosypose_amd._lib import CosyHipError
+    model.compute_dtype = 'fp32'
+    for hw in ((100, 100), (250, 250), (64, 64)):
+        model.render_size = hw
+        with pytest.raises(CosyHipError, match='not supported'):
+            model._net(1, torch.device('cuda'))
+    model.render_size = (240, 320)
+
+
+def _emulated_backbone(oracle, golden_sd, dtype, kinds):
+    tr = oracle.TorchRef(golden_sd)
+    return lambda x: tr.net_forward_emulated(x, dtype, kinds)
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_refiner_loop_low_precision(model, oracle, golden, golden_sd, labels21, mesh_table, dtype):
+    """configs[1]/[2] style run (4 refiner iterations, 16-bit backbone, the reference's native 240x320 crops -- every !FULLW
+    wave variant) against (1) the storage-emulating oracle loop: tight, per parameter group; (2) the fp32 reference poses:
+    fp16 within north_star's 1e-4, bf16 reported (throughput mode, bound = 3x measured)."""
+    from conftest import pose_errors
     name, B, n_it, (h, w), seed = 'b3_n4_480', 3, 4, (480, 640), 32
     obj = golden[f'fw_{name}_obj']
     images = syn.make_frames(seed + 100, B, h, w); K = syn.make_K(B, h, w); TCO = syn.make_TCO(seed + 200, B)
+    _, plan = _block_plan(model, (240, 320), dtype, B)
     model.renderer = FakeRenderer(seed * 1000)
-    model.compute_dtype = dtype
     with torch.no_grad():
         out = model(images=dev(images), K=dev(K), labels=labels21[obj], TCO=dev(TCO), n_iterations=n_it)
     model.compute_dtype = 'fp32'
-    err = rel_err(out[f'iteration={n_it}']['TCO_output'].cpu().numpy(), golden[f'fw_{name}_it{n_it}_TCO_output'])
-    print(f'{dtype}: refined pose deviation after {n_it} iterations = {err:.3e}')
-    assert err < tol
+    got = out[f'iteration={n_it}']['TCO_output'].cpu().numpy()
+    emu = oracle.pose_predictor_forward(images, K, obj, TCO, mesh_table, None,
+                                        lambda n, T, Kc: syn.make_renders(seed * 1000 + n, B, 240, 320), n_iterations=n_it,
+                                        render_size=(240, 320), backbone=_emulated_backbone(oracle, golden_sd, dtype, [p[7] for p in plan]))
+    r_e, t_e = pose_errors(got, emu[f'iteration={n_it}']['TCO_output'])
+    r_f, t_f = pose_errors(got, golden[f'fw_{name}_it{n_it}_TCO_output'])
+    print(f'{dtype}: refined poses after {n_it} iterations: vs emulation R {r_e:.2e} t {t_e:.2e}; vs reference fp32 R {r_f:.2e} t {t_f:.2e}')
+    assert max(r_e, t_e) < 2e-5
+    assert max(r_f, t_f) < (1e-4 if dtype == 'fp16' else 6e-4)
 
 
 def test_backbone_module_api(model, oracle, golden_sd):
@@ -326,32 +440,44 @@ def _headline_case(D=32, n_frames=4, seed=1):
     return obj, im, boxes, syn.make_frames(seed, n_frames, h, w), syn.make_K(n_frames, h, w)
 
 
-@pytest.fixture(scope='module')
-def headline_oracle(oracle, golden_sd, mesh_table):
-    """fp32 oracle poses of the headline case: every iteration's TCO_output (C geometry / roi_align + torch-CPU backbone)."""
+def _headline_oracle_loop(oracle, mesh_table, backbone):
+    """oracle poses of the headline case: every iteration's outputs (C geometry / roi_align + the given torch-CPU backbone)."""
     obj, im, boxes, frames, K = _headline_case()
-    tr = oracle.TorchRef(golden_sd)
     rend = lambda call: syn.make_renders(9000 + call, len(obj), 256, 256)
     TCO = oracle.tco_init_from_boxes(boxes, K[im])
     coarse = oracle.pose_predictor_forward(frames[im], K[im], obj, TCO, mesh_table, None, lambda n, t, k: rend(n), 1, (256, 256),
-                                           backbone=tr.net_forward)
+                                           backbone=backbone)
     refine = oracle.pose_predictor_forward(frames[im], K[im], obj, coarse['iteration=1']['TCO_output'], mesh_table, None,
-                                           lambda n, t, k: rend(1 + n), 4, (256, 256), backbone=tr.net_forward)
+                                           lambda n, t, k: rend(1 + n), 4, (256, 256), backbone=backbone)
     out = {'coarse/iteration=1': coarse['iteration=1']}
     out.update({f'refiner/iteration={n}': refine[f'iteration={n}'] for n in range(1, 5)})
     return out
 
 
-@pytest.mark.parametrize('dtype,tol_pose,tol_kcrop', [('fp32', NET_TOL, NET_TOL), ('bf16', 3e-4, 3e-4), ('fp16', 6e-5, 6e-5)])
-def test_headline_config_vs_oracle(model, labels21, headline_oracle, dtype, tol_pose, tol_kcrop):
-    """fp32: <= 1e-4 relative on every iteration's poses / crop cameras / boxes (north_star's bound).  bf16 / fp16: the
-    deviation of the throughput modes from the fp32 oracle, asserted at <= 3x what was measured when the test was written
-    (poses / crop cameras: bf16 1.3e-4 / 9.5e-5, fp16 3.0e-5 / 1.3e-5; fp32 itself lands at 6e-8 / 1e-6)."""
+@pytest.fixture(scope='module')
+def headline_oracle(oracle, golden_sd, mesh_table):
+    return _headline_oracle_loop(oracle, mesh_table, oracle.TorchRef(golden_sd).net_forward)
+
+
+# north_star: "<= 1e-4 relative on pose parameters".  fp32 is the reference's own arithmetic; fp16 is the headline
+# (benched) storage type and is held to the same bound, per parameter group and per crop (conftest.pose_errors /
+# rows_rel_err); bf16 cannot meet it (8 significant bits: every stored activation AND weight carries 2e-3 relative
+# rounding) and is kept as a throughput mode, asserted at <= 3x its measured deviation.
+@pytest.mark.parametrize('dtype,tol', [('fp32', NET_TOL), ('fp16', NET_TOL), ('bf16', 1.2e-3)])
+def test_headline_config_vs_oracle(model, oracle, golden_sd, mesh_table, labels21, headline_oracle, dtype, tol):
+    """BASELINE configs[1]'s shape (256x256 crops, 512x512 frames, coarse 1 + refiner 4, the bench's own detections): every
+    iteration's poses / crop cameras / boxes against the fp32 oracle loop, per parameter group; the 16-bit modes also against
+    the storage-emulating oracle loop (tight: what the fused kernels compute is what the emulation says they should)."""
     import pandas as pd
+    from conftest import pose_errors, rows_rel_err
     from cosypose_amd import tensor_collection as tc
     from cosypose_amd.pose_predictor import CoarseRefinePosePredictor
     obj, im, boxes, frames, K = _headline_case()
     det = tc.PandasTensorCollection(infos=pd.DataFrame(dict(label=labels21[obj], batch_im_id=im, score=1.0)), bboxes=dev(boxes))
+    kinds = None
+    if dtype != 'fp32':
+        _, plan = _block_plan(model, (256, 256), dtype, 32)
+        kinds = [p[7] for p in plan]
     model.renderer = FakeRenderer(9000)
     model.compute_dtype = dtype
     model.render_size = (256, 256)
@@ -359,21 +485,32 @@ def test_headline_config_vs_oracle(model, labels21, headline_oracle, dtype, tol_
     pred = CoarseRefinePosePredictor(coarse_model=model, refiner_model=model, bsz_objects=64)
     final, allp = pred.get_predictions(dev(frames), dev(K), detections=det, n_coarse_iterations=1, n_refiner_iterations=4)
     model.compute_dtype = 'fp32'; model.render_size = (240, 320)
-    worst = {}
-    for key, want in headline_oracle.items():
-        got = allp[key]
-        for f, src in (('poses', 'TCO_output'), ('K_crop', 'K_crop'), ('boxes_rend', 'boxes_rend'), ('boxes_crop', 'boxes_crop')):
-            worst[f] = max(worst.get(f, 0.0), rel_err(getattr(got, f).cpu().numpy(), want[src]))
-    print(f'headline config, {dtype}: worst relative deviation over 5 iterations: ' + ', '.join(f'{k} {v:.2e}' for k, v in worst.items()))
+
+    def worst_vs(ref):
+        w = dict(R=0.0, t=0.0, K_crop=0.0, boxes_rend=0.0, boxes_crop=0.0)
+        for key, want in ref.items():
+            got = allp[key]
+            r, t = pose_errors(got.poses.cpu().numpy(), want['TCO_output'])
+            w['R'] = max(w['R'], r); w['t'] = max(w['t'], t)
+            for f in ('K_crop', 'boxes_rend', 'boxes_crop'):
+                w[f] = max(w[f], rows_rel_err(getattr(got, f).cpu().numpy(), want[f]))
+        return w
+    w = worst_vs(headline_oracle)
+    print(f'headline config, {dtype} vs fp32 oracle, worst over 5 iterations and 32 crops: ' + ', '.join(f'{k} {v:.2e}' for k, v in w.items()))
     assert torch.equal(final.poses, allp['refiner/iteration=4'].poses)
-    assert worst['poses'] < tol_pose and worst['K_crop'] < tol_kcrop
-    assert worst['boxes_rend'] < max(tol_pose, 10 * tol_kcrop) and worst['boxes_crop'] < max(tol_pose, 10 * tol_kcrop)
+    assert w['R'] < tol and w['t'] < tol and w['K_crop'] < tol
+    assert w['boxes_rend'] < 10 * tol and w['boxes_crop'] < 10 * tol
+    if kinds is not None:
+        emu = _headline_oracle_loop(oracle, mesh_table, _emulated_backbone(oracle, golden_sd, dtype, kinds))
+        we = worst_vs(emu)
+        print(f'headline config, {dtype} vs storage-emulating oracle: ' + ', '.join(f'{k} {v:.2e}' for k, v in we.items()))
+        assert we['R'] < 2e-5 and we['t'] < 2e-5 and we['K_crop'] < 2e-5
 
 
 # ---------------------------------------------------------------------------------------------
 # full-size (BASELINE configs[1]: 256 crops in flight) size-independent properties
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+@pytest.mark.parametrize('dtype', ['fp16', 'bf16', 'fp32'])
 def test_full_batch_properties(model, labels21, dtype):
     """At B=256, 256x256 crops: (1) bitwise run-to-run determinism (fixed-order reductions everywhere),
     (2) a crop's result does not depend on which other crops share the batch (bit-exact vs running it in a batch of 3),
@@ -710,7 +847,10 @@ def test_config2_refiner_only_fp16_tless_shape(model, oracle, golden_sd, mesh_ta
                                             render_size=hw, backbone=ref.net_forward)
         want[s:e] = out['iteration=4']['TCO_output']
         call += 4
-    assert rel_err(final.poses.cpu().numpy(), want) < 5e-4       # measured 1.9e-5 (fp16 storage, fp32 accumulation)
+    from conftest import pose_errors
+    r_, t_ = pose_errors(final.poses.cpu().numpy(), want)
+    print(f'config 2 share, fp16 vs fp32 oracle: R {r_:.2e} t {t_:.2e}')
+    assert max(r_, t_) < 1e-4      # north_star's bound, per parameter group (fp16 storage, fp32 accumulation)
 
 
 def test_config3_mixed_frame_sizes_skewed_shards(model, oracle, golden_sd, mesh_table):
@@ -1074,6 +1214,32 @@ def test_ddp_two_ranks_on_one_gpu():
     assert worst < 1e-6, worst                                            # identical gradients on both ranks
     differs = max(abs(g0[n][0] - solo0[2][n][0]) / max(solo0[2][n][1], 1e-12) for n in g0)
     assert differs > 1e-4                                                 # ... and they are not rank 0's own gradients
+
+
+def test_rccl_single_rank_collectives():
+    """The collectives of cosypose_amd.distributed / train_engine through the nccl backend (RCCL) in a forced 1-rank group:
+    byte all-gather (both header forms, empty share), the 42.8 MB gradient all-reduce, and get_predictions_sharded ==
+    get_predictions bit for bit.  Runs in its own process: a process group must not leak into the other tests."""
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), 'rccl_worker.py')], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0 and 'RCCL_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_wave_isa_stamp_matches_loaded_library():
+    """kernels_wave.hip relies on a register range hipcc is not told about; build() verifies it on the generated ISA and
+    stamps the verdict (cosypose_amd/build.py: check_wave_isa).  The library loaded here must be the one that was checked:
+    the stamp exists, says clean, and carries the hash of the kernel sources in this tree."""
+    import json
+    from cosypose_amd import build as hipbuild
+    assert os.path.exists(hipbuild.ISA_STAMP), 'no ISA-check stamp next to libcosyhip.so: build it with __graft_entry__.build()'
+    st = json.load(open(hipbuild.ISA_STAMP))
+    assert st['clean'] is True and st['src_sha'] == hipbuild._wave_src_sha(), st
+    assert os.path.getmtime(hipbuild.LIB) <= os.path.getmtime(hipbuild.ISA_STAMP) + 3600
 
 
 def test_training_reference_loop_unchanged_and_deterministic(golden_train, golden_sd):
