@@ -879,7 +879,7 @@ static FuseSmallPlan fuse_small_plan(int Cin, int Cmid, int H, int W, int Ho, in
     // built for the 8x8 (7x10) maps of blocks 19-25: stride 1, one 16-pixel block per wave, 232 or 384 input channels.
     // (On the 16x16 maps the input registers + a 400-pixel fp32 tile leave one workgroup per CU: not built.)
     p.ok = esz == 2 && Cmid % 48 == 0 && (p.kbn == 8 || p.kbn == 12) && p.mpw == 1 && p.lds <= 80 * 1024 && (k == 3 || k == 5) && s == 1 &&
-           12 * Wo * cdiv(Ho, 4) <= p.threads;
+           12 * Wo * cdiv(Ho, 4) <= p.threads && ((H == 8 && W == 8) || (H == 7 && W == 10));    // the two maps it is tested on
     return p;
 }
 static int fuse_small_enabled() { static const int v = tune_int("COSY_FUSE_SMALL", 1); return v; }

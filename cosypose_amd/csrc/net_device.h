@@ -81,8 +81,17 @@ template <int N> __device__ __forceinline__ float dpp_row_shr0(float v) {
 // (32 dependent LDS reads) sat on the critical path of every chunk while the other waves waited at the next barrier.
 __device__ __forceinline__ void reduce_squeeze_sums(const float* red, int stride, int NG, int CPT, int tid, int nthr, float* out) {
     const int outputs = NG * CPT;
+    if (outputs > nthr) {       // tiny maps (fewer threads than outputs): every thread walks several outputs serially
+        for (int o = tid; o < outputs; o += nthr) {
+            const int g = o / CPT, e = o - g * CPT;
+            float sacc = 0.f;
+            for (int t = g; t < stride; t += NG) sacc += red[t * CPT + e];
+            out[o] = sacc;
+        }
+        return;
+    }
     int parts = 4;
-    while (outputs * parts > nthr) parts >>= 1;
+    while (parts > 1 && outputs * parts > nthr) parts >>= 1;
     const int o = tid / parts, part = tid - o * parts;
     float sacc = 0.f;
     if (o < outputs) {

@@ -455,50 +455,68 @@ class TorchRef:
             return t.clamp(-65504.0, 65504.0).half().float()
         return t
 
-    def extract_features_emulated(self, x, storage, fused, probes=None):
-        """x (B,6,H,W) fp32; storage 'bf16' | 'fp16'; fused[i] truthy = block i runs a fused front (E never stored).
-        probes: dict filled with {-1: stem, i: block output, 100+i: D of block i, 200+i: gate (B,Cmid), 26: head}."""
+    def stem_emulated(self, x, storage):
+        """x (B,6,H,W) fp32 (rounded to the storage type here, as the crop kernel does) -> stem output"""
+        R = lambda t: self._rnd(t, storage)
+        sw = lambda t: t * self.torch.sigmoid(t)
+        return R(sw(self._bn(self._conv(R(x), R(self.sd['backbone._conv_stem.weight']), 3, 2), 'backbone._bn0')))
+
+    def block_emulated(self, i, x, storage, fused):
+        """MBConv block i on a block input that is already in the storage type -> (D, gate (B,Cmid), block output)"""
         torch = self.torch; sd = self.sd
         R = lambda t: self._rnd(t, storage)
         sw = lambda t: t * torch.sigmoid(t)
+        k, s, e, cin, cout = B3_BLOCKS[i]
+        p = f'backbone._blocks.{i}.'
+        inp = x
+        if e != 1:
+            x = sw(self._bn(self._conv(x, R(sd[p + '_expand_conv.weight']), 1, 1), p + '_bn0'))
+            if not fused:
+                x = R(x)
+        d32 = sw(self._bn(self._conv(x, sd[p + '_depthwise_conv.weight'], k, s, groups=x.shape[1]), p + '_bn1'))
+        q = d32.mean((2, 3), keepdim=True)
+        q = self._conv(sw(self._conv(q, sd[p + '_se_reduce.weight'], 1, 1, bias=sd[p + '_se_reduce.bias'])),
+                       sd[p + '_se_expand.weight'], 1, 1, bias=sd[p + '_se_expand.bias'])
+        g = torch.sigmoid(q)[:, :, 0, 0]                       # (B, Cmid)
+        D = R(d32)
+        W = R(sd[p + '_project_conv.weight'])[:, :, 0, 0]        # (Cout, Cmid)
+        hw = D.shape[2] * D.shape[3]
+        if hw % 64 == 0:                                         # gate folded into the weight fragments, per sample
+            if storage == 'fp16':
+                Wg = (W.half()[None] * g.half()[:, None, :]).float()
+            else:
+                Wg = R(W[None] * g[:, None, :])
+            y = torch.einsum('bnk,bkhw->bnhw', Wg, D)
+        else:                                                    # gate applied to the activation rows
+            if storage == 'fp16':
+                Dg = (D.half() * g.half()[:, :, None, None]).float()
+            else:
+                Dg = R(D * g[:, :, None, None])
+            y = torch.einsum('nk,bkhw->bnhw', W, Dg)
+        y = self._bn(y, p + '_bn2')
+        if s == 1 and cin == cout:
+            y = y + inp
+        return D, g, R(y)
+
+    def head_emulated(self, x, storage):
+        R = lambda t: self._rnd(t, storage)
+        sw = lambda t: t * self.torch.sigmoid(t)
+        return R(sw(self._bn(self._conv(x, R(self.sd['backbone._conv_head.weight']), 1, 1), 'backbone._bn1')))
+
+    def extract_features_emulated(self, x, storage, fused, probes=None):
+        """x (B,6,H,W) fp32; storage 'bf16' | 'fp16'; fused[i] truthy = block i runs a fused front (E never stored).
+        probes: dict filled with {-1: stem, i: block output, 100+i: D of block i, 200+i: gate (B,Cmid), 26: head}.
+        NOTE: two evaluations of a 26-block network that round at every layer decorrelate with depth (a value one ulp apart
+        perturbs the next layer's roundings), so the END-TO-END distance between this and the device grows to the size of
+        the storage type's own rounding noise; kernels are therefore checked block by block on the DEVICE's block inputs
+        (tests/test_gpu_parity.py: test_fused_kernels_vs_storage_emulation), where the distance stays at isolated ulps."""
         put = (lambda k, v: probes.__setitem__(k, v.clone())) if probes is not None else (lambda k, v: None)
-        x = R(x)
-        x = R(sw(self._bn(self._conv(x, R(sd['backbone._conv_stem.weight']), 3, 2), 'backbone._bn0')))
+        x = self.stem_emulated(x, storage)
         put(-1, x)
-        for i, (k, s, e, cin, cout) in enumerate(B3_BLOCKS):
-            p = f'backbone._blocks.{i}.'
-            inp = x
-            if e != 1:
-                x = sw(self._bn(self._conv(x, R(sd[p + '_expand_conv.weight']), 1, 1), p + '_bn0'))
-                if not fused[i]:
-                    x = R(x)
-            d32 = sw(self._bn(self._conv(x, sd[p + '_depthwise_conv.weight'], k, s, groups=x.shape[1]), p + '_bn1'))
-            q = d32.mean((2, 3), keepdim=True)
-            q = self._conv(sw(self._conv(q, sd[p + '_se_reduce.weight'], 1, 1, bias=sd[p + '_se_reduce.bias'])),
-                           sd[p + '_se_expand.weight'], 1, 1, bias=sd[p + '_se_expand.bias'])
-            g = torch.sigmoid(q)[:, :, 0, 0]                       # (B, Cmid)
-            D = R(d32)
-            put(100 + i, D); put(200 + i, g)
-            W = R(sd[p + '_project_conv.weight'])[:, :, 0, 0]        # (Cout, Cmid)
-            hw = D.shape[2] * D.shape[3]
-            if hw % 64 == 0:                                         # gate folded into the weight fragments, per sample
-                if storage == 'fp16':
-                    Wg = (W.half()[None] * g.half()[:, None, :]).float()
-                else:
-                    Wg = R(W[None] * g[:, None, :])
-                y = torch.einsum('bnk,bkhw->bnhw', Wg, D)
-            else:                                                    # gate applied to the activation rows
-                if storage == 'fp16':
-                    Dg = (D.half() * g.half()[:, :, None, None]).float()
-                else:
-                    Dg = R(D * g[:, :, None, None])
-                y = torch.einsum('nk,bkhw->bnhw', W, Dg)
-            x = self._bn(y, p + '_bn2')
-            if s == 1 and cin == cout:
-                x = x + inp
-            x = R(x)
-            put(i, x)
-        x = R(sw(self._bn(self._conv(x, R(sd['backbone._conv_head.weight']), 1, 1), 'backbone._bn1')))
+        for i in range(len(B3_BLOCKS)):
+            D, g, x = self.block_emulated(i, x, storage, fused[i])
+            put(100 + i, D); put(200 + i, g); put(i, x)
+        x = self.head_emulated(x, storage)
         put(26, x)
         return x
 

