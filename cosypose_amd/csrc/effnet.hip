@@ -65,6 +65,9 @@ struct Block {
     PwLayer exp, proj;
     void* exp_wp_fused;   // expand weights packed in 16- (wave) or 48-channel (small) tiles for the fused front
     float *dw_w, *dw_scale, *dw_bias, *se_wr, *se_br, *se_we, *se_be;
+    float *b0_fold, *dw_w_fold;   // small kernel: log2(e) * BN0 bias; taps * BN1 scale * ln 2 (the BN0 scale is inside exp_wp_fused)
+    bool se_batched;      // squeeze-excite as two batched GEMM kernels (late blocks) instead of one workgroup per sample
+    float *se_wr_p, *se_br_p, *se_we_p;   // zero-padded copies for the batched form: (CseP, Cmid), (CseP), (Cmid, CseP)
 };
 
 }  // namespace cosy
@@ -79,11 +82,12 @@ struct cosy_net {
     int chunk, fuse;
     unsigned small_mask;  // bit i: MBConv block i may run the fused whole-image front kernel (mbconv_small_kernel)
     unsigned wave_mask;   // bit i: ... the wave-autonomous front kernel (mbconv_wave_kernel); both only where the shape is built
+    int se_batch_from;    // blocks >= this run the batched squeeze-excite kernels
     int probe_layer;      // test probe (cosy_effnet_b3_set_probe): -2 = off
     float* probe_out;
     // activation workspaces: ws[0] holds max_batch samples; ws[1] (half size) serves the second half-batch when the
     // forward is split over two internal streams so that VALU-bound and MFMA/bandwidth-bound kernels co-reside
-    struct WS { void *act[2], *E, *D, *Hd, *actc[2], *Ec, *Dc; float *partial, *gate, *featbuf; } ws[2];
+    struct WS { void *act[2], *E, *D, *Hd, *actc[2], *Ec, *Dc; float *partial, *gate, *featbuf, *redv; } ws[2];
     int nstreams, last_split;
     hipStream_t side[2];
     hipEvent_t ev_fork, ev_join[2];
@@ -171,15 +175,32 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         if (b.d.e != 1) {
             mk_pw(b.exp, p, b.d.cin, b.cmid, p + (size_t)b.cmid * b.d.cin, b.H * b.W, false);
             if (b.fused) {
+                // Small kernel (blocks 19-25): BatchNorm 0 costs no instruction.  Its scale -- times log2(e), so that the SiLU that
+                // follows is t / (1 + 2^-t) -- is folded into the expand weights BEFORE they are rounded to the storage type, its bias
+                // (times log2 e) is the C operand of the first MFMA (b0_fold); the inverse factor ln 2 and BatchNorm 1's scale
+                // ride in the depthwise taps (dw_w_fold), BatchNorm 1's bias initialises the depthwise accumulators.
+                // (Measured on the wave kernel too: no gain there -- the freed VALU slots do not shorten its rows, and the MFMA
+                // results then feed inline asm directly, which needs explicit wait states -- so it keeps its BatchNorms.)
                 const PwCfg c48 = b.wave ? PwCfg{1, 1} : PwCfg{3, 1};   // 16-channel tiles for the wave kernel, 48 for the small kernel
                 const size_t ne = pw_packed_elems(b.d.cin, b.cmid, c48, n->dtype);
                 b.exp_wp_fused = bump.take(ne * n->esz);
+                std::vector<float> b0f(b.cmid, 0.f);
                 if (fill) {
+                    std::vector<float> sc0, bi0, ws(p, p + (size_t)b.cmid * b.d.cin);
+                    if (b.small) {
+                        fold_bn(p + (size_t)b.cmid * b.d.cin, b.cmid, b.cmid, sc0, bi0);
+                        const double L2E = 1.4426950408889634;
+                        for (int c = 0; c < b.cmid; ++c) {
+                            b0f[c] = (float)((double)bi0[c] * L2E);
+                            for (int k = 0; k < b.d.cin; ++k) ws[(size_t)c * b.d.cin + k] = (float)((double)p[(size_t)c * b.d.cin + k] * (double)sc0[c] * L2E);
+                        }
+                    }
                     std::vector<char> tmp(ne * n->esz);
-                    pw_pack_weights(p, b.d.cin, b.cmid, c48, n->dtype, tmp.data());
+                    pw_pack_weights(ws.data(), b.d.cin, b.cmid, c48, n->dtype, tmp.data());
                     hipError_t e2 = hipMemcpy(b.exp_wp_fused, tmp.data(), tmp.size(), hipMemcpyHostToDevice);
                     if (e2 != hipSuccess) *herr = e2;
                 }
+                b.b0_fold = up_f32(b0f);
                 b.n_tiles = b.wave ? wave_max_tiles() : 1;
             }
             p += (size_t)b.cmid * b.d.cin + 4 * b.cmid;
@@ -194,6 +215,14 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
             if (fill) fold_bn(p, b.cmid, b.cmid, sc, bi); else { sc.assign(b.cmid, 0.f); bi.assign(b.cmid, 0.f); }
             p += 4 * b.cmid;
             b.dw_w = up_f32(w); b.dw_scale = up_f32(sc); b.dw_bias = up_f32(bi);
+            b.dw_w_fold = nullptr;
+            if (b.small) {
+                std::vector<float> wf(w.size(), 0.f);
+                if (fill)
+                    for (int t = 0; t < kk; ++t)
+                        for (int c = 0; c < b.cmid; ++c) wf[t * b.cmid + c] = (float)((double)w[t * b.cmid + c] * (double)sc[c] * 0.6931471805599453);
+                b.dw_w_fold = up_f32(wf);
+            }
         }
         {   // SE: reduce (Cse,Cmid), bias, expand (Cmid,Cse) -> stored transposed (Cse,Cmid), bias
             std::vector<float> wr(p, p + (fill ? (size_t)b.cse * b.cmid : 0)); if (!fill) wr.assign((size_t)b.cse * b.cmid, 0.f);
@@ -208,6 +237,19 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
             std::vector<float> be(b.cmid, 0.f); if (fill) be.assign(p, p + b.cmid);
             p += b.cmid;
             b.se_wr = up_f32(wr); b.se_br = up_f32(br); b.se_we = up_f32(we); b.se_be = up_f32(be);
+            b.se_batched = i >= n->se_batch_from && se_batched_supported(b.cmid, b.cse);
+            b.se_wr_p = b.se_br_p = b.se_we_p = nullptr;
+            if (b.se_batched) {
+                const int csep = (b.cse + 15) & ~15;
+                std::vector<float> wrp((size_t)csep * b.cmid, 0.f), brp(csep, 0.f), wep((size_t)b.cmid * csep, 0.f);
+                if (fill) {
+                    std::copy(wr.begin(), wr.end(), wrp.begin());
+                    std::copy(br.begin(), br.end(), brp.begin());
+                    for (int c = 0; c < b.cmid; ++c)
+                        for (int j = 0; j < b.cse; ++j) wep[(size_t)c * csep + j] = we[(size_t)j * b.cmid + c];
+                }
+                b.se_wr_p = up_f32(wrp); b.se_br_p = up_f32(brp); b.se_we_p = up_f32(wep);
+            }
         }
         mk_pw(b.proj, p, b.cmid, b.d.cout, p + (size_t)b.d.cout * b.cmid, b.Ho * b.Wo, true);
         p += (size_t)b.d.cout * b.cmid + 4 * b.d.cout;
@@ -257,6 +299,7 @@ static void layout_ws(cosy_net* n, Bump& b, cosy_net::WS& w, size_t B) {
     w.partial = (float*)b.take(part * sizeof(float));
     w.gate = (float*)b.take(B * gate * sizeof(float));
     w.featbuf = (float*)b.take(B * (size_t)HEAD_C * sizeof(float));
+    w.redv = (float*)b.take(B * (size_t)128 * sizeof(float));
 }
 static void layout_workspace(cosy_net* n, Bump& b) {
     n->X = b.take((size_t)n->maxB * n->H * n->W * 8 * n->esz);
@@ -307,7 +350,9 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         int se_tiles = b.n_tiles;     // partial-sum tiles per sample the front kernel writes (the wave kernel decides per launch)
         if (b.fused) {
             FuseArgs f{};
-            f.X = in; f.Wp = b.exp_wp_fused; f.s0 = b.exp.scale; f.b0 = b.exp.bias; f.dww = b.dw_w; f.s1 = b.dw_scale; f.b1 = b.dw_bias;
+            f.X = in; f.Wp = b.exp_wp_fused;
+            if (b.small) { f.b0 = b.b0_fold; f.dww = b.dw_w_fold; f.b1 = b.dw_bias; }
+            else { f.s0 = b.exp.scale; f.b0 = b.exp.bias; f.dww = b.dw_w; f.s1 = b.dw_scale; f.b1 = b.dw_bias; }
             f.D = Dbuf; f.partial = w.partial; f.zeros = n->zeros;
             f.B = Bc; f.H = b.H; f.W = b.W; f.Cin = b.d.cin; f.Cmid = b.cmid; f.Ho = b.Ho; f.Wo = b.Wo; f.k = b.d.k; f.s = b.d.s; f.pad_lo = b.pad_lo;
             if ((rc = b.wave ? launch_mbconv_wave(f, n->dtype, &se_tiles, s) : launch_mbconv_small(f, n->dtype, s))) return rc;
@@ -341,8 +386,8 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         SeArgs se{};
         se.partial = w.partial; se.n_tiles = se_tiles; se.w_red = b.se_wr; se.b_red = b.se_br; se.w_exp = b.se_we; se.b_exp = b.se_be;
         se.gate = w.gate; se.B = Bc; se.C = b.cmid; se.Cse = b.cse; se.HW = b.Ho * b.Wo;
-        if ((rc = launch_se(se, s))) return rc;
-        if ((rc = mark("se_kernel", i, (double)Bc * se_tiles * b.cmid * 4 + (double)Bc * b.cmid * 4 + 2.0 * b.cse * b.cmid * 4,
+        if ((rc = b.se_batched ? launch_se_batched(se, b.se_wr_p, b.se_br_p, b.se_we_p, w.redv, s) : launch_se(se, s))) return rc;
+        if ((rc = mark(b.se_batched ? "se_fc1_kernel+se_fc2_kernel" : "se_kernel", i, (double)Bc * se_tiles * b.cmid * 4 + (double)Bc * b.cmid * 4 + 2.0 * b.cse * b.cmid * 4,
                        4.0 * Bc * b.cse * b.cmid))) return rc;
         PwArgs a{};
         a.A = Dbuf; a.Wp = b.proj.Wp; a.out = out; a.scale = b.proj.scale; a.bias = b.proj.bias;
@@ -466,6 +511,7 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
         const int c = tune_int("COSY_EARLY_CHUNK", 0);   // measured: chunking the early segment is slower (kernels are issue-bound)
         n->chunk = c <= 0 ? max_batch : c;
         n->fuse = tune_int("COSY_FUSE", 1);
+        n->se_batch_from = tune_int("COSY_SE_BATCH_FROM", 19);
         n->small_mask = (unsigned)tune_int("COSY_SMALL_MASK", 0x3f80000);   // blocks 19-25 (8x8 / 7x10 maps): whole-image kernel
         n->wave_mask = (unsigned)tune_int("COSY_WAVE_MASK", 0x3fffc);   // blocks 2-17: maps 16..128 pixels wide, stride per shape table
         n->nstreams = tune_int("COSY_STREAMS", 1) == 2 && max_batch >= 32 ? 2 : 1;   // measured: 2 streams x half batches is ~10 % slower

@@ -50,9 +50,13 @@ int launch_dwconv(const DwArgs& a, int dtype, hipStream_t s);
 struct FuseArgs {
     const void* X;       // (B,H,W,Cin) block input
     const void* Wp;      // expand weights packed with PwCfg{3,1} (48-channel tiles; small kernel) / PwCfg{1,1} (wave kernel)
-    const float* s0; const float* b0;   // folded BN0 (Cmid)
-    const float* dww;    // (k*k, Cmid) fp32 depthwise taps
-    const float* s1; const float* b1;   // folded BN1 (Cmid)
+    // wave kernel: s0/b0 = folded BN0 scale/bias, dww = fp32 depthwise taps (k*k, Cmid), s1/b1 = folded BN1 scale/bias.
+    // small kernel: both BatchNorm scales are folded away at create time -- Wp holds W * s0 * log2(e) (rounded to the storage type
+    // after the scaling), b0 = log2(e) * BN0 bias (the C operand of the first MFMA), dww = taps * s1 * ln 2, b1 = BN1 bias
+    // (initialises the depthwise accumulators); s0 / s1 are unused (null).
+    const float* s0; const float* b0;
+    const float* dww;
+    const float* s1; const float* b1;
     void* D;             // (B,Ho,Wo,Cmid)
     float* partial;      // (B, n_tiles, Cmid)
     const void* zeros;
@@ -80,6 +84,10 @@ struct SeArgs {
     int B, C, Cse, HW;
 };
 int launch_se(const SeArgs& a, hipStream_t s);
+// batched form for the late blocks: the two FCs as GEMMs over the batch (16-sample tiles share one read of the weights);
+// wr_p (CseP, C), br_p (CseP), we_p (C, CseP): zero-padded copies, CseP = Cse rounded up to 16; redv: (B, CseP) scratch
+bool se_batched_supported(int C, int Cse);
+int launch_se_batched(const SeArgs& a, const float* wr_p, const float* br_p, const float* we_p, float* redv, hipStream_t s);
 
 size_t stem_packed_elems(int dtype);
 void stem_pack_weights(const float* w_oihw /*(40,6,3,3)*/, int dtype, void* dst);

@@ -654,7 +654,7 @@ bool small_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W) {
 //   * squeeze sums are complete per (sample, chunk): partial has n_tiles = 1.
 // ------------------------------------------------------------------------------------------
 struct FuseSKArgs {
-    const void* X; const void* Wp; const float* s0; const float* b0; const float* dww; const float* s1; const float* b1;
+    const void* X; const void* Wp; const float* b0; const float* dww; const float* b1;
     void* D; float* partial; const void* zeros;
     int H, W, NP, Cin, Cmid, Ho, Wo, lo, THin, TWin, nkb_total, MBr, ncg, cpw, dbg;
     unsigned rcp_w;   // ceil(2^16 / W): p / W == (p * rcp_w) >> 16 for p < MBr*16 (checked on the host)
@@ -668,9 +668,10 @@ __global__ __launch_bounds__(512) void mbconv_small_kernel(FuseSKArgs a) {
     constexpr int NROW = (R - 1) * S + KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int TWin = a.TWin, npos = a.THin * a.TWin;
-    // per-chunk parameters [s0 48][b0 48][s1 48][b1 48][taps KS*KS x 48] fp32, double buffered: they are prefetched by DMA
-    // one chunk ahead (fetching them with ordinary loads at the top of a chunk exposes ~2 us of latency per chunk)
-    constexpr int PU = 4 * (CC / 4) + KS * KS * (CC / 4);      // 16-byte units per parameter block
+    // per-chunk parameters [b0 48][b1 48][taps KS*KS x 48] fp32, double buffered: they are prefetched by DMA one chunk ahead
+    // (fetching them with ordinary loads at the top of a chunk exposes ~2 us of latency per chunk).  As in the wave kernel the
+    // BatchNorm scales are folded into the expand weights (x log2 e) and the taps (x ln 2); the biases start the accumulators.
+    constexpr int PU = 2 * (CC / 4) + KS * KS * (CC / 4);      // 16-byte units per parameter block
     constexpr int PJ = (PU + 63) / 64, PBYTES = PJ * 1024;
     char* Et = smem;
     char* Wl = Et + (size_t)npos * PITCH;
@@ -696,7 +697,7 @@ __global__ __launch_bounds__(512) void mbconv_small_kernel(FuseSKArgs a) {
             const float* src = (const float*)a.zeros;
             if (u < PU) {
                 const int arr = u / (CC / 4), q = u - arr * (CC / 4);
-                const float* base = arr == 0 ? a.s0 : arr == 1 ? a.b0 : arr == 2 ? a.s1 : arr == 3 ? a.b1 : a.dww + (size_t)(arr - 4) * a.Cmid;
+                const float* base = arr == 0 ? a.b0 : arr == 1 ? a.b1 : a.dww + (size_t)(arr - 2) * a.Cmid;
                 src = base + ch * CC + q * 4;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -740,20 +741,20 @@ __global__ __launch_bounds__(512) void mbconv_small_kernel(FuseSKArgs a) {
     __syncthreads();
     for (int ch = ch0; ch < ch1; ++ch) {
         const float* P = (const float*)(Pl + (size_t)(ch & 1) * PBYTES);
-        const float* wl = P + 4 * CC;
+        const float* wl = P + 2 * CC;
         // ---- expansion on the matrix cores -> Et (real pixels only)
         {
             const int n0 = kg * 4 * NI;
-            float sc[NI * 4], bi[NI * 4];
+            f32x4 bi[NI];
 #pragma unroll
-            for (int q = 0; q < NI; ++q) { load4(P + n0 + q * 4, sc + q * 4); load4(P + CC + n0 + q * 4, bi + q * 4); }
+            for (int q = 0; q < NI; ++q) bi[q] = *(const f32x4*)(P + n0 + q * 4);
 #pragma unroll
             for (int mi = 0; mi < MPW; ++mi) {
                 const int mb = wave + mi * nwaves;
                 if (mb < a.MBr && !COSY_DBG(a.dbg & 2)) {
                     f32x4 acc[NI];
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) acc[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int ni = 0; ni < NI; ++ni) acc[ni] = bi[ni];          // log2(e) * BN0 bias: C operand of the first MFMA
 #pragma unroll
                     for (int kb = 0; kb < KBN; ++kb)
 #pragma unroll
@@ -769,8 +770,8 @@ __global__ __launch_bounds__(512) void mbconv_small_kernel(FuseSKArgs a) {
                         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                float v = acc[ni][r] * sc[ni * 4 + r] + bi[ni * 4 + r];
-                                v12[ni * 4 + r] = v * sigmoid_t<T>(v);
+                                const float t = acc[ni][r];               // = log2(e) * BN0(expand)
+                                v12[ni * 4 + r] = t * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-t));   // = log2(e) * silu
                             }
                         float* dst = (float*)(Et + (size_t)((y + a.lo) * TWin + x + a.lo) * PITCH) + kg * 4 * NI;
                         store4(dst, v12); store4(dst + 4, v12 + 4); store4(dst + 8, v12 + 8);
@@ -785,13 +786,13 @@ __global__ __launch_bounds__(512) void mbconv_small_kernel(FuseSKArgs a) {
 #pragma unroll
         for (int c = 0; c < CPT; ++c) sum[c] = 0.f;
         if (has_unit) {
-            float sc[CPT], bi[CPT];
-            load4(P + 2 * CC + cq * CPT, sc); load4(P + 3 * CC + cq * CPT, bi);
+            float bi[CPT];
+            load4(P + CC + cq * CPT, bi);
             float acc[R][CPT];
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int c = 0; c < CPT; ++c) acc[r][c] = 0.f;
+                for (int c = 0; c < CPT; ++c) acc[r][c] = bi[c];             // BN1 bias (its scale is in the taps)
 #pragma unroll 1
             for (int kx = 0; kx < KS; ++kx) {
                 float wc[KS][CPT];
@@ -816,7 +817,7 @@ __global__ __launch_bounds__(512) void mbconv_small_kernel(FuseSKArgs a) {
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int c = 0; c < CPT; ++c) {
-                    float v = acc[r][c] * sc[c] + bi[c];
+                    float v = acc[r][c];
                     v = v * sigmoid_t<T>(v);
                     yv[r][c] = v;
                     if (uyq * R + r < a.Ho) sum[c] += v;
@@ -870,7 +871,7 @@ static FuseSmallPlan fuse_small_plan(int Cin, int Cmid, int H, int W, int Ho, in
     if (p.THin < H + k - 1) p.THin = H + k - 1;
     p.TWin = (Wo - 1) * s + k;
     if (p.TWin < W + k - 1) p.TWin = W + k - 1;
-    const int pj = (4 * 12 + k * k * 12 + 63) / 64;     // parameter block, see the kernel
+    const int pj = (2 * 12 + k * k * 12 + 63) / 64;     // parameter block, see the kernel
     p.lds = (size_t)p.THin * p.TWin * et_pitch(4, s) + (size_t)3 * p.kbn * 1024 + (size_t)2 * pj * 1024 + (size_t)p.threads * 4 * 4;
     const int nchunks = Cmid / 48;
     static const int cpw_target = tune_int("COSY_SMALL_CPW", 15);
@@ -909,7 +910,7 @@ template <typename T>
 static int launch_fuse_small_t(const FuseArgs& a, hipStream_t s) {
     const FuseSmallPlan p = fuse_small_plan(a.Cin, a.Cmid, a.H, a.W, a.Ho, a.Wo, a.k, a.s, sizeof(T));
     FuseSKArgs k;
-    k.X = a.X; k.Wp = a.Wp; k.s0 = a.s0; k.b0 = a.b0; k.dww = a.dww; k.s1 = a.s1; k.b1 = a.b1; k.D = a.D; k.partial = a.partial;
+    k.X = a.X; k.Wp = a.Wp; k.b0 = a.b0; k.dww = a.dww; k.b1 = a.b1; k.D = a.D; k.partial = a.partial;
     k.zeros = a.zeros; k.H = a.H; k.W = a.W; k.NP = a.H * a.W; k.Cin = a.Cin; k.Cmid = a.Cmid; k.Ho = a.Ho; k.Wo = a.Wo; k.lo = a.pad_lo;
     k.THin = p.THin; k.TWin = p.TWin; k.nkb_total = pw_nkb_total(a.Cin, COSY_BF16); k.MBr = p.MBr; k.ncg = p.ncg; k.cpw = p.cpw;
     k.rcp_w = (65536u + a.W - 1) / a.W;
@@ -1038,6 +1039,94 @@ __global__ __launch_bounds__(512) void se_kernel(SeArgs a) {
 int launch_se(const SeArgs& a, hipStream_t s) {
     if (a.B == 0) return COSY_OK;
     hipLaunchKernelGGL(se_kernel, dim3(a.B), dim3(512), (a.C + ((a.Cse + 3) & ~3) + 2048) * sizeof(float), s, a);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Batched squeeze-excite for the late blocks (Cmid 1392 / 2304, Cse 58 / 96).  se_kernel runs one workgroup per sample and
+// every workgroup reads the whole of both FC matrices (0.65 / 1.77 MB): 256 samples = 166 / 453 MB through L2, 20 / 48 us
+// per block.  The two FCs are small GEMMs over the BATCH: z = pooled (B x C) * Wr^T (C x Cse), gate = sigmoid(swish(z + br)
+// (B x Cse) * We^T (Cse x C) + be), so a 16-sample tile shares one read of the weights.  Both run on the fp32 matrix
+// instruction (v_mfma_f32_16x16x4_f32: an exact fp32 FMA chain per output, rows independent of each other -> a sample's
+// gate does not depend on its tile mates: batch-invariant and deterministic).  Weights = MFMA A operand (rows = outputs),
+// samples = B operand (columns), so a lane ends up with 4 consecutive outputs of one sample: 16-byte stores.
+//   se_fc1: grid (sample tiles, Cse tiles of 16); the WAVES waves of a workgroup split the C range (k), fixed-order LDS combine.
+//   se_fc2: grid (sample tiles, groups of WAVES channel tiles); k = padded Cse (4-6 steps: every load in flight at once).
+// wr_p (CseP, C) and we_p (C, CseP) are zero-padded copies (CseP = Cse rounded up to 16) made at create time.
+// ------------------------------------------------------------------------------------------
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void se_fc1_kernel(const float* __restrict__ partial, int n_tiles, const float* __restrict__ wr_p,
+                                                            const float* __restrict__ br_p, float* __restrict__ redv, int B, int C, int CseP,
+                                                            float inv_hw) {
+    __shared__ f32x4 comb[WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kg = lane >> 4;
+    const int b = min((int)blockIdx.x * 16 + i, B - 1), j0 = blockIdx.y * 16;
+    const float* prow = partial + (size_t)b * n_tiles * C + kg * 4;
+    const float* wrow = wr_p + (size_t)(j0 + i) * C + kg * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int nsteps = C >> 4;
+    for (int st0 = wave; st0 < nsteps; st0 += 4 * WAVES) {        // 4 independent steps (8+ loads) in flight per wave
+        f32x4 a[4], w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int st = st0 + u * WAVES;
+            a[u] = f32x4{0.f, 0.f, 0.f, 0.f}; w[u] = a[u];
+            if (st < nsteps) {
+                w[u] = *(const f32x4*)(wrow + st * 16);
+                for (int t = 0; t < n_tiles; ++t) a[u] += *(const f32x4*)(prow + (size_t)t * C + st * 16);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mma(acc, w[u], a[u]);
+    }
+    comb[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+        f32x4 s = comb[0][lane];
+#pragma unroll
+        for (int q = 1; q < WAVES; ++q) s += comb[q][lane];
+        const f32x4 bias = *(const f32x4*)(br_p + j0 + kg * 4);
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float z = s[e] * inv_hw + bias[e]; r[e] = z * (1.f / (1.f + expf(-z))); }
+        if ((int)blockIdx.x * 16 + i < B) *(f32x4*)(redv + (size_t)b * CseP + j0 + kg * 4) = r;
+    }
+}
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void se_fc2_kernel(const float* __restrict__ redv, const float* __restrict__ we_p,
+                                                            const float* __restrict__ be, float* __restrict__ gate, int B, int C, int CseP) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kg = lane >> 4;
+    const int ct = blockIdx.y * WAVES + wave;
+    if (ct * 16 >= C) return;
+    const int b = min((int)blockIdx.x * 16 + i, B - 1), c0 = ct * 16;
+    const float* rrow = redv + (size_t)b * CseP + kg * 4;
+    const float* wrow = we_p + (size_t)(c0 + i) * CseP + kg * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int nsteps = CseP >> 4;       // <= 8
+    f32x4 a[8], w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        a[u] = f32x4{0.f, 0.f, 0.f, 0.f}; w[u] = a[u];
+        if (u < nsteps) { w[u] = *(const f32x4*)(wrow + u * 16); a[u] = *(const f32x4*)(rrow + u * 16); }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mma(acc, w[u], a[u]);
+    const f32x4 bias = *(const f32x4*)(be + c0 + kg * 4);
+    f32x4 g;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = 1.f / (1.f + expf(-(acc[e] + bias[e])));
+    if ((int)blockIdx.x * 16 + i < B) *(f32x4*)(gate + (size_t)b * C + c0 + kg * 4) = g;
+}
+bool se_batched_supported(int C, int Cse) { return C % 16 == 0 && (Cse + 15) / 16 <= 8; }
+int launch_se_batched(const SeArgs& a, const float* wr_p, const float* br_p, const float* we_p, float* redv, hipStream_t s) {
+    if (a.B == 0) return COSY_OK;
+    const int CseP = (a.Cse + 15) & ~15;
+    COSY_REQUIRE(se_batched_supported(a.C, a.Cse), "se_batched: C=%d Cse=%d not supported", a.C, a.Cse);
+    constexpr int W1 = 8, W2 = 4;
+    hipLaunchKernelGGL(se_fc1_kernel<W1>, dim3(cdiv(a.B, 16), CseP / 16), dim3(W1 * 64), 0, s, a.partial, a.n_tiles, wr_p, br_p, redv, a.B, a.C,
+                       CseP, 1.f / (float)a.HW);
+    hipLaunchKernelGGL(se_fc2_kernel<W2>, dim3(cdiv(a.B, 16), cdiv(a.C / 16, W2)), dim3(W2 * 64), 0, s, redv, we_p, a.b_exp, a.gate, a.B, a.C, CseP);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }

@@ -85,6 +85,23 @@ template <int TOP, int I> __device__ __forceinline__ f32x4 xfrag_read() {
                  : "n"(TOP - 4 * (I + 1)), "n"(TOP - 4 * (I + 1) + 1), "n"(TOP - 4 * (I + 1) + 2), "n"(TOP - 4 * (I + 1) + 3));
     return f32x4{x0, x1, x2, x3};
 }
+// Fence: an empty asm that CLOBBERS the reserved fragment registers.  No value that is live across it can be allocated there, so
+// placing one at every point of the row loop where fragments are (or are about to be) in flight -- after the loads are issued,
+// in front of the wait -- keeps every long-lived value of the kernel out of the range by construction; what is left to luck
+// (and to profiles/check_wave_isa.py) are temporaries that live entirely between two fences.
+template <int TOP, int NFRAG> __device__ __forceinline__ void xfrag_fence() {
+    if constexpr (TOP == 256 && NFRAG == 5) asm volatile("; XFENCE" ::: "v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
+    else if constexpr (TOP == 256 && NFRAG == 6) asm volatile("; XFENCE" ::: "v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
+    else if constexpr (TOP == 256 && NFRAG == 8) asm volatile("; XFENCE" ::: "v224","v225","v226","v227","v228","v229","v230","v231","v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
+    else if constexpr (TOP == 256 && NFRAG == 10) asm volatile("; XFENCE" ::: "v216","v217","v218","v219","v220","v221","v222","v223","v224","v225","v226","v227","v228","v229","v230","v231","v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
+    else if constexpr (TOP == 168 && NFRAG == 4) asm volatile("; XFENCE" ::: "v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
+    else if constexpr (TOP == 168 && NFRAG == 5) asm volatile("; XFENCE" ::: "v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
+    else if constexpr (TOP == 168 && NFRAG == 6) asm volatile("; XFENCE" ::: "v144","v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
+    else if constexpr (TOP == 168 && NFRAG == 8) asm volatile("; XFENCE" ::: "v136","v137","v138","v139","v140","v141","v142","v143","v144","v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
+    else if constexpr (TOP == 128 && NFRAG == 3) asm volatile("; XFENCE" ::: "v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
+    else if constexpr (TOP == 128 && NFRAG == 4) asm volatile("; XFENCE" ::: "v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
+    else static_assert(TOP < 0, "xfrag_fence: add the clobber list of this (budget, fragments) pair");
+}
 template <int MINW> __device__ __forceinline__ void xfrag_reserve() {
     if constexpr (MINW == 2) asm volatile("; XRESERVE" ::: "v255");
     else if constexpr (MINW == 3) asm volatile("; XRESERVE" ::: "v167");
@@ -155,10 +172,12 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
             constexpr int i = decltype(ic)::value;
             xfrag_load<XTOP, i>(xoff[i / KBN][i % KBN], rowp);
         }, std::make_integer_sequence<int, PPL * KBN>{});
+        xfrag_fence<XTOP, PPL * KBN>();
         st_in_flight = 0;
     };
     auto wait_row = [&]() {
         constexpr int NST = (PPL / S) * NI;
+        xfrag_fence<XTOP, PPL * KBN>();
         if (st_in_flight) asm volatile("s_waitcnt vmcnt(%0) ; XWAIT" :: "n"(NST) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) ; XWAIT" ::: "memory");
         unroll_seq([&](auto ic) {

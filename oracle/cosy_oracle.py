@@ -441,7 +441,9 @@ class TorchRef:
     # ---- storage emulation (test infrastructure for the 16-bit throughput modes) ----------------------------------------
     # The same network with every value rounded to the 16-bit storage type exactly where the HIP path stores one:
     # network input, stem output, block inputs / outputs, the depthwise output D, the expanded tensor E of the UNFUSED blocks
-    # (the fused fronts keep E in fp32 registers / LDS), the head activation; the 1x1-conv and stem weights; and the
+    # (the fused fronts keep E in fp32 registers / LDS; the small kernel also folds BN0's scale into its expand weights before
+    # rounding them),
+    # the head activation; the 1x1-conv and stem weights; and the
     # squeeze-excite gate where the project GEMM applies it -- to the weight fragments (maps with Ho*Wo % 64 == 0:
     # bf16 round(w * g), fp16 w * half(g) in half arithmetic) or to the activation rows (other maps).  Accumulation, BatchNorm,
     # SiLU, the depthwise taps, the squeeze sums (taken BEFORE D is rounded) and the SE FCs are fp32, as on the device.
@@ -469,9 +471,20 @@ class TorchRef:
         k, s, e, cin, cout = B3_BLOCKS[i]
         p = f'backbone._blocks.{i}.'
         inp = x
-        if e != 1:
+        if e != 1 and fused == 2:
+            # small kernel (front kind 2, mbconv_small_kernel): BN0's scale times log2(e) is folded into the expand weights
+            # BEFORE they are rounded to the storage type, its bias enters as the MFMA's C operand, the expanded tensor stays fp32
+            # (effnet.hip: build_weights).  t = log2(e) * BN0(expand); the device evaluates silu as (t / (1 + 2^-t)) * ln 2.
+            g64 = sd[p + '_bn0.weight'].double() / torch.sqrt(sd[p + '_bn0.running_var'].double() + 1e-3)
+            s0 = g64.float().double()
+            b0 = (sd[p + '_bn0.bias'].double() - sd[p + '_bn0.running_mean'].double() * g64).float().double()
+            L2E = 1.4426950408889634
+            We = R((sd[p + '_expand_conv.weight'].double() * (s0 * L2E)[:, None, None, None]).float())
+            t = self._conv(x, We, 1, 1) + (b0 * L2E).float()[None, :, None, None]
+            x = sw(t * 0.6931471805599453)
+        elif e != 1:
             x = sw(self._bn(self._conv(x, R(sd[p + '_expand_conv.weight']), 1, 1), p + '_bn0'))
-            if not fused:
+            if not fused:                                        # unfused blocks store the expanded tensor
                 x = R(x)
         d32 = sw(self._bn(self._conv(x, sd[p + '_depthwise_conv.weight'], k, s, groups=x.shape[1]), p + '_bn1'))
         q = d32.mean((2, 3), keepdim=True)
@@ -504,7 +517,8 @@ class TorchRef:
         return R(sw(self._bn(self._conv(x, R(self.sd['backbone._conv_head.weight']), 1, 1), 'backbone._bn1')))
 
     def extract_features_emulated(self, x, storage, fused, probes=None):
-        """x (B,6,H,W) fp32; storage 'bf16' | 'fp16'; fused[i] truthy = block i runs a fused front (E never stored).
+        """x (B,6,H,W) fp32; storage 'bf16' | 'fp16'; fused[i] = front kernel of block i as cosy_effnet_b3_block_info reports it
+        (0 unfused: E is stored; 1 wave, 2 small: E never stored).
         probes: dict filled with {-1: stem, i: block output, 100+i: D of block i, 200+i: gate (B,Cmid), 26: head}.
         NOTE: two evaluations of a 26-block network that round at every layer decorrelate with depth (a value one ulp apart
         perturbs the next layer's roundings), so the END-TO-END distance between this and the device grows to the size of
