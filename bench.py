@@ -318,7 +318,7 @@ def main():
         kinds = agg(lambda r: r['name'])
         fams = agg(lambda r: r['name'].split('<')[0].split('+')[0])
         total_ms = sum(k['ms'] for k in kinds.values())
-        n_fw = sum(r['n'] for r in recs if r['name'].startswith('stem_kernel'))      # forwards timed
+        n_fw = sum(r['n'] for r in recs if r['name'].startswith('stem_'))      # forwards timed
         if args.layers:
             per = agg(lambda r: (r['layer'], r['name']))
             for (layer, name), k in per.items():

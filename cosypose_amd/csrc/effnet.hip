@@ -57,7 +57,7 @@ static long param_count() {
 
 struct PwLayer { int K = 0, N = 0; PwCfg cfg{4, 2}; void* Wp = nullptr; float* scale = nullptr; float* bias = nullptr; };
 struct Block {
-    BlkDef d; int cmid, cse, H, W, Ho, Wo, pad_lo, n_tiles;
+    BlkDef d; int cmid, cse, H, W, Ho, Wo, pad_lo, n_tiles, dw_tiles;   // n_tiles: most partial-sum tiles per sample any front of this block writes (sizing); dw_tiles: dwconv_kernel's
     bool skip;
     bool wave;            // front = mbconv_wave_kernel (kernels_wave.hip)
     bool small;           // front = mbconv_small_kernel (whole-image kernel of the late blocks)
@@ -165,7 +165,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         b.H = h; b.W = w_; b.Ho = out_dim(h, b.d.k, b.d.s); b.Wo = out_dim(w_, b.d.k, b.d.s);
         int hi; static_pad(b.d.k, b.d.s, &b.pad_lo, &hi);
         b.skip = (b.d.s == 1 && b.d.cin == b.d.cout);  // id_skip, efficientnet.py:94
-        b.n_tiles = dw_num_tiles(b.cmid, b.Ho, b.Wo, b.d.k);
+        b.n_tiles = b.dw_tiles = dw_num_tiles(b.cmid, b.Ho, b.Wo, b.d.k);
         // fused fronts exist for the shapes of the two supported crop sizes (256x256, 240x320) in the 2-byte types; every other
         // shape (and fp32) runs the generic unfused kernels, which are shape-agnostic
         b.wave = n->fuse && b.d.e != 1 && ((n->wave_mask >> i) & 1) && wave_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
@@ -347,7 +347,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
     auto run_block = [&](int i, const void* in, void* out, int Bc, void* Ebuf, void* Dbuf, int b0) -> int {
         const Block& b = n->blk[i];
         const void* src = in;
-        int se_tiles = b.n_tiles;     // partial-sum tiles per sample the front kernel writes (the wave kernel decides per launch)
+        int se_tiles = b.fused ? b.n_tiles : b.dw_tiles;     // partial-sum tiles per sample the front kernel writes (the wave kernel decides per launch)
         if (b.fused) {
             FuseArgs f{};
             f.X = in; f.Wp = b.exp_wp_fused;
@@ -375,7 +375,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         d.B = Bc; d.H = b.H; d.W = b.W; d.C = b.cmid; d.Ho = b.Ho; d.Wo = b.Wo; d.k = b.d.k; d.s = b.d.s; d.pad_lo = b.pad_lo; d.zeros = n->zeros;
         if ((rc = launch_dwconv(d, n->dtype, s))) return rc;
         snprintf(kn, sizeof(kn), "dwconv_kernel<%s, %d, %d>", dt_name(n->dtype), b.d.k, b.d.s);
-        if ((rc = mark(kn, i, ((double)Bc * b.H * b.W * b.cmid + (double)Bc * b.Ho * b.Wo * b.cmid) * esz_d + (double)Bc * b.n_tiles * b.cmid * 4,
+        if ((rc = mark(kn, i, ((double)Bc * b.H * b.W * b.cmid + (double)Bc * b.Ho * b.Wo * b.cmid) * esz_d + (double)Bc * b.dw_tiles * b.cmid * 4,
                        2.0 * Bc * b.Ho * b.Wo * b.cmid * b.d.k * b.d.k))) return rc;
         }
 #ifdef COSY_TUNE
@@ -511,7 +511,9 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
         const int c = tune_int("COSY_EARLY_CHUNK", 0);   // measured: chunking the early segment is slower (kernels are issue-bound)
         n->chunk = c <= 0 ? max_batch : c;
         n->fuse = tune_int("COSY_FUSE", 1);
-        n->se_batch_from = tune_int("COSY_SE_BATCH_FROM", 19);
+        // measured (256 crops): batched from block 19: +1.5 %, from 9: another +1.1 % over one-workgroup-per-sample everywhere; the early
+        // blocks (Cmid <= 288, Cse <= 12) stay on se_kernel: two dependent launches cost what its one does
+        n->se_batch_from = tune_int("COSY_SE_BATCH_FROM", 9);
         n->small_mask = (unsigned)tune_int("COSY_SMALL_MASK", 0x3f80000);   // blocks 19-25 (8x8 / 7x10 maps): whole-image kernel
         n->wave_mask = (unsigned)tune_int("COSY_WAVE_MASK", 0x3fffc);   // blocks 2-17: maps 16..128 pixels wide, stride per shape table
         n->nstreams = tune_int("COSY_STREAMS", 1) == 2 && max_batch >= 32 ? 2 : 1;   // measured: 2 streams x half batches is ~10 % slower
