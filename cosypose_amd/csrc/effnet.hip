@@ -601,8 +601,11 @@ int cosy_effnet_b3_set_probe(cosy_net_t* n, int layer, float* out) {
 int cosy_effnet_b3_block_info(const cosy_net_t* n, int i, int* dims) {
     COSY_REQUIRE(n && dims && i >= 0 && i < 26, "block_info: bad arguments");
     const Block& b = n->blk[i];
-    const int v[10] = {b.H, b.W, b.Ho, b.Wo, b.d.cin, b.cmid, b.d.cout, b.wave ? 1 : b.small ? 2 : 0, b.d.k, b.d.s};
-    for (int q = 0; q < 10; ++q) dims[q] = v[q];
+    // where the project GEMM applies the squeeze-excite gate: to the weight fragments (maps of a multiple of 64 pixels: a wave's 64
+    // rows belong to one sample) or to the activation rows
+    const int gate_w = (b.Ho * b.Wo) % 64 == 0;
+    const int v[11] = {b.H, b.W, b.Ho, b.Wo, b.d.cin, b.cmid, b.d.cout, b.wave ? 1 : b.small ? 2 : 0, b.d.k, b.d.s, gate_w};
+    for (int q = 0; q < 11; ++q) dims[q] = v[q];
     return COSY_OK;
 }
 

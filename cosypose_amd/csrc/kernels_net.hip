@@ -419,6 +419,7 @@ void small_kernel_name(int Cin, int k, int s, int dtype, int H, int W, char* buf
 int launch_pw_gemm(const PwArgs& a, PwCfg cfg, int dtype, hipStream_t s) {
     if (a.M == 0) return COSY_OK;
     COSY_REQUIRE(a.K % 8 == 0 && a.N % 8 == 0, "pw_gemm: K=%d and N=%d must be multiples of 8", a.K, a.N);
+
     return COSY_DISPATCH_T(dtype, launch_pw_t<T>(a, cfg, dtype, s));
 }
 

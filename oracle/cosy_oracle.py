@@ -463,8 +463,10 @@ class TorchRef:
         sw = lambda t: t * self.torch.sigmoid(t)
         return R(sw(self._bn(self._conv(R(x), R(self.sd['backbone._conv_stem.weight']), 3, 2), 'backbone._bn0')))
 
-    def block_emulated(self, i, x, storage, fused):
-        """MBConv block i on a block input that is already in the storage type -> (D, gate (B,Cmid), block output)"""
+    def block_emulated(self, i, x, storage, fused, gate_on_weights=None):
+        """MBConv block i on a block input that is already in the storage type -> (D, gate (B,Cmid), block output).
+        gate_on_weights: where the device's project GEMM applies the SE gate (cosy_effnet_b3_block_info); default = the tile
+        kernel's rule (maps of a multiple of 64 pixels: weights, else activation rows)."""
         torch = self.torch; sd = self.sd
         R = lambda t: self._rnd(t, storage)
         sw = lambda t: t * torch.sigmoid(t)
@@ -494,7 +496,9 @@ class TorchRef:
         D = R(d32)
         W = R(sd[p + '_project_conv.weight'])[:, :, 0, 0]        # (Cout, Cmid)
         hw = D.shape[2] * D.shape[3]
-        if hw % 64 == 0:                                         # gate folded into the weight fragments, per sample
+        if gate_on_weights is None:
+            gate_on_weights = hw % 64 == 0
+        if gate_on_weights:                                      # gate folded into the weight fragments, per sample
             if storage == 'fp16':
                 Wg = (W.half()[None] * g.half()[:, None, :]).float()
             else:
@@ -516,7 +520,7 @@ class TorchRef:
         sw = lambda t: t * self.torch.sigmoid(t)
         return R(sw(self._bn(self._conv(x, R(self.sd['backbone._conv_head.weight']), 1, 1), 'backbone._bn1')))
 
-    def extract_features_emulated(self, x, storage, fused, probes=None):
+    def extract_features_emulated(self, x, storage, fused, probes=None, gate_w=None):
         """x (B,6,H,W) fp32; storage 'bf16' | 'fp16'; fused[i] = front kernel of block i as cosy_effnet_b3_block_info reports it
         (0 unfused: E is stored; 1 wave, 2 small: E never stored).
         probes: dict filled with {-1: stem, i: block output, 100+i: D of block i, 200+i: gate (B,Cmid), 26: head}.
@@ -528,17 +532,17 @@ class TorchRef:
         x = self.stem_emulated(x, storage)
         put(-1, x)
         for i in range(len(B3_BLOCKS)):
-            D, g, x = self.block_emulated(i, x, storage, fused[i])
+            D, g, x = self.block_emulated(i, x, storage, fused[i], None if gate_w is None else gate_w[i])
             put(100 + i, D); put(200 + i, g); put(i, x)
         x = self.head_emulated(x, storage)
         put(26, x)
         return x
 
-    def net_forward_emulated(self, x, storage, fused, probes=None):
+    def net_forward_emulated(self, x, storage, fused, probes=None, gate_w=None):
         torch = self.torch
         with torch.no_grad():
             x = torch.as_tensor(np.asarray(x, np.float32)) if not torch.is_tensor(x) else x
-            f = self.extract_features_emulated(x, storage, fused, probes).flatten(2).mean(-1)
+            f = self.extract_features_emulated(x, storage, fused, probes, gate_w).flatten(2).mean(-1)
             pose = torch.nn.functional.linear(f, self.sd['pose_fc.weight'], self.sd['pose_fc.bias'])
         return f.numpy(), pose.numpy()
 

@@ -181,7 +181,7 @@ def _block_plan(model, hw, dtype, B=2):
     h = model._net(B, torch.device('cuda'))
     plan = []
     for i in range(26):
-        dims = (ctypes.c_int * 10)()
+        dims = (ctypes.c_int * 11)()
         check(lib().cosy_effnet_b3_block_info(h, i, dims))
         plan.append(list(dims))
     return h, plan
@@ -247,8 +247,8 @@ def test_fused_kernels_vs_storage_emulation(model, oracle, golden_sd, dtype, hw)
     with torch.no_grad():
         cur = _probe(model, h, x, -1, (B, 40, Hs, Ws))
         compare('stem', cur, tr.stem_emulated(T(x), dtype))
-        for i, (H_, W_, Ho, Wo, cin, cmid, cout, kind, k, s_) in enumerate(plan):
-            D_e, g_e, y_e = tr.block_emulated(i, T(cur), dtype, kinds[i])
+        for i, (H_, W_, Ho, Wo, cin, cmid, cout, kind, k, s_, gate_w) in enumerate(plan):
+            D_e, g_e, y_e = tr.block_emulated(i, T(cur), dtype, kinds[i], bool(gate_w))
             compare(f'D{i}', _probe(model, h, x, 100 + i, (B, cmid, Ho, Wo)), D_e)
             compare(f'g{i}', _probe(model, h, x, 200 + i, (B, cmid)), g_e, gate=True)
             cur = _probe(model, h, x, i, (B, cout, Ho, Wo))
@@ -292,9 +292,9 @@ def test_unsupported_crop_size_fails_loudly(model):
     model.render_size = (240, 320)
 
 
-def _emulated_backbone(oracle, golden_sd, dtype, kinds):
+def _emulated_backbone(oracle, golden_sd, dtype, plan):
     tr = oracle.TorchRef(golden_sd)
-    return lambda x: tr.net_forward_emulated(x, dtype, kinds)
+    return lambda x: tr.net_forward_emulated(x, dtype, [p[7] for p in plan], gate_w=[bool(p[10]) for p in plan])
 
 
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
@@ -314,7 +314,7 @@ def test_refiner_loop_low_precision(model, oracle, golden, golden_sd, labels21, 
     got = out[f'iteration={n_it}']['TCO_output'].cpu().numpy()
     emu = oracle.pose_predictor_forward(images, K, obj, TCO, mesh_table, None,
                                         lambda n, T, Kc: syn.make_renders(seed * 1000 + n, B, 240, 320), n_iterations=n_it,
-                                        render_size=(240, 320), backbone=_emulated_backbone(oracle, golden_sd, dtype, [p[7] for p in plan]))
+                                        render_size=(240, 320), backbone=_emulated_backbone(oracle, golden_sd, dtype, plan))
     r_e, t_e = pose_errors(got, emu[f'iteration={n_it}']['TCO_output'])
     r_f, t_f = pose_errors(got, golden[f'fw_{name}_it{n_it}_TCO_output'])
     print(f'{dtype}: refined poses after {n_it} iterations: vs emulation R {r_e:.2e} t {t_e:.2e}; vs reference fp32 R {r_f:.2e} t {t_f:.2e}')
@@ -478,10 +478,9 @@ def test_headline_config_vs_oracle(model, oracle, golden_sd, mesh_table, labels2
     from cosypose_amd.pose_predictor import CoarseRefinePosePredictor
     obj, im, boxes, frames, K = _headline_case()
     det = tc.PandasTensorCollection(infos=pd.DataFrame(dict(label=labels21[obj], batch_im_id=im, score=1.0)), bboxes=dev(boxes))
-    kinds = None
+    plan = None
     if dtype != 'fp32':
         _, plan = _block_plan(model, (256, 256), dtype, 32)
-        kinds = [p[7] for p in plan]
     model.renderer = FakeRenderer(9000)
     model.compute_dtype = dtype
     model.render_size = (256, 256)
@@ -504,8 +503,8 @@ def test_headline_config_vs_oracle(model, oracle, golden_sd, mesh_table, labels2
     assert torch.equal(final.poses, allp['refiner/iteration=4'].poses)
     assert w['R'] < tol and w['t'] < tol and w['K_crop'] < tol
     assert w['boxes_rend'] < 10 * tol and w['boxes_crop'] < 10 * tol
-    if kinds is not None:
-        emu = _headline_oracle_loop(oracle, mesh_table, _emulated_backbone(oracle, golden_sd, dtype, kinds))
+    if plan is not None:
+        emu = _headline_oracle_loop(oracle, mesh_table, _emulated_backbone(oracle, golden_sd, dtype, plan))
         we = worst_vs(emu)
         print(f'headline config, {dtype} vs storage-emulating oracle: ' + ', '.join(f'{k} {v:.2e}' for k, v in we.items()))
         assert we['R'] < tol and we['t'] < tol and we['K_crop'] < tol      # informative: see test_refiner_loop_low_precision
