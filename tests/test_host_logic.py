@@ -253,3 +253,25 @@ def test_lr_schedule_matches_the_reference_scheduler_sequence():
     resumed = LRSchedule(1e-3, 2, 3, 2, start_epoch=5, faithful=False)
     assert [fresh.current(e, b) for e in range(5, 8) for b in range(3)] == [resumed.current(e, b) for e in range(5, 8) for b in range(3)]
     assert abs(fresh.current(1, 2) - 1e-3) < 1e-15 and abs(fresh.current(4, 0) - 1e-3 * 7 / 6 * 0.1) < 1e-15
+
+
+def test_add_noise_vs_reference_fixture():
+    """h_pose's pose-noise generators ('gt+noise', 'fixed+trans_noise'): cosypose_amd.pose_forward_loss.add_noise against the
+    outputs of the reference's own add_noise (cosypose/lib3d/transform_ops.py:35-51; tests/golden/generate_golden_noise.py binds
+    scipy's static-axes Euler rotation in place of the absent transforms3d), same numpy seed: same poses, and the same
+    number of RNG draws consumed."""
+    import numpy as np
+    import torch
+    from conftest import REPO
+    from cosypose_amd import synthetic as syn
+    from cosypose_amd.pose_forward_loss import add_noise
+    g = dict(np.load(REPO / 'tests' / 'golden' / 'reference_golden_noise.npz'))
+    for name in ('gt_noise', 'trans_only', 'one'):
+        seed, np_seed, B = (int(v) for v in g[f'{name}_seed'])
+        TCO = torch.from_numpy(syn.make_TCO(seed, B))
+        np.random.seed(np_seed)
+        out = add_noise(TCO, euler_deg_std=list(g[f'{name}_euler_std']), trans_std=list(g[f'{name}_trans_std']))
+        assert out.dtype == torch.float32 and tuple(out.shape) == (B, 4, 4)
+        np.testing.assert_allclose(out.numpy(), g[f'{name}_out'], rtol=0, atol=2e-7)
+        assert np.random.normal() == g[f'{name}_next_draw'][0]
+        assert torch.equal(out[:, 3], TCO[:, 3])
