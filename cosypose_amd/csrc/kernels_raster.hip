@@ -9,8 +9,9 @@
 //
 // Pipeline per call, all crops at once (meshes of a few 10^3..10^4 triangles, a few pixels each at crop resolution):
 //   1. project: one thread per (crop, vertex) -> (u, v, z_cam)
-//   2. z-buffer: one thread per (crop, triangle) walks the triangle's pixel bounding box; edge functions at pixel
-//      centres; 64-bit atomicMin of (depth bits << 32 | face id): order-independent, hence deterministic
+//   2. z-buffer: one thread per (crop, triangle) walks the triangle's pixel bounding box (boxes of more than 64 pixels are
+//      shared by the 64 lanes of the wave); edge functions at pixel centres; 64-bit atomicMin of (depth bits << 32 | face
+//      id): order-independent, hence deterministic
 //   3. resolve: one thread per pixel re-derives the barycentrics of the winning face, perspective-correct colour
 //      interpolation, Lambert term from the camera-space face normal, clamps, writes planar RGB (+ depth).
 // fp32 with contraction off: oracle/cosy_oracle.c:cosy_oracle_rasterize is the same arithmetic in scalar loops and the
@@ -54,41 +55,74 @@ __global__ __launch_bounds__(256) void raster_project_kernel(const float* __rest
     o[2] = c[2];
 }
 
+// one pixel of one triangle: edge functions at the pixel centre, perspective-correct depth, 64-bit atomicMin of (depth | face)
+__device__ __forceinline__ void raster_pixel(float ax, float ay, float az, float bx, float by, float bz, float cx, float cy, float cz,
+                                             float inv_area, int f, int x, int y, int W, unsigned long long* zb) {
+    const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+    const float w0 = edge_fn(bx, by, cx, cy, px, py) * inv_area;
+    const float w1 = edge_fn(cx, cy, ax, ay, px, py) * inv_area;
+    const float w2 = edge_fn(ax, ay, bx, by, px, py) * inv_area;
+    if (!(w0 >= 0.f && w1 >= 0.f && w2 >= 0.f)) return;
+    const float iz = (w0 / az + w1 / bz) + w2 / cz;
+    const float z = 1.f / iz;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned int)f;
+    atomicMin(zb + (size_t)y * W + x, key);
+}
+
+// Triangles whose pixel box holds more than BIG pixels are not walked by their own thread (one thread per triangle serialises
+// a coarse mesh: a cube that fills a 256x256 crop is 12 triangles of ~10^4 pixels each): the wave takes them one after the
+// other (ballot + readlane broadcast of the triangle) and its 64 lanes share the box.  Same per-pixel arithmetic, and the
+// z-buffer merge is an order-independent min: results are identical to the one-thread walk.
 __global__ __launch_bounds__(256) void raster_tri_kernel(const float* __restrict__ uvz, const int* __restrict__ faces,
                                                          const int* __restrict__ n_faces, const int* __restrict__ obj,
                                                          const float* __restrict__ TCO, const float* __restrict__ K, int V, int F, int H,
                                                          int W, unsigned long long* __restrict__ zbuf) {
-    const int b = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+    constexpr int BIG = 64;
+    const int b = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
     const int o = obj[b];
-    if (f >= n_faces[o]) return;
-    if (!pose_finite(TCO + (size_t)b * 16, K + (size_t)b * 9)) return;
-    const int* tri = faces + ((size_t)o * F + f) * 3;
-    const float* base = uvz + (size_t)b * V * 3;
-    const float ax = base[tri[0] * 3], ay = base[tri[0] * 3 + 1], az = base[tri[0] * 3 + 2];
-    const float bx = base[tri[1] * 3], by = base[tri[1] * 3 + 1], bz = base[tri[1] * 3 + 2];
-    const float cx = base[tri[2] * 3], cy = base[tri[2] * 3 + 1], cz = base[tri[2] * 3 + 2];
-    const float near = 0.01f;
-    if (!(az > near && bz > near && cz > near)) return;
-    const float area = edge_fn(ax, ay, bx, by, cx, cy);
-    if (area == 0.f || !isfinite(area)) return;
-    const float xmin = fminf(ax, fminf(bx, cx)), xmax = fmaxf(ax, fmaxf(bx, cx));
-    const float ymin = fminf(ay, fminf(by, cy)), ymax = fmaxf(ay, fmaxf(by, cy));
-    int x0 = (int)floorf(xmin - 0.5f), x1 = (int)ceilf(xmax - 0.5f), y0 = (int)floorf(ymin - 0.5f), y1 = (int)ceilf(ymax - 0.5f);
-    x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, W - 1); y1 = min(y1, H - 1);
-    const float inv_area = 1.f / area;
     unsigned long long* zb = zbuf + (size_t)b * H * W;
-    for (int y = y0; y <= y1; ++y)
-        for (int x = x0; x <= x1; ++x) {
-            const float px = (float)x + 0.5f, py = (float)y + 0.5f;
-            const float w0 = edge_fn(bx, by, cx, cy, px, py) * inv_area;
-            const float w1 = edge_fn(cx, cy, ax, ay, px, py) * inv_area;
-            const float w2 = edge_fn(ax, ay, bx, by, px, py) * inv_area;
-            if (!(w0 >= 0.f && w1 >= 0.f && w2 >= 0.f)) continue;
-            const float iz = (w0 / az + w1 / bz) + w2 / cz;
-            const float z = 1.f / iz;
-            const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned int)f;
-            atomicMin(zb + (size_t)y * W + x, key);
+    bool live = f < n_faces[o] && pose_finite(TCO + (size_t)b * 16, K + (size_t)b * 9);
+    float ax = 0.f, ay = 0.f, az = 1.f, bx = 0.f, by = 0.f, bz = 1.f, cx = 0.f, cy = 0.f, cz = 1.f, inv_area = 0.f;
+    int x0 = 0, x1 = -1, y0 = 0, y1 = -1;
+    if (live) {
+        const int* tri = faces + ((size_t)o * F + f) * 3;
+        const float* base = uvz + (size_t)b * V * 3;
+        ax = base[tri[0] * 3]; ay = base[tri[0] * 3 + 1]; az = base[tri[0] * 3 + 2];
+        bx = base[tri[1] * 3]; by = base[tri[1] * 3 + 1]; bz = base[tri[1] * 3 + 2];
+        cx = base[tri[2] * 3]; cy = base[tri[2] * 3 + 1]; cz = base[tri[2] * 3 + 2];
+        const float near = 0.01f;
+        const float area = edge_fn(ax, ay, bx, by, cx, cy);
+        live = (az > near && bz > near && cz > near) && !(area == 0.f || !isfinite(area));
+        if (live) {
+            const float xmin = fminf(ax, fminf(bx, cx)), xmax = fmaxf(ax, fmaxf(bx, cx));
+            const float ymin = fminf(ay, fminf(by, cy)), ymax = fmaxf(ay, fmaxf(by, cy));
+            x0 = max((int)floorf(xmin - 0.5f), 0); y0 = max((int)floorf(ymin - 0.5f), 0);
+            x1 = min((int)ceilf(xmax - 0.5f), W - 1); y1 = min((int)ceilf(ymax - 0.5f), H - 1);
+            inv_area = 1.f / area;
+            live = x1 >= x0 && y1 >= y0;
         }
+    }
+    const bool big = live && (long)(x1 - x0 + 1) * (y1 - y0 + 1) > BIG;
+    if (live && !big) {
+        for (int y = y0; y <= y1; ++y)
+            for (int x = x0; x <= x1; ++x) raster_pixel(ax, ay, az, bx, by, bz, cx, cy, cz, inv_area, f, x, y, W, zb);
+    }
+    unsigned long long todo = __ballot(big);
+    while (todo) {                                   // wave-uniform loop over the wave's big triangles
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        auto bc = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); };
+        const float tax = bc(ax), tay = bc(ay), taz = bc(az), tbx = bc(bx), tby = bc(by), tbz = bc(bz), tcx = bc(cx), tcy = bc(cy), tcz = bc(cz);
+        const float tinv = bc(inv_area);
+        const int tx0 = __builtin_amdgcn_readlane(x0, src), tx1 = __builtin_amdgcn_readlane(x1, src);
+        const int ty0 = __builtin_amdgcn_readlane(y0, src), ty1 = __builtin_amdgcn_readlane(y1, src);
+        const int tf = __builtin_amdgcn_readlane(f, src);
+        const int bw = tx1 - tx0 + 1, npx = bw * (ty1 - ty0 + 1);
+        for (int i = lane; i < npx; i += 64) {
+            const int yy = i / bw, xx = i - yy * bw;
+            raster_pixel(tax, tay, taz, tbx, tby, tbz, tcx, tcy, tcz, tinv, tf, tx0 + xx, ty0 + yy, W, zb);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void raster_resolve_kernel(const unsigned long long* __restrict__ zbuf, const float* __restrict__ uvz,

@@ -939,6 +939,51 @@ def test_rasteriser_vs_cpu_twin_and_geometry(oracle):
     assert np.array_equal(again, rgb[:2])
 
 
+def test_rasteriser_large_triangles_vs_cpu_twin(oracle):
+    """coarse meshes close to the camera: boxes (12 triangles of up to ~2*10^4 pixels each) and an 8-triangle octahedron -- the
+    z-buffer pass hands pixel boxes of more than 64 pixels to the whole wave; depth / winning faces / colours must equal the
+    scalar CPU twin's pixel for pixel, mixed with fine meshes in the same batch (both paths inside one wave), and the pass must
+    not serialise (one thread walking such a triangle alone took milliseconds per crop)."""
+    import time
+    from cosypose_amd.rasterizer import RenderMeshes, HipBatchRenderer
+    rs = np.random.RandomState(5)
+
+    def box(ex, ey, ez):
+        v = np.array([[sx * ex, sy * ey, sz * ez] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], np.float32)
+        f = np.array([[0, 1, 3], [0, 3, 2], [4, 6, 7], [4, 7, 5], [0, 4, 5], [0, 5, 1], [2, 3, 7], [2, 7, 6], [0, 2, 6], [0, 6, 4],
+                      [1, 5, 7], [1, 7, 3]], np.int32)
+        return v, f
+    octa_v = np.array([[0.1, 0, 0], [-0.1, 0, 0], [0, 0.08, 0], [0, -0.08, 0], [0, 0, 0.12], [0, 0, -0.12]], np.float32)
+    octa_f = np.array([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]], np.int32)
+    fv, ff, fc = syn.make_render_meshes(7, 1)
+    verts = [box(0.1, 0.08, 0.06)[0], box(0.05, 0.12, 0.09)[0], octa_v, fv[0]]
+    faces = [box(1, 1, 1)[1], box(1, 1, 1)[1], octa_f, ff[0]]
+    colors = [rs.uniform(0.2, 1.0, (len(v), 3)).astype(np.float32) for v in verts[:3]] + [fc[0]]
+    labels = np.array(['box_a', 'box_b', 'octa', 'fine'])
+    meshes = RenderMeshes(labels, verts, faces, colors).cuda()
+    renderer = HipBatchRenderer(meshes)
+    B, H, W = 16, 256, 256
+    obj = (np.arange(B) % 4).astype(np.int32)
+    TCO = syn.make_TCO(21, B, z_range=(0.25, 0.5), xy=0.03)
+    K = np.tile(np.array([[600., 0, 128.0], [0, 600., 128.0], [0, 0, 1]], np.float32), (B, 1, 1))
+    infos = [dict(name=labels[o]) for o in obj]
+    rgb, depth = renderer.render(infos, dev(TCO), dev(K), resolution=(H, W), render_depth=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        renderer.render(infos, dev(TCO), dev(K), resolution=(H, W))
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    rgb, depth = rgb.cpu().numpy(), depth.cpu().numpy()
+    r_o, d_o, zb = oracle.rasterize(meshes.verts.cpu().numpy(), meshes.colors.cpu().numpy(), meshes.faces.cpu().numpy(),
+                                    meshes.n_faces.cpu().numpy(), obj, TCO, K, H, W)
+    assert np.array_equal(depth, d_o) and np.abs(rgb - r_o).max() < 1e-6
+    cover = (depth > 0).reshape(B, -1).mean(1)
+    print(f'large-triangle batch: coverage per crop {cover.min():.2f}..{cover.max():.2f}, {ms:.2f} ms per 16-crop render')
+    assert cover[obj < 3].min() > 0.15           # the coarse objects do fill a good part of their crop
+    assert ms < 5.0                               # 16 crops of 256x256: ~0.2 ms; one thread per big triangle took > 20 ms
+
+
 def _textured_setup(n_obj=4, shading='opengl'):
     """meshes with spherical texture coordinates and a procedural texture per object"""
     from cosypose_amd.rasterizer import RenderMeshes, HipBatchRenderer
