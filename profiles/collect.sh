@@ -10,17 +10,20 @@ TAG=${1:-run}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-profile $*"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-other-dtypes $*"
 rocprofv3 -M --kernel-trace --stats -f csv -d $OUT/stats -o t -- python bench.py $ARGS > $OUT/bench_stats.json 2> $OUT/stats.err
 pass() { # name counters...
   local name=$1; shift
   rocprofv3 -M --kernel-trace --pmc "$@" -f csv -d $OUT/pmc_$name -o t -- python bench.py $ARGS > /dev/null 2> $OUT/pmc_$name.err || echo "pmc pass $name failed"
 }
 pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE
-pass sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES
+pass sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_BUSY_CU_CYCLES
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
-pass mfma MfmaUtil SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES
+pass mfma MfmaUtil SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr TA_TOTAL_WAVEFRONTS_sum
+# the collectives through RCCL on this one GPU (forced 1-rank group): the all-gather of the refined poses shows up as RCCL kernels
+COSY_FORCE_DIST=1 rocprofv3 -M --kernel-trace --stats -f csv -d $OUT/rccl -o t -- python bench.py $ARGS > $OUT/bench_rccl.json 2> $OUT/rccl.err
+grep -i -E "nccl|rccl|Name" $OUT/rccl/*/*kernel_stats.csv 2>/dev/null | head -20 > $OUT/rccl_kernels.csv
 python profiles/summarize.py $OUT > $OUT/summary.txt 2>&1
 tail -60 $OUT/summary.txt

@@ -63,18 +63,21 @@ def main(root):
     for fn in sorted(os.listdir(d)):
         h.update(fn.encode()); h.update(open(os.path.join(d, fn), 'rb').read())
     # csrc_sha ties the numbers to the kernel sources they were measured on (bench.py reports `traffic` only on a match)
-    json.dump(dict(csrc_sha=h.hexdigest()[:16], kernels=traffic), open(f'{root}/pmc_traffic.json', 'w'), indent=1)
+    json.dump(dict(csrc_sha=h.hexdigest()[:16], dtype=os.environ.get('COSY_PROFILE_DTYPE', 'fp16'), kernels=traffic), open(f'{root}/pmc_traffic.json', 'w'), indent=1)
     # matrix-core utilisation per kernel: rocprofv3's MfmaUtil (= sum SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * #SIMD), percent)
-    # and the MFMA FLOP rate from SQ_INSTS_VALU_MFMA_MOPS_BF16 * 512 over the kernel's mean duration
+    # and the MFMA FLOP rate from SQ_INSTS_VALU_MFMA_MOPS_{F16,BF16} * 512 over the kernel's mean duration
     mf = defaultdict(lambda: defaultdict(list))
     for (k, g), c in ctr.items():
-        for n in ('MfmaUtil', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_VALU_MFMA_MOPS_BF16'):
+        for n in ('MfmaUtil', 'SQ_VALU_MFMA_BUSY_CYCLES'):
             mf[k][n] += c.get(n, [])
+        # MFMA op counters of the 16-bit types (the headline runs fp16, the bf16 line beside it bf16): whichever the kernel used
+        a16, b16 = c.get('SQ_INSTS_VALU_MFMA_MOPS_F16', []), c.get('SQ_INSTS_VALU_MFMA_MOPS_BF16', [])
+        mf[k]['MOPS'] += [x + y for x, y in zip(a16, b16)] if a16 and b16 else (a16 or b16)
     rows = []
     for k, v in mf.items():
-        if v['MfmaUtil'] and bykern[k][1] and sum(v['SQ_INSTS_VALU_MFMA_MOPS_BF16']) > 0:
+        if v['MfmaUtil'] and bykern[k][1] and sum(v['MOPS']) > 0:
             t_us = bykern[k][0] / bykern[k][1]
-            mops = sum(v['SQ_INSTS_VALU_MFMA_MOPS_BF16']) / len(v['SQ_INSTS_VALU_MFMA_MOPS_BF16'])
+            mops = sum(v['MOPS']) / len(v['MOPS'])
             rows.append((sum(v['MfmaUtil']) / len(v['MfmaUtil']), mops * 512 / (t_us * 1e-6) / 1e12, t_us, k))
     if rows:
         print('== matrix-core utilisation per kernel (PMC pass `mfma`): MfmaUtil %, MFMA TFLOP/s issued, avg us')

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Batch sweep table: for 256..2048 crops per forward, the headline throughput and, per GEMM-like
 kernel, mean duration, matrix-core utilisation (rocprofv3 MfmaUtil) and the MFMA FLOP rate issued
-(SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512 / duration).  Input: the directory profiles/collect_all.sh writes."""
+(SQ_INSTS_VALU_MFMA_MOPS_{F16,BF16} x 512 / duration).  Input: the directory profiles/collect_all.sh writes."""
 import csv
 import glob
 import json
@@ -30,7 +30,7 @@ def main(root):
                 k = short(r['Kernel_Name'])
                 if r['Counter_Name'] == 'MfmaUtil':
                     util[k].append(float(r['Counter_Value']))
-                elif r['Counter_Name'] == 'SQ_INSTS_VALU_MFMA_MOPS_BF16':
+                elif r['Counter_Name'] in ('SQ_INSTS_VALU_MFMA_MOPS_BF16', 'SQ_INSTS_VALU_MFMA_MOPS_F16'):
                     mops[k].append(float(r['Counter_Value']))
         for k in dur:
             if util.get(k) and mops.get(k) and sum(mops[k]) > 0:
