@@ -328,12 +328,11 @@ static int launch_pw_dma_mi(PwKArgs k, hipStream_t s) {
     k.nsamp = k.rowgate ? pw_gate_nsamp(16 * MI * WM, k.HW) : 2;
     const size_t lds = (size_t)NS * NB * 1024 + 1024 + (GATE ? (size_t)k.nsamp * k.nkb_total * DT<T>::KB * 4 : 0);
     COSY_REQUIRE(lds <= 160 * 1024, "pw_gemm_dma: the gate rows of %d samples x K=%d do not fit the LDS (map of %d pixels too small)", k.nsamp, k.K, k.HW);
-    static bool attr_set = false;
-    if (!attr_set) {
-        COSY_CHECK_HIP(hipFuncSetAttribute((const void*)pw_gemm_dma_kernel<T, NI, WN, NS, GATE, MI, NWV>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    // once per instantiation and process, race-free: function-local statics are initialised exactly once (C++11), also when two
+    // nets launch from two threads at the same time (the header promises thread-safety across distinct nets / streams)
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)pw_gemm_dma_kernel<T, NI, WN, NS, GATE, MI, NWV>,
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    COSY_CHECK_HIP(attr_rc);
     hipLaunchKernelGGL((pw_gemm_dma_kernel<T, NI, WN, NS, GATE, MI, NWV>), dim3(grid), dim3(NWV * 64), lds, s, k);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
@@ -894,14 +893,12 @@ static bool fuse_small_rowmap(int Ho, int Wo, int threads) {
 template <typename T, int KS, int KBN>
 static int launch_fuse_small_m(const FuseSmallPlan& p, const FuseSKArgs& k, int B, hipStream_t s) {
     const dim3 grid((unsigned)(B * k.ncg)), block(p.threads);
-    static bool attr_set = false;
-    if (!attr_set) {
-        COSY_CHECK_HIP(hipFuncSetAttribute((const void*)mbconv_small_kernel<T, KS, 1, 4, KBN, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024));
-        COSY_CHECK_HIP(hipFuncSetAttribute((const void*)mbconv_small_kernel<T, KS, 1, 4, KBN, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024));
-        attr_set = true;
-    }
+    static const hipError_t attr_rc0 = hipFuncSetAttribute((const void*)mbconv_small_kernel<T, KS, 1, 4, KBN, 1, false>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static const hipError_t attr_rc1 = hipFuncSetAttribute((const void*)mbconv_small_kernel<T, KS, 1, 4, KBN, 1, true>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    COSY_CHECK_HIP(attr_rc0);
+    COSY_CHECK_HIP(attr_rc1);
     if (fuse_small_rowmap(k.Ho, k.Wo, p.threads)) hipLaunchKernelGGL((mbconv_small_kernel<T, KS, 1, 4, KBN, 1, true>), grid, block, p.lds, s, k);
     else hipLaunchKernelGGL((mbconv_small_kernel<T, KS, 1, 4, KBN, 1, false>), grid, block, p.lds, s, k);
     COSY_CHECK_HIP(hipGetLastError());

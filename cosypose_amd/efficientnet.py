@@ -5,8 +5,9 @@ Drop-in for `EfficientNet.from_name('efficientnet-b3', in_channels=6)`
 (cosypose/models/efficientnet.py:206-210): `load_state_dict` accepts reference checkpoints
 unchanged (`_conv_stem.weight`, `_bn0.*`, `_blocks.{i}._{expand_conv,bn0,depthwise_conv,bn1,
 se_reduce,se_expand,project_conv,bn2}.*`, `_conv_head.weight`, `_bn1.*`), `forward(x)`
-returns the (B,1536,h,w) feature map.  Inference (eval mode) only: training-mode batch-norm
-and drop_connect are out of scope for this round.
+returns the (B,1536,h,w) feature map.  This module's forward is the inference (eval-mode) engine; the
+train-mode network (batch-statistics BatchNorm, drop_connect, backward: SURVEY 8a-13) runs through
+cosypose_amd.train_engine on the same parameters.
 """
 import ctypes
 

@@ -6,7 +6,7 @@ Reference: MBConvBlock.forward / EfficientNet.extract_features in train mode (co
 (training/train_pose.py:317-331: backward, clip_grad_norm_(0.5), Adam) and DDP's gradient averaging.
 
 Design: fp32, activations NHWC (rows = pixels, so every 1x1 convolution and its two gradients are plain row-major
-GEMMs -> rocBLAS through torch.mm); everything else -- BatchNorm statistics / apply / backward with the Swish fused
+GEMMs -> the library's own fp32 MFMA kernels, cosy_train_gemm / cosy_wgrad); everything else -- BatchNorm statistics / apply / backward with the Swish fused
 in, depthwise forward / data / weight gradients, squeeze-excite scaling and its gradients, pooling, the stem's
 im2col, the loss gradient, gradient norm + clip + Adam on flat buffers -- is hand-written HIP in
 csrc/kernels_train.hip behind the C ABI.  The whole network is ONE autograd node (`backbone_train`): its backward

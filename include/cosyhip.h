@@ -184,8 +184,9 @@ int cosy_dists_add(const float* TXO_pred, const float* TXO_gt, const float* pts_
                    int symmetric, float* dists, cosy_stream_t stream);
 
 /* ---- training step of the refiner network, fp32, activations NHWC = rows x channels --------------
- * The 1x1 convolutions / linear layers and their gradients are plain GEMMs run by the host side (rocBLAS); these
- * entry points are everything else of cosypose/training/train_pose.py:317-331's step.  `workspace` is a device buffer
+ * Every piece of cosypose/training/train_pose.py:317-331's step: the 1x1 convolutions and their gradients on the library's own
+ * fp32 MFMA GEMMs (cosy_train_gemm / cosy_wgrad below), BatchNorm, depthwise, squeeze-excite scaling, loss gradient, clip +
+ * Adam; only the 64-row squeeze-excite / pose FCs are left to the host side (torch.addmm, 1.3 ms of a 43 ms step).  `workspace` is a device buffer
  * of cosy_train_workspace_bytes() bytes shared by the reductions (deterministic two-stage sums, no atomics). */
 size_t cosy_train_workspace_bytes(void);
 /* crop + render pack (as cosy_crop_pack) into a caller-owned NHWC8 buffer of element type `dtype` */

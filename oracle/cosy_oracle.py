@@ -24,15 +24,21 @@ _SO = os.path.join(_HERE, '_build', 'libcosy_oracle.so')
 _SRC = os.path.join(_HERE, 'cosy_oracle.c')
 
 
-def build(force=False):
-    """gcc-compile the C restatement into oracle/_build/ (idempotent)."""
-    if not force and os.path.exists(_SO) and os.path.getmtime(_SO) >= os.path.getmtime(_SRC):
-        return _SO
-    os.makedirs(os.path.dirname(_SO), exist_ok=True)
-    cmd = ['gcc', '-O3', '-march=x86-64-v2', '-fopenmp', '-fPIC', '-shared', '-fno-fast-math',
-           '-ffp-contract=off', '-o', _SO, _SRC, '-lm']
+_SO_SAN = os.path.join(os.path.dirname(_SO), 'libcosy_oracle_san.so')
+
+
+def build(force=False, sanitize=False):
+    """gcc-compile the C restatement into oracle/_build/ (idempotent).  sanitize=True: the AddressSanitizer +
+    UndefinedBehaviorSanitizer build (tests/test_oracle_sanitizers.py runs the golden tests on it in a subprocess with libasan
+    preloaded; COSY_ORACLE_SANITIZE=1 makes lib() load it)."""
+    so = _SO_SAN if sanitize else _SO
+    if not force and os.path.exists(so) and os.path.getmtime(so) >= os.path.getmtime(_SRC):
+        return so
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    opt = ['-O1', '-g', '-fno-omit-frame-pointer', '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined'] if sanitize else ['-O3']
+    cmd = ['gcc'] + opt + ['-march=x86-64-v2', '-fopenmp', '-fPIC', '-shared', '-fno-fast-math', '-ffp-contract=off', '-o', so, _SRC, '-lm']
     subprocess.check_call(cmd)
-    return _SO
+    return so
 
 
 _lib = None
@@ -41,9 +47,9 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
-            build()
-        _lib = ctypes.CDLL(_SO)
+        san = os.environ.get('COSY_ORACLE_SANITIZE') == '1'
+        so = build(sanitize=san)
+        _lib = ctypes.CDLL(so)
         _lib.cosy_oracle_b3_param_count.restype = ctypes.c_long
         _lib.cosy_oracle_b3_forward.restype = ctypes.c_int
         _lib.cosy_oracle_scatter_argmin.restype = ctypes.c_int
