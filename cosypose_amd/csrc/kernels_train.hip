@@ -29,7 +29,8 @@ struct RedGeom { int cgroups, nslab, rows_per_slab; };
 RedGeom red_geom(long M, int C) {
     RedGeom g;
     g.cgroups = cdiv(C, 64);
-    long cap = 4096 / g.cgroups;               // up to ~4096 workgroups per reduction (16 waves/CU); the combine pass is parallel
+    static const int red_cap = tune_int("COSY_RED_CAP", 1024);
+    long cap = red_cap / g.cgroups;            // up to ~1024 workgroups per reduction: more slabs only lengthen the combine pass (4096: 12.9 us per combine, 1024: 6.7 us, first stage unchanged)
     if (cap < 8) cap = 8;
     long nslab = cdiv(M, 128);
     if (nslab > cap) nslab = cap;
@@ -59,36 +60,47 @@ __device__ __forceinline__ void slab_write(const double* acc, double* lds /*[4][
 // ------------------------------------------------------------------------------------------
 // BatchNorm, training mode
 // ------------------------------------------------------------------------------------------
+// Row-slab reductions of the BatchNorm kernels.  A workgroup covers 64 channels x one slab of rows as 16 channel quads x 16 row
+// lanes: every lane issues 16-byte loads (a row's 64 channels = 256 contiguous bytes over 16 lanes), four independent rows in
+// flight per lane, double accumulators per channel; the 16 row lanes of a channel are combined through LDS in a fixed order
+// (deterministic).  (Round 2's form -- lane = channel, 4-byte loads, one row per iteration -- ran at 2.5-3.1 TB/s.)
+template <int NQ>
+__device__ __forceinline__ void slab_write_quads(const double (*acc)[NQ] /*[4 channels][NQ]*/, double* lds /*[16][16][4][NQ]*/, double* partial,
+                                                 int slab, int C, int cbase) {
+    const int tid = threadIdx.x, cq = tid & 15, rs = tid >> 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) lds[((rs * 16 + cq) * 4 + k) * NQ + q] = acc[k][q];
+    __syncthreads();
+    if (tid < 64 && cbase + tid < C) {
+        const int cq2 = tid >> 2, k = tid & 3;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            double v = 0.;
+            for (int r = 0; r < 16; ++r) v += lds[((r * 16 + cq2) * 4 + k) * NQ + q];
+            partial[((size_t)slab * NQ + q) * C + cbase + tid] = v;
+        }
+    }
+}
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long M, int C, int rows_per_slab,
                                                        double* __restrict__ partial) {
-    __shared__ double lds[4 * 64 * 2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane, slab = blockIdx.y;
+    __shared__ double lds[16 * 16 * 4 * 2];
+    const int tid = threadIdx.x, cq = tid & 15, rs = tid >> 4;
+    const int cbase = blockIdx.x * 64, c0 = cbase + cq * 4, slab = blockIdx.y;
     const long r0 = (long)slab * rows_per_slab, r1 = min(M, r0 + rows_per_slab);
-    double acc[2] = {0., 0.};
-    if (c < C)
-        for (long r = r0 + wave; r < r1; r += 4) {
-            const double v = x[r * C + c];
-            acc[0] += v; acc[1] += v * v;
+    double acc[4][2] = {{0., 0.}, {0., 0.}, {0., 0.}, {0., 0.}};
+    if (c0 < C)
+        for (long r = r0 + rs; r < r1; r += 64) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = r + 16 * u < r1 ? *(const f32x4*)(x + (r + 16 * u) * C + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const double d = v[u][k]; acc[k][0] += d; acc[k][1] += d * d; }
         }
-    slab_write<2>(acc, lds, partial, slab, C, c);
-}
-__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ sums /*[2][C]*/, long M, int C, float eps,
-                                                             float momentum, float* __restrict__ mean, float* __restrict__ rstd,
-                                                             float* __restrict__ running_mean, float* __restrict__ running_var) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const double s = sums[c], ss = sums[C + c];
-    const double m = s / (double)M;
-    double var = ss / (double)M - m * m;
-    if (var < 0.) var = 0.;
-    mean[c] = (float)m;
-    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {   // nn.BatchNorm2d: running <- (1-mom) running + mom batch; the variance unbiased
-        const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
-        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
-        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
-    }
+    slab_write_quads<2>(acc, lds, partial, slab, C, cbase);
 }
 
 // out = act(bn(x)) [* rowscale[b]] [+ res];  act: 0 none, 1 swish.  Vectorised over 4 channels.
@@ -130,26 +142,35 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, long M,
                                                             int C, int act, const float* __restrict__ rowscale, int HW,
                                                             int rows_per_slab, double* __restrict__ partial) {
-    __shared__ double lds[4 * 64 * 2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane, slab = blockIdx.y;
+    __shared__ double lds[16 * 16 * 4 * 2];
+    const int tid = threadIdx.x, cq = tid & 15, rs = tid >> 4;
+    const int cbase = blockIdx.x * 64, c0 = cbase + cq * 4, slab = blockIdx.y;
     const long r0 = (long)slab * rows_per_slab, r1 = min(M, r0 + rows_per_slab);
-    double acc[2] = {0., 0.};
-    if (c < C) {
-        const float m = mean[c], rs_ = rstd[c], g = gamma[c], b = beta[c];
-        for (long r = r0 + wave; r < r1; r += 4) {
-            const float xhat = (x[r * C + c] - m) * rs_;
-            const float d = bn_dy(dout[r * C + c], xhat, g, b, act, rowscale ? rowscale[r / HW] : 1.f);
-            acc[0] += d; acc[1] += (double)d * xhat;
+    double acc[4][2] = {{0., 0.}, {0., 0.}, {0., 0.}, {0., 0.}};
+    if (c0 < C) {
+        const f32x4 m = *(const f32x4*)(mean + c0), rs_ = *(const f32x4*)(rstd + c0), g = *(const f32x4*)(gamma + c0), b = *(const f32x4*)(beta + c0);
+        for (long r = r0 + rs; r < r1; r += 64) {
+            f32x4 xv[4], dv[4];
+            float sc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long rr = r + 16 * u;
+                const bool ok = rr < r1;
+                xv[u] = ok ? *(const f32x4*)(x + rr * C + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+                dv[u] = ok ? *(const f32x4*)(dout + rr * C + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+                sc[u] = !ok ? 0.f : (rowscale ? rowscale[rr / HW] : 1.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float xhat = (xv[u][k] - m[k]) * rs_[k];
+                    const float d = bn_dy(dv[u][k], xhat, g[k], b[k], act, sc[u]);
+                    acc[k][0] += d; acc[k][1] += (double)d * xhat;
+                }
         }
     }
-    slab_write<2>(acc, lds, partial, slab, C, c);
-}
-__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ sums /*[2][C]: sum dy, sum dy*xhat*/, int C,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    if (accumulate) { dbeta[c] += sums[c]; dgamma[c] += sums[C + c]; } else { dbeta[c] = sums[c]; dgamma[c] = sums[C + c]; }
+    slab_write_quads<2>(acc, lds, partial, slab, C, cbase);
 }
 // dx = gamma * rstd * (dy - sum(dy)/M - xhat * sum(dy*xhat)/M); sum_dy / sum_dyx are THIS call's sums (not accumulated grads)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ x,
@@ -178,29 +199,53 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------
 // depthwise convolution (static "same" padding: lo = pad before), weights as (k*k, C)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wt, int H, int W, int C4,
-                                                     int Ho, int Wo, int k, int s, int lo, long n4, float* __restrict__ out) {
+// Depthwise correlation with a register sliding window (forward at both strides; data gradient at stride 1: 22 of the 26 blocks).  A thread owns 4 channels x one column x
+// R consecutive rows: per tap column it walks the R + K - 1 input rows ONCE and feeds up to K accumulators, so it issues
+// K * (R + K - 1) 16-byte loads instead of R * K * K (K = 5: 40 instead of 100), with compile-time taps and no per-tap bounds
+// arithmetic.  FLIP = the data gradient: dx = dy (*) flipped taps with padding K - 1 - lo (for the symmetric "same" padding of
+// stride 1 that is lo again).  Sums run in a fixed order (kx outer, rows inner): deterministic.
+template <int K, int S, bool FLIP>
+__global__ __launch_bounds__(256) void dw_rows_kernel(const float* __restrict__ x, const float* __restrict__ wt, int H, int W, int Ho, int Wo, int C4,
+                                                      long n, float* __restrict__ out) {
+    static_assert(!FLIP || S == 1, "the data-gradient form is stride 1 only");
+    constexpr int R = 4, LO = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
+    if (i >= n) return;
     const int c4 = (int)(i % C4);
     long p = i / C4;
     const int ox = (int)(p % Wo); p /= Wo;
-    const int oy = (int)(p % Ho);
-    const long b = p / Ho;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int ky = 0; ky < k; ++ky) {
-        const int iy = oy * s - lo + ky;
-        if (iy < 0 || iy >= H) continue;
-        for (int kx = 0; kx < k; ++kx) {
-            const int ix = ox * s - lo + kx;
-            if (ix < 0 || ix >= W) continue;
-            const f32x4 v = ((const f32x4*)x)[((b * H + iy) * W + ix) * C4 + c4];
-            const f32x4 w = ((const f32x4*)wt)[(size_t)(ky * k + kx) * C4 + c4];
+    const int nyq = (Ho + R - 1) / R;
+    const int oy0 = (int)(p % nyq) * R;
+    const long b = p / nyq;
+    const f32x4* xb = (const f32x4*)x + (size_t)b * H * W * C4 + c4;
+    f32x4 acc[R];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] += v[q] * w[q];
+    for (int r = 0; r < R; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+        const int ix = ox * S - LO + kx;
+        if (ix < 0 || ix >= W) continue;
+        f32x4 w[K];
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int tap = FLIP ? (K - 1 - ky) * K + (K - 1 - kx) : ky * K + kx;
+            w[ky] = ((const f32x4*)wt)[(size_t)tap * C4 + c4];
+        }
+#pragma unroll
+        for (int rr = 0; rr < (R - 1) * S + K; ++rr) {
+            const int iy = oy0 * S - LO + rr;
+            if (iy < 0 || iy >= H) continue;
+            const f32x4 v = xb[((size_t)iy * W + ix) * C4];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int ky = rr - r * S;
+                if (ky >= 0 && ky < K) acc[r] += w[ky] * v;
+            }
         }
     }
-    ((f32x4*)out)[i] = acc;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (oy0 + r < Ho) ((f32x4*)out)[(((size_t)b * Ho + oy0 + r) * Wo + ox) * C4 + c4] = acc[r];
 }
 __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ wt, int H, int W, int C4,
                                                           int Ho, int Wo, int k, int s, int lo, long n4, float* __restrict__ dx) {
@@ -212,14 +257,15 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restric
     const int iy = (int)(p % H);
     const long b = p / H;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int ky = 0; ky < k; ++ky) {
+    // only the taps whose parity matches contribute (ty = iy + lo - ky must be a multiple of s): step through those directly
+    for (int ky = (iy + lo) % s; ky < k; ky += s) {
         const int ty = iy + lo - ky;
-        if (ty < 0 || ty % s) continue;
+        if (ty < 0) break;
         const int oy = ty / s;
         if (oy >= Ho) continue;
-        for (int kx = 0; kx < k; ++kx) {
+        for (int kx = (ix + lo) % s; kx < k; kx += s) {
             const int tx = ix + lo - kx;
-            if (tx < 0 || tx % s) continue;
+            if (tx < 0) break;
             const int ox = tx / s;
             if (ox >= Wo) continue;
             const f32x4 v = ((const f32x4*)dy)[((b * Ho + oy) * Wo + ox) * C4 + c4];
@@ -237,36 +283,40 @@ template <int K, int S>
 __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy, int H, int W, int C,
                                                             int Ho, int Wo, int lo, long nunits, int units_per_slab,
                                                             double* __restrict__ partial) {
-    constexpr int KK = K * K, RUN = 8, XS = (RUN - 1) * S + K;
-    __shared__ double lds[4 * 64 * KK];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane, slab = blockIdx.y;
+    // A workgroup covers 64 channels x one slab of units (unit = a run of RUN output pixels of one row) as 16 channel quads x 16
+    // unit lanes: 16-byte loads (a pixel's 64 channels = 256 contiguous bytes over 16 lanes), K*K x 4 register accumulators per
+    // lane, sliding window along x so each input row is loaded once per tap row.  (Round 2: lane = channel, 4-byte loads.)
+    // The 16 unit lanes of a quad are combined with two xor-shuffles inside the wave and a fixed-order LDS pass over the 4 waves.
+    constexpr int KK = K * K, RUN = 4, XS = (RUN - 1) * S + K;
+    __shared__ float lds[4 * 16 * 4 * KK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cq = lane & 15, us = wave * 4 + (lane >> 4);
+    const int cbase = blockIdx.x * 64, c0 = cbase + cq * 4, slab = blockIdx.y;
     const long u0 = (long)slab * units_per_slab, u1 = min(nunits, u0 + units_per_slab);
     const int runs = (Wo + RUN - 1) / RUN;
-    float acc[KK];
+    f32x4 acc[KK];
 #pragma unroll
-    for (int q = 0; q < KK; ++q) acc[q] = 0.f;
-    if (c < C)
-        for (long u = u0 + wave; u < u1; u += 4) {
+    for (int q = 0; q < KK; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c0 < C)
+        for (long u = u0 + us; u < u1; u += 16) {
             const int run = (int)(u % runs);
             const long t = u / runs;
             const int oy = (int)(t % Ho);
             const long b = t / Ho;
             const int ox0 = run * RUN;
-            float d[RUN];
+            f32x4 d[RUN];
 #pragma unroll
-            for (int j = 0; j < RUN; ++j) d[j] = ox0 + j < Wo ? dy[((b * Ho + oy) * Wo + ox0 + j) * C + c] : 0.f;
+            for (int j = 0; j < RUN; ++j) d[j] = ox0 + j < Wo ? *(const f32x4*)(dy + ((b * Ho + oy) * Wo + ox0 + j) * C + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
             const int ixb = ox0 * S - lo;
 #pragma unroll
             for (int ky = 0; ky < K; ++ky) {
                 const int iy = oy * S - lo + ky;
                 if (iy < 0 || iy >= H) continue;
-                const float* xr = x + ((b * H + iy) * W) * C + c;
-                float xs[XS];
+                const float* xr = x + ((b * H + iy) * W) * C + c0;
+                f32x4 xs[XS];
 #pragma unroll
                 for (int j = 0; j < XS; ++j) {
                     const int ix = ixb + j;
-                    xs[j] = (ix >= 0 && ix < W) ? xr[(long)ix * C] : 0.f;
+                    xs[j] = (ix >= 0 && ix < W) ? *(const f32x4*)(xr + (long)ix * C) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx)
@@ -274,10 +324,25 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
                     for (int j = 0; j < RUN; ++j) acc[ky * K + kx] += d[j] * xs[j * S + kx];
             }
         }
-    double accd[KK];
+    // lanes l, l^16, l^32, l^48 hold the same channel quad: fold them, then the 4 waves through LDS
 #pragma unroll
-    for (int q = 0; q < KK; ++q) accd[q] = acc[q];
-    slab_write<KK>(accd, lds, partial, slab, C, c);
+    for (int q = 0; q < KK; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = acc[q][k];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 16) lds[((wave * 16 + cq) * 4 + k) * KK + q] = v;
+        }
+    __syncthreads();
+    for (int i = tid; i < 64 * KK; i += 256) {
+        const int cl = i / KK, q = i - cl * KK;              // channel within the group, tap
+        if (cbase + cl < C) {
+            const int idx = ((cl >> 2) * 4 + (cl & 3)) * KK + q;
+            const double v = (((double)lds[idx] + (double)lds[16 * 4 * KK + idx]) + (double)lds[2 * 16 * 4 * KK + idx]) + (double)lds[3 * 16 * 4 * KK + idx];
+            partial[((size_t)slab * KK + q) * C + cbase + cl] = v;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -372,6 +437,61 @@ __global__ __launch_bounds__(1024) void combine_partials_kernel(const PT* __rest
         if (out_f) out_f[j] = (float)t;
     }
 }
+// BatchNorm: the combine of the per-slab partials and the per-channel finish in ONE launch (they were two: a tiny dependent
+// kernel costs ~4 us here, 156 of them per step).  A workgroup owns 64 channels: 16 waves stride the slabs for both sums,
+// fixed-order LDS combine, then wave 0 finishes.  partial = [slab][2][C] doubles.
+__device__ __forceinline__ void combine2_(const double* __restrict__ partial, int nslab, int C, int c, double* lds /*[16][64][2]*/, double* out2) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double a0 = 0., a1 = 0.;
+    if (c < C) {
+        int k = wave;
+        for (; k + 48 < nslab; k += 64) {          // 8 loads in flight
+            double p0[4], p1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { p0[u] = partial[((size_t)(k + 16 * u) * 2) * C + c]; p1[u] = partial[((size_t)(k + 16 * u) * 2 + 1) * C + c]; }
+            a0 += (p0[0] + p0[1]) + (p0[2] + p0[3]); a1 += (p1[0] + p1[1]) + (p1[2] + p1[3]);
+        }
+        for (; k < nslab; k += 16) { a0 += partial[((size_t)k * 2) * C + c]; a1 += partial[((size_t)k * 2 + 1) * C + c]; }
+    }
+    lds[(wave * 64 + lane) * 2] = a0; lds[(wave * 64 + lane) * 2 + 1] = a1;
+    __syncthreads();
+    double t0 = 0., t1 = 0.;
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { t0 += lds[(w * 64 + lane) * 2]; t1 += lds[(w * 64 + lane) * 2 + 1]; }
+    }
+    out2[0] = t0; out2[1] = t1;
+}
+__global__ __launch_bounds__(1024) void bn_stats_combine_final_kernel(const double* __restrict__ partial, int nslab, long M, int C, float eps,
+                                                                      float momentum, float* __restrict__ mean, float* __restrict__ rstd,
+                                                                      float* __restrict__ running_mean, float* __restrict__ running_var) {
+    __shared__ double lds[16 * 64 * 2];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    double t[2];
+    combine2_(partial, nslab, C, c, lds, t);
+    if ((threadIdx.x >> 6) != 0 || c >= C) return;
+    const double m = t[0] / (double)M;
+    double var = t[1] / (double)M - m * m;
+    if (var < 0.) var = 0.;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {   // nn.BatchNorm2d: running <- (1-mom) running + mom batch; the variance unbiased
+        const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+}
+__global__ __launch_bounds__(1024) void bn_bwd_combine_final_kernel(const double* __restrict__ partial, int nslab, int C, float* __restrict__ sums /*[2][C]*/,
+                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    __shared__ double lds[16 * 64 * 2];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    double t[2];
+    combine2_(partial, nslab, C, c, lds, t);
+    if ((threadIdx.x >> 6) != 0 || c >= C) return;
+    const float s0 = (float)t[0], s1 = (float)t[1];
+    sums[c] = s0; sums[C + c] = s1;        // this call's sums (needed by dx)
+    if (accumulate) { dbeta[c] += s0; dgamma[c] += s1; } else { dbeta[c] = s0; dgamma[c] = s1; }
+}
 
 // ------------------------------------------------------------------------------------------
 // squeeze-excite pieces, pooling, activations
@@ -381,20 +501,35 @@ __global__ __launch_bounds__(1024) void combine_partials_kernel(const PT* __rest
 template <int MODE>
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ a, const float* __restrict__ a2, int HW, int C,
                                                           int rows_per_chunk, double* __restrict__ partial) {
-    __shared__ double lds[4 * 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane, b = blockIdx.y, chunk = blockIdx.z, nchunk = gridDim.z;
+    // 16 channel quads x 16 row lanes per workgroup, 16-byte loads, four independent rows in flight per lane (see bn_stats_kernel)
+    __shared__ double lds[16 * 16 * 4];
+    const int tid = threadIdx.x, cq = tid & 15, rs = tid >> 4;
+    const int cbase = blockIdx.x * 64, c0 = cbase + cq * 4, b = blockIdx.y, chunk = blockIdx.z, nchunk = gridDim.z;
     const int p0 = chunk * rows_per_chunk, p1 = min(HW, p0 + rows_per_chunk);
-    double acc = 0.;
-    if (c < C)
-        for (int p = p0 + wave; p < p1; p += 4) {
-            const size_t o = ((size_t)b * HW + p) * C + c;
-            acc += MODE == 0 ? (double)a[o] : (double)a[o] * a2[o];
+    double acc[4] = {0., 0., 0., 0.};
+    if (c0 < C)
+        for (int p = p0 + rs; p < p1; p += 64) {
+            f32x4 v[4], w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = p + 16 * u < p1;
+                const size_t o = ((size_t)b * HW + p + 16 * u) * C + c0;
+                v[u] = ok ? *(const f32x4*)(a + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (MODE != 0) w[u] = ok ? *(const f32x4*)(a2 + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] += MODE == 0 ? (double)v[u][k] : (double)v[u][k] * w[u][k];
         }
-    lds[wave * 64 + lane] = acc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lds[(rs * 16 + cq) * 4 + k] = acc[k];
     __syncthreads();
-    if (wave == 0 && c < C)
-        partial[((size_t)b * nchunk + chunk) * C + c] = ((lds[lane] + lds[64 + lane]) + lds[128 + lane]) + lds[192 + lane];
+    if (tid < 64 && cbase + tid < C) {
+        double v = 0.;
+        for (int r = 0; r < 16; ++r) v += lds[(r * 16 + (tid >> 2)) * 4 + (tid & 3)];
+        partial[((size_t)b * nchunk + chunk) * C + cbase + tid] = v;
+    }
 }
 __global__ __launch_bounds__(256) void rows_reduce_final_kernel(const double* __restrict__ partial, int nchunk, int C, float scale,
                                                                 float* __restrict__ out) {
@@ -719,11 +854,9 @@ int cosy_bn_train_stats(const float* x, long M, int C, float eps, float momentum
     const RedGeom g = red_geom(M, C);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(g.cgroups, g.nslab), dim3(256), 0, s, x, M, C, g.rows_per_slab, (double*)workspace);
     COSY_CHECK_HIP(hipGetLastError());
-    double* sums = (double*)workspace + (size_t)g.nslab * 2 * C;
-    hipLaunchKernelGGL(combine_partials_kernel<double>, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, (const double*)workspace, g.nslab, (long)2 * C, sums,
-                       (float*)nullptr);
+    hipLaunchKernelGGL(bn_stats_combine_final_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, (const double*)workspace, g.nslab, M, C, eps, momentum,
+                       mean, rstd, running_mean, running_var);
     COSY_CHECK_HIP(hipGetLastError());
-    LAUNCH1D(bn_stats_final_kernel, C, s, (const double*)sums, M, C, eps, momentum, mean, rstd, running_mean, running_var);
     return COSY_OK;
 }
 
@@ -747,10 +880,9 @@ int cosy_bn_train_backward(const float* dout, const float* x, const float* mean,
                        HW, g.rows_per_slab, (double*)workspace);
     COSY_CHECK_HIP(hipGetLastError());
     // this call's sums (needed by dx) into `sums`; the parameter gradients accumulate on request
-    hipLaunchKernelGGL(combine_partials_kernel<double>, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, (const double*)workspace, g.nslab, (long)2 * C,
-                       (double*)nullptr, sums);
+    hipLaunchKernelGGL(bn_bwd_combine_final_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, (const double*)workspace, g.nslab, C, sums, dgamma, dbeta,
+                       accumulate);
     COSY_CHECK_HIP(hipGetLastError());
-    LAUNCH1D(bn_bwd_final_kernel, C, s, (const float*)sums, C, dgamma, dbeta, accumulate);
     LAUNCH1D(bn_bwd_apply_kernel, M * (C / 4), s, dout, x, mean, rstd, gamma, beta, sums, sums + C, M * (C / 4), C / 4, 1.f / (float)M, act,
              rowscale, HW, dx);
     return COSY_OK;
@@ -764,7 +896,12 @@ int cosy_dw_train_forward(const float* x, const float* wt, int B, int H, int W, 
     const int Ho = stride == 1 ? H : (H + (k - 2) - k) / 2 + 1, Wo = stride == 1 ? W : (W + (k - 2) - k) / 2 + 1;
     const long n4 = (long)B * Ho * Wo * (C / 4);
     if (n4 == 0) return COSY_OK;
-    LAUNCH1D(dw_fwd_kernel, n4, s, x, wt, H, W, C / 4, Ho, Wo, k, stride, lo, n4, out);
+    (void)lo;
+    const long n = (long)B * cdiv(Ho, 4) * Wo * (C / 4);
+    if (k == 3 && stride == 1) LAUNCH1D((dw_rows_kernel<3, 1, false>), n, s, x, wt, H, W, Ho, Wo, C / 4, n, out);
+    else if (k == 5 && stride == 1) LAUNCH1D((dw_rows_kernel<5, 1, false>), n, s, x, wt, H, W, Ho, Wo, C / 4, n, out);
+    else if (k == 3) LAUNCH1D((dw_rows_kernel<3, 2, false>), n, s, x, wt, H, W, Ho, Wo, C / 4, n, out);
+    else LAUNCH1D((dw_rows_kernel<5, 2, false>), n, s, x, wt, H, W, Ho, Wo, C / 4, n, out);
     return COSY_OK;
 }
 
@@ -776,6 +913,12 @@ int cosy_dw_train_backward_data(const float* dy, const float* wt, int B, int H, 
     const int Ho = stride == 1 ? H : (H + (k - 2) - k) / 2 + 1, Wo = stride == 1 ? W : (W + (k - 2) - k) / 2 + 1;
     const long n4 = (long)B * H * W * (C / 4);
     if (n4 == 0) return COSY_OK;
+    if (stride == 1) {
+        const long n = (long)B * cdiv(H, 4) * W * (C / 4);
+        if (k == 3) LAUNCH1D((dw_rows_kernel<3, 1, true>), n, s, dy, wt, H, W, H, W, C / 4, n, dx);
+        else LAUNCH1D((dw_rows_kernel<5, 1, true>), n, s, dy, wt, H, W, H, W, C / 4, n, dx);
+        return COSY_OK;
+    }
     LAUNCH1D(dw_bwd_data_kernel, n4, s, dy, wt, H, W, C / 4, Ho, Wo, k, stride, lo, n4, dx);
     return COSY_OK;
 }
@@ -786,9 +929,9 @@ int cosy_dw_train_backward_weight(const float* x, const float* dy, int B, int H,
     COSY_REQUIRE(x && dy && dwt && workspace && (k == 3 || k == 5) && (stride == 1 || stride == 2), "dw_train_backward_weight: bad argument");
     const int lo = stride == 1 ? (k - 1) / 2 : (k - 2) / 2;
     const int Ho = stride == 1 ? H : (H + (k - 2) - k) / 2 + 1, Wo = stride == 1 ? W : (W + (k - 2) - k) / 2 + 1;
-    const long nunits = (long)B * Ho * cdiv(Wo, 8);
-    COSY_REQUIRE(nunits > 0, "dw_train_backward_weight: empty batch");
-    RedGeom g = red_geom(nunits * 4, C);     // a unit is 8 pixels: ask for slabs as if there were nunits*4 rows
+    const long nunits = (long)B * Ho * cdiv(Wo, 4);     // unit = a run of 4 output pixels of one row (RUN in the kernel)
+    COSY_REQUIRE(nunits > 0 && C % 4 == 0, "dw_train_backward_weight: empty batch or C %% 4 != 0");
+    RedGeom g = red_geom(nunits * 2, C);     // ask for slabs as if there were nunits*2 rows
     const int ups = (int)cdiv(nunits, g.nslab);
     g.nslab = cdiv(nunits, ups);
     const dim3 grid(g.cgroups, g.nslab);
@@ -822,7 +965,8 @@ int cosy_wgrad(const float* dY, const float* X, long M, int N, int K, float* dW,
     const int gy = cdiv(tn, TN), gz = cdiv(tk, TK);
     const size_t cap = cosy_train_workspace_bytes() / ((size_t)N * K * sizeof(float));
     COSY_REQUIRE(cap >= 1, "wgrad: N x K = %d x %d exceeds the workspace", N, K);
-    int nwg = (int)std::min<size_t>(1024, cap);
+    static const int wg_cap = tune_int("COSY_WG_CAP", 256);
+    int nwg = (int)std::min<size_t>((size_t)wg_cap, cap);
     if (gy * gz >= 64) nwg = std::min(nwg, 64);          // wide outputs: enough workgroups already, keep the combine short
     int rpw = (int)cdiv(M, (long)nwg * 4);
     rpw = cdiv(rpw, 8) * 8;
