@@ -13,18 +13,22 @@ import torch
 
 
 class TensorCollection:
-    """Named tensors sharing their first dimension; attribute access and fancy indexing."""
+    """Named tensors sharing their first dimension; attribute access and fancy indexing.
+
+    The tensors live in one dict (`.tensors`); every name in it is also readable / assignable as an attribute, any other
+    attribute is an ordinary instance attribute.  Casting / moving methods work in place and return self, as the reference's do."""
 
     def __init__(self, **kwargs):
-        self.__dict__['_tensors'] = dict()
+        object.__setattr__(self, '_tensors', {})
         for name, tensor in kwargs.items():
             self.register_tensor(name, tensor)
 
+    # ---- the tensor table
     def register_tensor(self, name, tensor):
         self._tensors[name] = tensor
 
     def delete_tensor(self, name):
-        del self._tensors[name]
+        self._tensors.pop(name)
 
     @property
     def tensors(self):
@@ -32,57 +36,64 @@ class TensorCollection:
 
     @property
     def device(self):
-        return next(iter(self._tensors.values())).device
+        for t in self._tensors.values():
+            return t.device
+        raise StopIteration('empty collection has no device')
 
+    # ---- attribute protocol: tensor names shadow nothing, they are looked up only when normal lookup fails
     def __getattr__(self, name):
-        tensors = self.__dict__.get('_tensors', {})
-        if name in tensors:
-            return tensors[name]
-        if name in self.__dict__:
-            return self.__dict__[name]
+        table = self.__dict__.get('_tensors')
+        if table is not None and name in table:
+            return table[name]
         raise AttributeError(name)
 
     def __setattr__(self, name, value):
-        if '_tensors' not in self.__dict__:
-            raise ValueError('Please call __init__')
-        if name in self._tensors:
-            self._tensors[name] = value
+        table = self.__dict__.get('_tensors')
+        if table is None:
+            raise ValueError(f'{type(self).__name__}.__init__ has not run: cannot set {name!r}')
+        if name in table:
+            table[name] = value
         else:
-            self.__dict__[name] = value
+            object.__setattr__(self, name, value)
 
     def __getitem__(self, ids):
         ids = _as_slice(ids)
         return TensorCollection(**{k: v[ids] for k, v in self._tensors.items()})
 
     def __repr__(self):
-        lines = [f'    {k}: {t.shape} {t.dtype} {t.device},' for k, t in self._tensors.items()]
-        return self.__class__.__name__ + '(\n' + '\n'.join(lines) + '\n)'
+        body = ''.join(f'    {k}: {t.shape} {t.dtype} {t.device},\n' for k, t in self._tensors.items())
+        return f'{type(self).__name__}(\n{body})'
 
+    # ---- pickling: the tensor table only
     def __getstate__(self):
         return {'tensors': self.tensors}
 
     def __setstate__(self, state):
-        self.__init__(**state['tensors'])
+        TensorCollection.__init__(self, **state['tensors'])
 
-    def to(self, torch_attr):
-        for k, v in self._tensors.items():
-            self._tensors[k] = v.to(torch_attr)
+    # ---- in-place casts / moves
+    def _apply(self, fn):
+        for k in list(self._tensors):
+            self._tensors[k] = fn(self._tensors[k])
         return self
 
+    def to(self, torch_attr):
+        return self._apply(lambda t: t.to(torch_attr))
+
     def cuda(self):
-        return self.to('cuda')
+        return self._apply(lambda t: t.to('cuda'))
 
     def cpu(self):
-        return self.to('cpu')
+        return self._apply(lambda t: t.to('cpu'))
 
     def float(self):
-        return self.to(torch.float)
+        return self._apply(lambda t: t.to(torch.float32))
 
     def double(self):
-        return self.to(torch.double)
+        return self._apply(lambda t: t.to(torch.float64))
 
     def half(self):
-        return self.to(torch.half)
+        return self._apply(lambda t: t.to(torch.float16))
 
     def clone(self):
         return TensorCollection(**{k: v.clone() for k, v in self._tensors.items()})
@@ -106,8 +117,7 @@ class PandasTensorCollection(TensorCollection):
         return PandasTensorCollection(self.infos.copy(), **super().clone().tensors)
 
     def __repr__(self):
-        s = super().__repr__()[:-1]
-        return s + '-' * 40 + '\n    infos:\n' + repr(self.infos) + '\n)'
+        return super().__repr__()[:-1] + '-' * 40 + f'\n    infos:\n{self.infos!r}\n)'
 
     def __getitem__(self, ids):
         ids = _as_slice(ids)
@@ -123,15 +133,13 @@ class PandasTensorCollection(TensorCollection):
         from .distributed import gather_collection
         return gather_collection(self)
 
+    # ---- pickling: tensors + the frame + the free-form meta dict
     def __getstate__(self):
-        state = super().__getstate__()
-        state['infos'] = self.infos
-        state['meta'] = self.meta
-        return state
+        return dict(tensors=self.tensors, infos=self.infos, meta=self.meta)
 
     def __setstate__(self, state):
-        self.__init__(state['infos'], **state['tensors'])
-        self.meta = state['meta']
+        PandasTensorCollection.__init__(self, state['infos'], **state['tensors'])
+        self.meta = state.get('meta', {})
 
 
 def _as_slice(ids):
