@@ -100,6 +100,7 @@ template <int TOP, int NFRAG> __device__ __forceinline__ void xfrag_fence() {
     else if constexpr (TOP == 168 && NFRAG == 8) asm volatile("; XFENCE" ::: "v136","v137","v138","v139","v140","v141","v142","v143","v144","v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
     else if constexpr (TOP == 128 && NFRAG == 3) asm volatile("; XFENCE" ::: "v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
     else if constexpr (TOP == 128 && NFRAG == 4) asm volatile("; XFENCE" ::: "v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
+    else if constexpr (TOP == 128 && NFRAG == 5) asm volatile("; XFENCE" ::: "v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
     else static_assert(TOP < 0, "xfrag_fence: add the clobber list of this (budget, fragments) pair");
 }
 template <int MINW> __device__ __forceinline__ void xfrag_reserve() {
@@ -112,6 +113,7 @@ template <typename F, int... Us>
 __device__ __forceinline__ void unroll_seq(F&& f, std::integer_sequence<int, Us...>) { (f(std::integral_constant<int, Us>{}), ...); }
 
 constexpr int wave_lcm(int a, int b) { int x = a; while (x % b) x += a; return x; }
+constexpr bool wave_wlds(int kbn, int minw) { return kbn >= 5 && minw >= 4; }
 
 template <typename T, int KS, int S, int KBN, int PPL, int NI, bool FULLW, int MINW>
 __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
@@ -125,6 +127,8 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     constexpr int NOPEN = (KS + S - 1) / S;                   // output rows that are accumulating at the same time
     constexpr int U = S * NOPEN;                              // input rows per unrolled super-iteration
     constexpr int PF = (4 + KS * KS) * 16 * NI;               // floats of the parameter block
+    constexpr bool WLDS = wave_wlds(KBN, MINW);               // expand-weight fragments parked in LDS instead of registers
+    constexpr int PFW = PF + (WLDS ? NI * KBN * 256 : 0);
     static_assert(PPL % S == 0, "a lane's pixel run must hold whole output pixels");
     typedef T out_t __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float smem_w[];
@@ -138,7 +142,8 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     const bool active = b < a.B;
     const int c0 = ch * 16 * NI;
 
-    float* P = smem_w + wave * PF;
+    float* P = smem_w + wave * PFW;
+    char* Wl = (char*)(P + PF);
 
     const T* __restrict__ X = (const T*)a.X + (size_t)min(b, a.B - 1) * a.H * a.W * a.Cin;
     const float* Pl = P + kg * 4;            // this lane's channel quad inside every 16-float group
@@ -201,6 +206,14 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
 #pragma unroll
             for (int kb = 0; kb < KBN; ++kb)
                 wf[ni][kb] = *(const raw_t*)((const T*)a.Wp + ((size_t)(ch * NI + ni) * a.nkb_total + kb) * 64 * EPL + lane * EPL);
+        if constexpr (WLDS) {
+            // 4 * KBN registers that a 4-waves-per-SIMD budget does not have: parked in the wave's LDS block and re-read in front
+            // of every row's MFMAs (one conflict-free ds_read_b128 per fragment and row)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int kb = 0; kb < KBN; ++kb) *(raw_t*)(Wl + (ni * KBN + kb) * 1024 + lane * 16) = wf[ni][kb];
+        }
     }
     // ---- parameters of the chunk -> wave-private LDS block [s0][b0][s1][b1][taps], 16*NI floats each
     if (active) {
@@ -272,7 +285,8 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
 #pragma unroll
                         for (int kb = 0; kb < KBN; ++kb) {
                             raw_t xv = __builtin_bit_cast(raw_t, xc[q][kb]);
-                            mma(m, wf[ni][kb], xv);
+                            if constexpr (WLDS) mma(m, *(const raw_t*)(Wl + (ni * KBN + kb) * 1024 + lane * 16), xv);
+                            else mma(m, wf[ni][kb], xv);
                         }
                         float y4[4];
 #pragma unroll
@@ -398,7 +412,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
 // across batch sizes.
 #define COSY_WAVE_VARIANTS(X)                                                                                      \
     X(3, 2, 1, 8, 1, true, 2, 4) X(3, 1, 1, 4, 1, true, 3, 2) X(5, 2, 1, 4, 1, true, 3, 1) X(5, 1, 2, 2, 1, true, 3, 2)      \
-    X(3, 2, 2, 2, 1, true, 4, 2) X(3, 1, 3, 1, 1, true, 4, 1) X(5, 1, 3, 1, 1, true, 4, 1) X(5, 1, 5, 1, 1, true, 3, 1)      \
+    X(3, 2, 2, 2, 1, true, 4, 2) X(3, 1, 3, 1, 1, true, 4, 1) X(5, 1, 3, 1, 1, true, 4, 1) X(5, 1, 5, 1, 1, true, 4, 1)      \
     X(3, 1, 1, 5, 1, true, 2, 2) X(5, 2, 1, 6, 1, false, 2, 1) X(5, 1, 2, 3, 1, false, 2, 2) X(3, 2, 2, 4, 1, false, 3, 1)   \
     X(3, 1, 3, 2, 1, false, 3, 1) X(5, 1, 3, 2, 1, false, 2, 1) X(5, 1, 5, 2, 1, false, 2, 1)
 enum { WAVE_MAX_RSPLIT = 4 };
@@ -438,7 +452,7 @@ void wave_kernel_name(int Cin, int Cmid, int k, int s, int dtype, int H, int W, 
 
 template <typename T, int KS, int S, int KBN, int PPL, int NI, bool FW, int MW, int RSP>
 static int launch_wave_k(WaveKArgs k, int* n_tiles_out, hipStream_t s) {
-    const size_t lds = (size_t)4 * (4 + KS * KS) * 16 * NI * sizeof(float);
+    const size_t lds = (size_t)4 * ((4 + KS * KS) * 16 * NI * sizeof(float) + (wave_wlds(KBN, MW) ? NI * KBN * 1024 : 0));
     k.dbg = tune_int("COSY_WAVE_DBG", 0);
     k.rsplit = tune_int("COSY_WAVE_RSPLIT", RSP);
     if (k.rsplit < 1) k.rsplit = 1;
