@@ -24,7 +24,8 @@ pass mfma MfmaUtil SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr TA_TOTAL_WAVEFRONTS_sum
 # the collectives through RCCL on this one GPU (forced 1-rank group).  With a single rank RCCL completes an all-gather as a device copy
 # (no ncclDevKernel appears in a kernel trace), so the evidence is RCCL's own log of the communicator and of every collective call.
-COSY_FORCE_DIST=1 NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,COLL python bench.py $ARGS > $OUT/bench_rccl.json 2> $OUT/rccl.err
-grep -E "RCCL version|HIP version|ROCm version|Init COMPLETE|comm 0x.* rank|AllGather|AllReduce|Broadcast" $OUT/rccl.err | cut -c1-260 | awk 'NR<=12 || /AllGather/ && ++n<=6' > $OUT/rccl_kernels.csv
+COSY_FORCE_DIST=1 NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,COLL python bench.py $ARGS > $OUT/rccl.log 2>&1
+tail -1 $OUT/rccl.log > $OUT/bench_rccl.json
+grep -E "RCCL version|HIP version|ROCm version|Init COMPLETE|comm 0x[0-9a-f]+ rank|Init timings|AllGather|AllReduce|Abort COMPLETE" $OUT/rccl.log | cut -c1-260 | awk '!/AllGather/ || ++n<=6' > $OUT/rccl_kernels.csv
 python profiles/summarize.py $OUT > $OUT/summary.txt 2>&1
 tail -60 $OUT/summary.txt
