@@ -5,7 +5,7 @@
 //
 // Why.  VALU micro-benchmark on MI355X (profiles/exp/valu_bench.hip): plain fp32 op 3.1, v_pk_fma_f32 5.9 (no gain),
 // v_exp_f32 / v_rcp_f32 8.7 cycles per wave instruction -> BN + SiLU costs ~32 cycles per 64 elements and the fused fronts
-// are VALU-bound; the LDS-ring kernels (mbconv_front / mbconv_rows) reach only ~35 % of that bound because every
+// are VALU-bound; the LDS-ring kernels of rounds 1-2 (a tiled and a row-streaming front, removed in round 3) reached only ~35 % of that bound because every
 // workgroup alternates barrier-separated expand / depthwise phases at 2-3 waves per SIMD.  Here every wave is independent:
 //   * a wave owns (sample, 16*NI expanded channels) and walks down the rows of the whole map;
 //   * pixel mapping of the MFMA B operand: lane (p = lane & 15) owns the PPL CONSECUTIVE pixels x = p*PPL .. p*PPL+PPL-1
@@ -19,7 +19,7 @@
 //     loop is unrolled S*ceil(KS/S) times so that every accumulator slot is a compile-time constant;
 //   * the block input is read as MFMA fragments straight from global memory one row ahead; per row the global memory
 //     operations are issued right after the expansion, ordered [previous output row's stores] -> [next input row's loads]
-//     (vmcnt retires in order and the compiler waits with vmcnt(0): see mbconv_rows_kernel), so the wait in front of the
+//     (vmcnt retires in order and the compiler waits with vmcnt(0)), so the wait in front of the
 //     next row's MFMAs only sees operations that are a whole depthwise phase old;
 //   * squeeze sums: per-lane registers over the whole image, one DPP tree per 16-lane row at the end (fixed order).
 // The 16*NI-channel chunks of one sample re-read the block input (x Cmid/16/NI through L2; it is the small tensor).

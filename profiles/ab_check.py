@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of backbone schedules with the experiment build (COSY_TUNE_LIB=1, lib/libcosyhip_tune.so): the same weights and
 input through two settings of the COSY_* knobs; prints the deviation of features / pose outputs between them and against
-the fp32 engine.  Usage: COSY_TUNE_LIB=1 python profiles/ab_check.py "COSY_ROWS_MASK=0" "COSY_ROWS_MASK=0x1fc" [--crop 256x256]"""
+the fp32 engine.  Usage: COSY_TUNE_LIB=1 python profiles/ab_check.py "COSY_WAVE_MASK=0" "COSY_WAVE_MASK=0x3fffc" [--crop 256x256]"""
 import os
 import sys
 import numpy as np
