@@ -1,4 +1,4 @@
-// Wave-autonomous fused MBConv front (2-byte storage types):
+// Wave-autonomous fused MBConv front (bf16 / fp16 storage; fp32 for the parity mode):
 //     expand 1x1 (MFMA) -> BN -> SiLU -> depthwise kxk -> BN -> SiLU -> D, squeeze sums
 // with the expanded rows held in REGISTERS -- no LDS ring, no workgroup barrier.
 // Reference: MBConvBlock.forward, cosypose/models/efficientnet.py:71-90.
@@ -90,17 +90,35 @@ template <int TOP, int I> __device__ __forceinline__ f32x4 xfrag_read() {
 // in front of the wait -- keeps every long-lived value of the kernel out of the range by construction; what is left to luck
 // (and to profiles/check_wave_isa.py) are temporaries that live entirely between two fences.
 template <int TOP, int NFRAG> __device__ __forceinline__ void xfrag_fence() {
-    if constexpr (TOP == 256 && NFRAG == 5) asm volatile("; XFENCE" ::: "v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
+    if constexpr (TOP == 256 && NFRAG == 3) asm volatile("; XFENCE" ::: "v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
+    else if constexpr (TOP == 256 && NFRAG == 4) asm volatile("; XFENCE" ::: "v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
+    else if constexpr (TOP == 256 && NFRAG == 5) asm volatile("; XFENCE" ::: "v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
     else if constexpr (TOP == 256 && NFRAG == 6) asm volatile("; XFENCE" ::: "v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
     else if constexpr (TOP == 256 && NFRAG == 8) asm volatile("; XFENCE" ::: "v224","v225","v226","v227","v228","v229","v230","v231","v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
+    else if constexpr (TOP == 256 && NFRAG == 9) asm volatile("; XFENCE" ::: "v220","v221","v222","v223","v224","v225","v226","v227","v228","v229","v230","v231","v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
     else if constexpr (TOP == 256 && NFRAG == 10) asm volatile("; XFENCE" ::: "v216","v217","v218","v219","v220","v221","v222","v223","v224","v225","v226","v227","v228","v229","v230","v231","v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
+    else if constexpr (TOP == 256 && NFRAG == 12) asm volatile("; XFENCE" ::: "v208","v209","v210","v211","v212","v213","v214","v215","v216","v217","v218","v219","v220","v221","v222","v223","v224","v225","v226","v227","v228","v229","v230","v231","v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
+    else if constexpr (TOP == 256 && NFRAG == 16) asm volatile("; XFENCE" ::: "v192","v193","v194","v195","v196","v197","v198","v199","v200","v201","v202","v203","v204","v205","v206","v207","v208","v209","v210","v211","v212","v213","v214","v215","v216","v217","v218","v219","v220","v221","v222","v223","v224","v225","v226","v227","v228","v229","v230","v231","v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
+    else if constexpr (TOP == 256 && NFRAG == 18) asm volatile("; XFENCE" ::: "v184","v185","v186","v187","v188","v189","v190","v191","v192","v193","v194","v195","v196","v197","v198","v199","v200","v201","v202","v203","v204","v205","v206","v207","v208","v209","v210","v211","v212","v213","v214","v215","v216","v217","v218","v219","v220","v221","v222","v223","v224","v225","v226","v227","v228","v229","v230","v231","v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
+    else if constexpr (TOP == 168 && NFRAG == 3) asm volatile("; XFENCE" ::: "v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
     else if constexpr (TOP == 168 && NFRAG == 4) asm volatile("; XFENCE" ::: "v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
     else if constexpr (TOP == 168 && NFRAG == 5) asm volatile("; XFENCE" ::: "v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
     else if constexpr (TOP == 168 && NFRAG == 6) asm volatile("; XFENCE" ::: "v144","v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
     else if constexpr (TOP == 168 && NFRAG == 8) asm volatile("; XFENCE" ::: "v136","v137","v138","v139","v140","v141","v142","v143","v144","v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
+    else if constexpr (TOP == 168 && NFRAG == 9) asm volatile("; XFENCE" ::: "v132","v133","v134","v135","v136","v137","v138","v139","v140","v141","v142","v143","v144","v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
+    else if constexpr (TOP == 168 && NFRAG == 10) asm volatile("; XFENCE" ::: "v128","v129","v130","v131","v132","v133","v134","v135","v136","v137","v138","v139","v140","v141","v142","v143","v144","v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
+    else if constexpr (TOP == 168 && NFRAG == 12) asm volatile("; XFENCE" ::: "v120","v121","v122","v123","v124","v125","v126","v127","v128","v129","v130","v131","v132","v133","v134","v135","v136","v137","v138","v139","v140","v141","v142","v143","v144","v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
+    else if constexpr (TOP == 168 && NFRAG == 16) asm volatile("; XFENCE" ::: "v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127","v128","v129","v130","v131","v132","v133","v134","v135","v136","v137","v138","v139","v140","v141","v142","v143","v144","v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
+    else if constexpr (TOP == 168 && NFRAG == 18) asm volatile("; XFENCE" ::: "v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127","v128","v129","v130","v131","v132","v133","v134","v135","v136","v137","v138","v139","v140","v141","v142","v143","v144","v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
     else if constexpr (TOP == 128 && NFRAG == 3) asm volatile("; XFENCE" ::: "v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
     else if constexpr (TOP == 128 && NFRAG == 4) asm volatile("; XFENCE" ::: "v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
     else if constexpr (TOP == 128 && NFRAG == 5) asm volatile("; XFENCE" ::: "v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
+    else if constexpr (TOP == 128 && NFRAG == 6) asm volatile("; XFENCE" ::: "v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
+    else if constexpr (TOP == 128 && NFRAG == 8) asm volatile("; XFENCE" ::: "v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
+    else if constexpr (TOP == 128 && NFRAG == 9) asm volatile("; XFENCE" ::: "v92","v93","v94","v95","v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
+    else if constexpr (TOP == 128 && NFRAG == 10) asm volatile("; XFENCE" ::: "v88","v89","v90","v91","v92","v93","v94","v95","v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
+    else if constexpr (TOP == 128 && NFRAG == 12) asm volatile("; XFENCE" ::: "v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95","v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
+    else if constexpr (TOP == 128 && NFRAG == 16) asm volatile("; XFENCE" ::: "v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95","v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
     else static_assert(TOP < 0, "xfrag_fence: add the clobber list of this (budget, fragments) pair");
 }
 template <int MINW> __device__ __forceinline__ void xfrag_reserve() {
@@ -113,7 +131,7 @@ template <typename F, int... Us>
 __device__ __forceinline__ void unroll_seq(F&& f, std::integer_sequence<int, Us...>) { (f(std::integral_constant<int, Us>{}), ...); }
 
 constexpr int wave_lcm(int a, int b) { int x = a; while (x % b) x += a; return x; }
-constexpr bool wave_wlds(int kbn, int minw) { return kbn >= 5 && minw >= 4; }
+constexpr bool wave_wlds(int kbn, int minw) { return (kbn >= 5 && minw >= 4) || kbn >= 9; }
 
 template <typename T, int KS, int S, int KBN, int PPL, int NI, bool FULLW, int MINW>
 __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
@@ -415,12 +433,20 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     X(3, 2, 2, 2, 1, true, 4, 2) X(3, 1, 3, 1, 1, true, 4, 1) X(5, 1, 3, 1, 1, true, 4, 1) X(5, 1, 5, 1, 1, true, 4, 1)      \
     X(3, 1, 1, 5, 1, true, 2, 2) X(5, 2, 1, 6, 1, false, 2, 1) X(5, 1, 2, 3, 1, false, 2, 2) X(3, 2, 2, 4, 1, false, 3, 1)   \
     X(3, 1, 3, 2, 1, false, 3, 1) X(5, 1, 3, 2, 1, false, 2, 1) X(5, 1, 5, 2, 1, false, 2, 1)
+// fp32 (parity mode): k-blocks are 16 deep (v_mfma_f32_16x16x4_f32 x 4 per fragment), so KBN = ceil(Cin / 16).  Same design, same
+// checks; these instantiations are what test_backbone_fp32_vs_reference holds to the reference's own per-stage outputs at <= 1e-4.
+// Not built (the fragment registers do not fit 256): 128- and 80-pixel rows with 2 k-blocks, 40-pixel rows with 3, 20-pixel rows with 9
+// -- those blocks run unfused in fp32.
+#define COSY_WAVE_VARIANTS_F32(X)                                                                                  \
+    X(3, 1, 2, 4, 1, true, 2, 2) X(5, 2, 2, 4, 1, true, 3, 1) X(5, 1, 3, 2, 1, true, 2, 2)      \
+    X(3, 2, 3, 2, 1, true, 3, 2) X(3, 1, 6, 1, 1, true, 3, 1) X(5, 1, 6, 1, 1, true, 3, 1) X(5, 1, 9, 1, 1, true, 3, 1)      \
+    X(5, 2, 2, 6, 1, false, 2, 1) X(3, 2, 3, 4, 1, false, 2, 1) X(3, 1, 6, 2, 1, false, 2, 1) X(5, 1, 6, 2, 1, false, 2, 1)
 enum { WAVE_MAX_RSPLIT = 4 };
 
 struct WavePlan { int kbn, ppl, ni; bool fullw, ok; };
-static WavePlan wave_plan(int Cin, int Cmid, int H, int W, int k, int s) {
+static WavePlan wave_plan(int Cin, int Cmid, int H, int W, int k, int s, int dtype) {
     WavePlan p{};
-    p.kbn = cdiv(Cin, 32);
+    p.kbn = cdiv(Cin, dtype == COSY_F32 ? 16 : 32);
     p.ppl = cdiv(W, 16);
     if (p.ppl % s) ++p.ppl;
     p.fullw = W == 16 * p.ppl;
@@ -431,22 +457,22 @@ static WavePlan wave_plan(int Cin, int Cmid, int H, int W, int k, int s) {
     p.ni = 1;
     if (Cmid % 16) return p;
 #define X(KS, S, KBN, PPL, NI, FW, MW, RSP) if (k == KS && s == S && p.kbn == KBN && p.ppl == PPL && p.ni == NI && p.fullw == FW) p.ok = true;
-    COSY_WAVE_VARIANTS(X)
+    if (dtype == COSY_F32) { COSY_WAVE_VARIANTS_F32(X) } else { COSY_WAVE_VARIANTS(X) }
 #undef X
     return p;
 }
 bool wave_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W) {
-    if (dtype == COSY_F32 || H <= 0) return false;
-    return wave_plan(Cin, Cmid, H, W, k, s).ok;
+    if (H <= 0) return false;
+    return wave_plan(Cin, Cmid, H, W, k, s, dtype).ok;
 }
 int wave_max_tiles() { return WAVE_MAX_RSPLIT; }
 void wave_kernel_name(int Cin, int Cmid, int k, int s, int dtype, int H, int W, char* buf, size_t n) {
-    const WavePlan p = wave_plan(Cin, Cmid, H, W, k, s);
+    const WavePlan p = wave_plan(Cin, Cmid, H, W, k, s, dtype);
     int mw = 0;
 #define X(KS, S, KBN, PPL, NI, FW, MW, RSP) if (k == KS && s == S && p.kbn == KBN && p.ppl == PPL && p.ni == NI && p.fullw == FW) mw = MW;
-    COSY_WAVE_VARIANTS(X)
+    if (dtype == COSY_F32) { COSY_WAVE_VARIANTS_F32(X) } else { COSY_WAVE_VARIANTS(X) }
 #undef X
-    snprintf(buf, n, "mbconv_wave_kernel<%s, %d, %d, %d, %d, %d, %s, %d>", dtype == COSY_BF16 ? "__bf16" : "_Float16", k, s, p.kbn, p.ppl,
+    snprintf(buf, n, "mbconv_wave_kernel<%s, %d, %d, %d, %d, %d, %s, %d>", dtype == COSY_F32 ? "float" : dtype == COSY_BF16 ? "__bf16" : "_Float16", k, s, p.kbn, p.ppl,
              p.ni, p.fullw ? "true" : "false", mw);
 }
 
@@ -468,7 +494,7 @@ static int launch_wave_k(WaveKArgs k, int* n_tiles_out, hipStream_t s) {
 }
 template <typename T>
 static int launch_wave_t(const FuseArgs& a, int* n_tiles_out, hipStream_t s) {
-    const WavePlan p = wave_plan(a.Cin, a.Cmid, a.H, a.W, a.k, a.s);
+    const WavePlan p = wave_plan(a.Cin, a.Cmid, a.H, a.W, a.k, a.s, sizeof(T) == 4 ? COSY_F32 : COSY_BF16);
     COSY_REQUIRE(p.ok, "mbconv_wave: unsupported shape Cin=%d Cmid=%d %dx%d k=%d s=%d", a.Cin, a.Cmid, a.H, a.W, a.k, a.s);
     WaveKArgs k;
     k.X = a.X; k.Wp = a.Wp; k.s0 = a.s0; k.b0 = a.b0; k.dww = a.dww; k.s1 = a.s1; k.b1 = a.b1; k.D = a.D; k.partial = a.partial;
@@ -478,7 +504,7 @@ static int launch_wave_t(const FuseArgs& a, int* n_tiles_out, hipStream_t s) {
     const bool fw_ = p.fullw;
 #define X(KS, S, KBN, PPL, NI, FW, MW, RSP) \
     if (ks_ == KS && st_ == S && kbn_ == KBN && ppl_ == PPL && ni_ == NI && fw_ == FW) return launch_wave_k<T, KS, S, KBN, PPL, NI, FW, MW, RSP>(k, n_tiles_out, s);
-    COSY_WAVE_VARIANTS(X)
+    if constexpr (sizeof(T) == 4) { COSY_WAVE_VARIANTS_F32(X) } else { COSY_WAVE_VARIANTS(X) }
 #undef X
     set_error("mbconv_wave: variant not built");
     return COSY_EINVAL;
@@ -487,7 +513,7 @@ static int launch_wave_t(const FuseArgs& a, int* n_tiles_out, hipStream_t s) {
 int launch_mbconv_wave(const FuseArgs& a, int dtype, int* n_tiles_out, hipStream_t s) {
     *n_tiles_out = 1;
     if (a.B == 0) return COSY_OK;
-    COSY_REQUIRE(dtype != COSY_F32, "mbconv_wave: 2-byte storage types only");
+    if (dtype == COSY_F32) return launch_wave_t<float>(a, n_tiles_out, s);
     if (dtype == COSY_BF16) return launch_wave_t<bf16_t>(a, n_tiles_out, s);
     return launch_wave_t<f16_t>(a, n_tiles_out, s);
 }

@@ -161,6 +161,12 @@ def test_backbone_fp32_vs_reference(model, golden, name, hw, seed):
     assert stage_err.max() < NET_TOL
     assert rel_err(feat, golden[f'bb_{name}_feat']) < NET_TOL
     assert rel_err(pose, golden[f'bb_{name}_pose']) < NET_TOL
+    # the fp32 instantiations of the wave-autonomous front are on this path: the same kernel design that sets the 16-bit headline,
+    # held here to the reference's own per-stage outputs
+    _, plan = _block_plan(model, hw, 'fp32')
+    kinds = [p[7] for p in plan]
+    fused = [i for i, k in enumerate(kinds) if k == 1]
+    assert fused == (list(range(3, 18)) if hw == (256, 256) else [5, 8, 9, 10, 11, 12, 13]), kinds
     model.render_size = (240, 320)
 
 
