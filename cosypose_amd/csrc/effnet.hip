@@ -61,7 +61,8 @@ struct Block {
     bool skip;
     bool wave;            // front = mbconv_wave_kernel (kernels_wave.hip)
     bool small;           // front = mbconv_small_kernel (whole-image kernel of the late blocks)
-    bool fused;           // wave || small: the expanded tensor never reaches HBM; otherwise pw_gemm_dma -> E -> dwconv
+    bool tiled;           // front = mbconv_tile_kernel (LDS-tiled kernel: high-resolution blocks the wave kernel's row mapping does not fit)
+    bool fused;           // wave || small || tiled: the expanded tensor never reaches HBM; otherwise pw_gemm_dma -> E -> dwconv
     PwLayer exp, proj;
     void* exp_wp_fused;   // expand weights packed in 16- (wave) or 48-channel (small) tiles for the fused front
     float *dw_w, *dw_scale, *dw_bias, *se_wr, *se_br, *se_we, *se_be;
@@ -81,6 +82,7 @@ struct cosy_net {
     void* X;
     int chunk, fuse;
     unsigned small_mask;  // bit i: MBConv block i may run the fused whole-image front kernel (mbconv_small_kernel)
+    unsigned tile_mask;   // bit i: ... the LDS-tiled front kernel (mbconv_tile_kernel) when neither of the others is built for its shape
     unsigned wave_mask;   // bit i: ... the wave-autonomous front kernel (mbconv_wave_kernel); both only where the shape is built
     int se_batch_from;    // blocks >= this run the batched squeeze-excite kernels
     int probe_layer;      // test probe (cosy_effnet_b3_set_probe): -2 = off
@@ -170,7 +172,8 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         // shape (and fp32) runs the generic unfused kernels, which are shape-agnostic
         b.wave = n->fuse && b.d.e != 1 && ((n->wave_mask >> i) & 1) && wave_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
         b.small = !b.wave && n->fuse && b.d.e != 1 && ((n->small_mask >> i) & 1) && small_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
-        b.fused = b.wave || b.small;
+        b.tiled = !b.wave && !b.small && n->fuse && b.d.e != 1 && ((n->tile_mask >> i) & 1) && tile_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype);
+        b.fused = b.wave || b.small || b.tiled;
         b.exp_wp_fused = nullptr;
         if (b.d.e != 1) {
             mk_pw(b.exp, p, b.d.cin, b.cmid, p + (size_t)b.cmid * b.d.cin, b.H * b.W, false);
@@ -181,7 +184,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
                 // ride in the depthwise taps (dw_w_fold), BatchNorm 1's bias initialises the depthwise accumulators.
                 // (Measured on the wave kernel too: no gain there -- the freed VALU slots do not shorten its rows, and the MFMA
                 // results then feed inline asm directly, which needs explicit wait states -- so it keeps its BatchNorms.)
-                const PwCfg c48 = b.wave ? PwCfg{1, 1} : PwCfg{3, 1};   // 16-channel tiles for the wave kernel, 48 for the small kernel
+                const PwCfg c48 = b.wave ? PwCfg{1, 1} : PwCfg{3, 1};   // 16-channel tiles for the wave kernel, 48 for the small / tiled kernels
                 const size_t ne = pw_packed_elems(b.d.cin, b.cmid, c48, n->dtype);
                 b.exp_wp_fused = bump.take(ne * n->esz);
                 std::vector<float> b0f(b.cmid, 0.f);
@@ -201,7 +204,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
                     if (e2 != hipSuccess) *herr = e2;
                 }
                 b.b0_fold = up_f32(b0f);
-                b.n_tiles = b.wave ? wave_max_tiles() : 1;
+                b.n_tiles = b.wave ? wave_max_tiles() : b.tiled ? tile_num_tiles(b.d.cin, b.Ho, b.Wo, b.d.k, b.d.s, n->dtype) : 1;
             }
             p += (size_t)b.cmid * b.d.cin + 4 * b.cmid;
         }
@@ -355,8 +358,9 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
             else { f.s0 = b.exp.scale; f.b0 = b.exp.bias; f.dww = b.dw_w; f.s1 = b.dw_scale; f.b1 = b.dw_bias; }
             f.D = Dbuf; f.partial = w.partial; f.zeros = n->zeros;
             f.B = Bc; f.H = b.H; f.W = b.W; f.Cin = b.d.cin; f.Cmid = b.cmid; f.Ho = b.Ho; f.Wo = b.Wo; f.k = b.d.k; f.s = b.d.s; f.pad_lo = b.pad_lo;
-            if ((rc = b.wave ? launch_mbconv_wave(f, n->dtype, &se_tiles, s) : launch_mbconv_small(f, n->dtype, s))) return rc;
+            if ((rc = b.wave ? launch_mbconv_wave(f, n->dtype, &se_tiles, s) : b.tiled ? launch_mbconv_tile(f, n->dtype, s) : launch_mbconv_small(f, n->dtype, s))) return rc;
             if (b.wave) wave_kernel_name(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W, kn, sizeof(kn));
+            else if (b.tiled) tile_kernel_name(b.d.cin, b.d.k, b.d.s, n->dtype, kn, sizeof(kn));
             else small_kernel_name(b.d.cin, b.d.k, b.d.s, n->dtype, b.H, b.W, kn, sizeof(kn));
             if ((rc = mark(kn, i, ((double)Bc * b.H * b.W * b.d.cin + (double)Bc * b.Ho * b.Wo * b.cmid + (double)b.d.cin * b.cmid) * esz_d,
                            2.0 * Bc * b.H * b.W * b.d.cin * b.cmid + 2.0 * Bc * b.Ho * b.Wo * b.cmid * b.d.k * b.d.k))) return rc;
@@ -514,7 +518,8 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
         // measured (256 crops): batched from block 19: +1.5 %, from 9: another +1.1 % over one-workgroup-per-sample everywhere; the early
         // blocks (Cmid <= 288, Cse <= 12) stay on se_kernel: two dependent launches cost what its one does
         n->se_batch_from = tune_int("COSY_SE_BATCH_FROM", 9);
-        n->small_mask = (unsigned)tune_int("COSY_SMALL_MASK", 0x3f80000);   // blocks 19-25 (8x8 / 7x10 maps): whole-image kernel
+        n->small_mask = (unsigned)tune_int("COSY_SMALL_MASK", 0x3f80000);
+        n->tile_mask = (unsigned)tune_int("COSY_TILE_MASK", 0x13c);         // blocks 2-5 and 8 (measured in round 1: it loses on the k=5 stride-1 blocks 6/7)   // blocks 19-25 (8x8 / 7x10 maps): whole-image kernel
         n->wave_mask = (unsigned)tune_int("COSY_WAVE_MASK", 0x3fffc);   // blocks 2-17: maps 16..128 pixels wide, stride per shape table
         n->nstreams = tune_int("COSY_STREAMS", 1) == 2 && max_batch >= 32 ? 2 : 1;   // measured: 2 streams x half batches is ~10 % slower
     }
@@ -604,7 +609,7 @@ int cosy_effnet_b3_block_info(const cosy_net_t* n, int i, int* dims) {
     // where the project GEMM applies the squeeze-excite gate: to the weight fragments (maps of a multiple of 64 pixels: a wave's 64
     // rows belong to one sample) or to the activation rows
     const int gate_w = (b.Ho * b.Wo) % 64 == 0;
-    const int v[11] = {b.H, b.W, b.Ho, b.Wo, b.d.cin, b.cmid, b.d.cout, b.wave ? 1 : b.small ? 2 : 0, b.d.k, b.d.s, gate_w};
+    const int v[11] = {b.H, b.W, b.Ho, b.Wo, b.d.cin, b.cmid, b.d.cout, b.wave ? 1 : b.small ? 2 : b.tiled ? 3 : 0, b.d.k, b.d.s, gate_w};
     for (int q = 0; q < 11; ++q) dims[q] = v[q];
     return COSY_OK;
 }

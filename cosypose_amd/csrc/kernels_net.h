@@ -62,6 +62,11 @@ struct FuseArgs {
     const void* zeros;
     int B, H, W, Cin, Cmid, Ho, Wo, k, s, pad_lo;
 };
+// tiled variant (LDS tile per workgroup) for high-resolution blocks whose row width the wave kernel is not built for
+bool tile_supported(int Cin, int Cmid, int k, int s, int dtype);
+int tile_num_tiles(int Cin, int Ho, int Wo, int k, int s, int dtype);
+int launch_mbconv_tile(const FuseArgs& a, int dtype, hipStream_t s);
+void tile_kernel_name(int Cin, int k, int s, int dtype, char* buf, size_t n);
 // whole-image variant for the small maps of the late blocks (kernels_net.hip: mbconv_small_kernel); partial has ONE tile per sample
 bool small_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W);
 int launch_mbconv_small(const FuseArgs& a, int dtype, hipStream_t s);

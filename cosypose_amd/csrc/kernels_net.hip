@@ -625,6 +625,260 @@ int launch_dwconv(const DwArgs& a, int dtype, hipStream_t s) {
 }
 
 // ==========================================================================================
+// Tiled fused MBConv front (round 1's design): expand 1x1 (MFMA) + BN + SiLU -> LDS tile -> depthwise kxk + BN + SiLU + squeeze
+// partials, for the high-resolution blocks whose ROW WIDTH the wave kernel is not built for -- block 2 of the reference's native
+// 240x320 crops (160-pixel rows) and blocks 2-8 of crop sizes outside the two tuned ones.  The 6x-expanded tensor never touches
+// HBM.  A workgroup owns one (sample, TH x TW output tile):
+//   1. the halo'd input tile ((TH-1)s+k) x ((TW-1)s+k) pixels x Cin is DMA'd once into LDS in MFMA-fragment order
+//      (1 KiB blocks = 16 pixels x 32 k, lane-linear: one global_load_lds per block, zero page for padding);
+//   2. per chunk of 48 expanded channels: every wave runs the 1x1 expansion of a few 16-pixel blocks on the matrix
+//      cores (weights = MFMA A operand, so a lane ends up with 12 contiguous channels of one pixel), applies BN+SiLU,
+//      ZEROES pixels outside the image (the depthwise conv's padding acts on the expanded tensor) and parks the
+//      result in an fp32 LDS tile Et[pixel][48] (row pitch +16 B: conflict-free 16-byte writes);
+//   3. depthwise from Et (sliding window over rows), BN+SiLU, NHWC store, squeeze sums.
+// Cost: the expansion is recomputed on the halo (x1.2-1.9), and the phases alternate behind barriers -- which is why the wave
+// kernel replaced it wherever its row mapping fits (block 2 at 256 crops of 256x256: 554 -> 335 us).
+// ==========================================================================================
+// Bytes per pixel row of the LDS tile of expanded activations: +16 keeps the expand epilogue's 16-byte writes conflict-free.
+constexpr int et_pitch(int elem_size, int stride) { (void)stride; return 48 * elem_size + 16; }
+struct FusePlan { int TH, TW, THin, TWin, MB, kbn, threads, ntx, nty, et_f32; size_t lds; };
+static FusePlan fuse_plan(int Cin, int Ho, int Wo, int k, int s, int esz) {
+    FusePlan p;
+    const int R = s == 1 ? 4 : 2;
+    p.et_f32 = 1;                                  // the LDS tile that holds the expanded activations is fp32
+    const int ees = p.et_f32 ? 4 : 2;
+    if (s == 1) { p.TH = esz == 2 ? 8 : 4; p.TW = 16; }
+    else { p.TH = 4; p.TW = 8; }
+    if (p.TW > Wo) p.TW = Wo;
+    p.THin = (p.TH - 1) * s + k; p.TWin = (p.TW - 1) * s + k;
+    p.MB = (p.THin * p.TWin + 15) / 16;
+    p.kbn = cdiv(Cin, esz == 2 ? 32 : 16);
+    const int cpt = 16 / ees, units = (48 / cpt) * p.TW * (p.TH / R);
+    p.threads = ((units < 384 ? units : 384) + 63) / 64 * 64;
+    {   // enough waves for the expand phase too: at most 2 sixteen-pixel blocks per wave (COSY_FUSE_MBW, experiments)
+        static const int mbw = tune_int("COSY_FUSE_MBW", 0);
+        if (mbw > 0) { int t = cdiv(p.MB, mbw) * 64; if (t > 384) t = 384; if (t > p.threads) p.threads = t; }
+    }
+    p.lds = (size_t)p.MB * p.kbn * 1024 + (size_t)p.MB * 16 * et_pitch(ees, s) + (size_t)k * k * 48 * 4 + (size_t)p.threads * 8 * 4;
+    p.ntx = cdiv(Wo, p.TW); p.nty = cdiv(Ho, p.TH);
+    return p;
+}
+int tile_num_tiles(int Cin, int Ho, int Wo, int k, int s, int dtype) {
+    FusePlan p = fuse_plan(Cin, Ho, Wo, k, s, dtype == COSY_F32 ? 4 : 2);
+    return p.ntx * p.nty;
+}
+// shapes the tiled kernel is built for: up to 2 k-blocks of input channels (the high-resolution blocks), 48-channel chunks
+bool tile_supported(int Cin, int Cmid, int k, int s, int dtype) {
+    const int kbn = cdiv(Cin, dtype == COSY_F32 ? 16 : 32);
+    return dtype != COSY_F32 && Cmid % 48 == 0 && kbn <= 2 && (k == 3 || k == 5) && (s == 1 || s == 2);
+}
+
+struct FuseKArgs {
+    const void* X; const void* Wp; const float* s0; const float* b0; const float* dww; const float* s1; const float* b1;
+    void* D; float* partial; const void* zeros;
+    int H, W, Cin, Cmid, Ho, Wo, lo, TH, TW, THin, TWin, MB, ntx, n_tiles, nkb_total, dbg;
+    unsigned rcp_tw;   // ceil(2^16 / TWin): p / TWin == (p * rcp_tw) >> 16 for the tile's pixel range (checked on the host)
+};
+
+// T = storage type of X/D (and of the MFMA operands), ET = element type of the LDS tile of expanded activations
+template <typename T, typename ET, int KS, int S, int R, int KBN>
+__global__ __launch_bounds__(384) void mbconv_tile_kernel(FuseKArgs a) {
+    using raw_t = typename DT<T>::raw_t;
+    constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
+    constexpr int NI = 3, CC = 48;
+    constexpr int PITCH = et_pitch((int)sizeof(ET), S);  // bytes per Et pixel row: conflict-free depthwise reads
+    constexpr int CPT = 16 / (int)sizeof(ET);         // channels per depthwise thread (one 16-byte Et read)
+    constexpr int NG = CC / CPT;                      // channel groups per chunk
+    constexpr int NROW = (R - 1) * S + KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int TWin = a.TWin, Pin = a.THin * a.TWin, MB = a.MB;
+    char* Xt = smem;
+    char* Et = Xt + (size_t)MB * KBN * 1024;
+    float* wl = (float*)(Et + (size_t)MB * 16 * PITCH);
+    float* red = wl + KS * KS * CC;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthr >> 6;
+    const int job = blockIdx.x, tile_id = job % a.n_tiles, b = job / a.n_tiles;
+    const int tx = tile_id % a.ntx, ty = tile_id / a.ntx;
+    const int oy0 = ty * a.TH, ox0 = tx * a.TW;
+    const int iy0 = oy0 * S - a.lo, ix0 = ox0 * S - a.lo;
+    const int prow = lane & 15, kg = lane >> 4;
+
+    // ---- 1. DMA the input tile into LDS in fragment order
+    {
+        const T* __restrict__ X = (const T*)a.X + (size_t)b * a.H * a.W * a.Cin;
+        for (int blk = wave; blk < MB * KBN; blk += nwaves) {
+            const int mb = blk / KBN, kb = blk - mb * KBN;
+            const int p = mb * 16 + prow, k = kb * KB + kg * EPL;
+            const int yy = (int)(((unsigned)p * a.rcp_tw) >> 16), xx = p - yy * TWin, iy = iy0 + yy, ix = ix0 + xx;
+            const bool ok = p < Pin && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && k < a.Cin;
+            const void* src = ok ? (const void*)(X + ((size_t)iy * a.W + ix) * a.Cin + k) : a.zeros;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(Xt + (size_t)blk * 1024), 16, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int nchunks = a.Cmid / CC;
+    const int nyq = a.TH / R;
+    const int units = NG * a.TW * nyq;
+    const int stride = (nthr / NG) * NG;
+    const int cq = tid % NG;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        // taps of this chunk -> LDS
+        for (int i = tid; i < KS * KS * (CC / 4); i += nthr) {
+            const int tap = i / (CC / 4), q = i - tap * (CC / 4);
+            *(f32x4*)(wl + tap * CC + q * 4) = *(const f32x4*)(a.dww + (size_t)tap * a.Cmid + ch * CC + q * 4);
+        }
+        // ---- 2. expansion on the matrix cores -> Et
+        {
+            raw_t wf[NI][KBN];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int kb = 0; kb < KBN; ++kb)
+                    wf[ni][kb] = *(const raw_t*)((const T*)a.Wp + ((size_t)(ch * NI + ni) * a.nkb_total + kb) * 64 * EPL + lane * EPL);
+            const int n0 = ch * CC + kg * 4 * NI;   // this lane's 12 consecutive expanded channels
+            float sc[NI * 4], bi[NI * 4];
+#pragma unroll
+            for (int q = 0; q < NI; ++q) { load4(a.s0 + n0 + q * 4, sc + q * 4); load4(a.b0 + n0 + q * 4, bi + q * 4); }
+            for (int mb = wave; mb < (COSY_DBG(a.dbg & 2) ? 0 : MB); mb += nwaves) {
+                f32x4 acc[NI];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < KBN; ++kb) {
+                    const raw_t xf = *(const raw_t*)(Xt + (size_t)(mb * KBN + kb) * 1024 + lane * 16);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) mma(acc[ni], wf[ni][kb], xf);
+                }
+                const int p = mb * 16 + prow;
+                const int yy = (int)(((unsigned)p * a.rcp_tw) >> 16), xx = p - yy * TWin, iy = iy0 + yy, ix = ix0 + xx;
+                const bool inside = p < Pin && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                float y[NI * 4];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[ni][r] * sc[ni * 4 + r] + bi[ni * 4 + r];
+                        v = v * sigmoid_t<T>(v);
+                        y[ni * 4 + r] = inside ? v : 0.f;
+                    }
+                ET* dst = (ET*)(Et + (size_t)p * PITCH) + kg * 4 * NI;
+                if constexpr (sizeof(ET) == 2) { store8(dst, y); store4(dst + 8, y + 8); }
+                else { store4(dst, y); store4(dst + 4, y + 4); store4(dst + 8, y + 8); }
+            }
+        }
+        __syncthreads();
+        // ---- 3. depthwise from Et
+        float sum[CPT];
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) sum[c] = 0.f;
+        if (tid < stride && !COSY_DBG(a.dbg & 1)) {
+            const int c0 = ch * CC + cq * CPT;
+            float sc[CPT], bi[CPT];
+#pragma unroll
+            for (int c = 0; c < CPT; c += 4) { load4(a.s1 + c0 + c, sc + c); load4(a.b1 + c0 + c, bi + c); }
+            T* __restrict__ out = (T*)a.D + (size_t)b * a.Ho * a.Wo * a.Cmid + c0;
+#pragma unroll 1
+            for (int u = tid; u < units; u += stride) {
+                const int q = u / NG, x = q % a.TW, yq = q / a.TW;
+                const int ox = ox0 + x, oyb = oy0 + yq * R;
+                if (ox >= a.Wo || oyb >= a.Ho) continue;
+                float acc[R][CPT];
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int c = 0; c < CPT; ++c) acc[r][c] = 0.f;
+#pragma unroll 1
+                for (int kx = 0; kx < KS; ++kx) {
+                    float wc[KS][CPT];
+#pragma unroll
+                    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                        for (int c = 0; c < CPT; c += 4) load4(wl + (ky * KS + kx) * CC + cq * CPT + c, wc[ky] + c);
+                    const char* col = Et + ((size_t)(yq * R * S) * TWin + x * S + kx) * PITCH + cq * 16;
+#pragma unroll
+                    for (int rr = 0; rr < NROW; ++rr) {
+                        float v[CPT];
+                        if constexpr (sizeof(ET) == 2) lds_ld8((const ET*)(col + (size_t)rr * TWin * PITCH), v);
+                        else load4((const float*)(col + (size_t)rr * TWin * PITCH), v);
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const int ky = rr - r * S;
+                            if (ky >= 0 && ky < KS) {
+#pragma unroll
+                                for (int c = 0; c < CPT; ++c) acc[r][c] += wc[ky][c] * v[c];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int oy = oyb + r;
+                    if (oy < a.Ho) {
+                        float y[CPT];
+#pragma unroll
+                        for (int c = 0; c < CPT; ++c) {
+                            float v = acc[r][c] * sc[c] + bi[c];
+                            v = v * sigmoid_t<T>(v);
+                            y[c] = v;
+                            sum[c] += v;
+                        }
+                        T* o = out + ((size_t)oy * a.Wo + ox) * a.Cmid;
+                        if constexpr (CPT == 8) store8(o, y); else store4(o, y);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) red[tid * CPT + c] = sum[c];
+        __syncthreads();
+        reduce_squeeze_sums(red, stride, NG, CPT, tid, nthr, a.partial + ((size_t)b * a.n_tiles + tile_id) * a.Cmid + ch * CC);
+        // next chunk: its Et writes happen after this barrier's readers are done (all Et reads precede the barrier above);
+        // `red` is rewritten only after the next chunk's first barrier.
+    }
+}
+
+template <typename T, typename ET, int KBN>
+static int launch_fuse_k(const FuseArgs& a, const FusePlan& p, const FuseKArgs& k, hipStream_t s) {
+    dim3 grid((unsigned)(k.n_tiles * a.B)), block(p.threads);
+    if (a.k == 3 && a.s == 1) hipLaunchKernelGGL((mbconv_tile_kernel<T, ET, 3, 1, 4, KBN>), grid, block, p.lds, s, k);
+    else if (a.k == 3 && a.s == 2) hipLaunchKernelGGL((mbconv_tile_kernel<T, ET, 3, 2, 2, KBN>), grid, block, p.lds, s, k);
+    else if (a.k == 5 && a.s == 1) hipLaunchKernelGGL((mbconv_tile_kernel<T, ET, 5, 1, 4, KBN>), grid, block, p.lds, s, k);
+    else if (a.k == 5 && a.s == 2) hipLaunchKernelGGL((mbconv_tile_kernel<T, ET, 5, 2, 2, KBN>), grid, block, p.lds, s, k);
+    else { set_error("mbconv_tile: unsupported k=%d s=%d", a.k, a.s); return COSY_EINVAL; }
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+template <typename T>
+static int launch_tile_t(const FuseArgs& a, hipStream_t s) {
+    const FusePlan p = fuse_plan(a.Cin, a.Ho, a.Wo, a.k, a.s, sizeof(T));
+    FuseKArgs k;
+    k.X = a.X; k.Wp = a.Wp; k.s0 = a.s0; k.b0 = a.b0; k.dww = a.dww; k.s1 = a.s1; k.b1 = a.b1; k.D = a.D; k.partial = a.partial;
+    k.zeros = a.zeros; k.H = a.H; k.W = a.W; k.Cin = a.Cin; k.Cmid = a.Cmid; k.Ho = a.Ho; k.Wo = a.Wo; k.lo = a.pad_lo;
+    k.TH = p.TH; k.TW = p.TW; k.THin = p.THin; k.TWin = p.TWin; k.MB = p.MB; k.ntx = p.ntx; k.n_tiles = p.ntx * p.nty;
+    k.nkb_total = pw_nkb_total(a.Cin, sizeof(T) == 4 ? COSY_F32 : COSY_BF16);   // k-block geometry depends on the element size only
+    k.rcp_tw = (65536u + p.TWin - 1) / p.TWin;
+    static const int dbg = tune_int("COSY_FUSE_DBG", 0);   // phase knock-out, timing experiments only
+    k.dbg = dbg;
+    for (int q = 0; q < p.MB * 16; ++q)
+        if ((int)(((unsigned)q * k.rcp_tw) >> 16) != q / p.TWin) { set_error("mbconv_tile: reciprocal division inexact"); return COSY_EINVAL; }
+    if (p.kbn == 1) return launch_fuse_k<T, float, 1>(a, p, k, s);
+    return launch_fuse_k<T, float, 2>(a, p, k, s);
+}
+
+void tile_kernel_name(int Cin, int k, int s, int dtype, char* buf, size_t n) {
+    snprintf(buf, n, "mbconv_tile_kernel<%s, float, %d, %d, %d, %d>", dtype == COSY_BF16 ? "__bf16" : "_Float16", k, s, s == 1 ? 4 : 2, cdiv(Cin, 32));
+}
+int launch_mbconv_tile(const FuseArgs& a, int dtype, hipStream_t s) {
+    if (a.B == 0) return COSY_OK;
+    COSY_REQUIRE(tile_supported(a.Cin, a.Cmid, a.k, a.s, dtype), "mbconv_tile: unsupported shape Cin=%d Cmid=%d k=%d s=%d", a.Cin, a.Cmid, a.k, a.s);
+    return dtype == COSY_BF16 ? launch_tile_t<bf16_t>(a, s) : launch_tile_t<f16_t>(a, s);
+}
+
+// ==========================================================================================
 // Fused MBConv front for the SMALL maps of the late blocks (H*W <= 320 pixels, Cin up to 384):
 // expand 1x1 (MFMA) + BN + SiLU -> LDS -> depthwise kxk + BN + SiLU + squeeze sums; the 6x-expanded tensor never touches HBM.
 // (The larger maps run the wave-autonomous kernel of kernels_wave.hip; shapes neither kernel is built for run unfused:
@@ -632,7 +886,6 @@ int launch_dwconv(const DwArgs& a, int dtype, hipStream_t s) {
 // ==========================================================================================
 // Bytes per pixel row of the LDS tile of expanded activations: +16 keeps the expand epilogue's 16-byte writes (16 pixels
 // per instruction, one pitch apart) conflict-free.
-constexpr int et_pitch(int elem_size, int stride) { (void)stride; return 48 * elem_size + 16; }
 static bool fuse_use_small(int Cin, int Cmid, int H, int W, int Ho, int Wo, int k, int s, int dtype);
 static int conv_out(int in, int k, int s) { return s == 1 ? in : (in - 2) / 2 + 1; }   // static same padding (image_size 300)
 // H, W = the block's input map

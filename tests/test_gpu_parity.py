@@ -213,7 +213,7 @@ ULP = {'bf16': 2.0 ** -7, 'fp16': 2.0 ** -10}
 L2_TOL = {'bf16': 6e-4, 'fp16': 1.5e-4}   # relative L2 per tensor, block-local comparison (measured worst: 3.4e-4 / 7.7e-5)
 
 
-@pytest.mark.parametrize('hw', [(256, 256), (240, 320), (192, 256)], ids=['256x256', '240x320', '192x256'])
+@pytest.mark.parametrize('hw', [(256, 256), (240, 320), (192, 256), (224, 224)], ids=['256x256', '240x320', '192x256', '224x224'])
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
 def test_fused_kernels_vs_storage_emulation(model, oracle, golden_sd, dtype, hw):
     """The kernels that set the headline (mbconv_wave_kernel, mbconv_small_kernel, the gated pw_gemm_dma, stem, dwconv in their
@@ -225,16 +225,19 @@ def test_fused_kernels_vs_storage_emulation(model, oracle, golden_sd, dtype, hw)
     asserted as (1) relative L2 error per tensor (a one-pixel halo or padding slip in any variant shows up as >= 1e-2), (2) no
     element further than 1.5 storage ulps of the tensor's scale away (measured: < 0.8), (3) gates (fp32 on both sides) within 5e-6.  256x256 and
     240x320 reach every fused variant (FULLW and !FULLW wave kernels, row-mapped and plain small kernels, weight- and
-    row-side gates); 192x256 is a size the schedule was not tuned for (other wave variants by width, generic unfused blocks).
+    row-side gates, the tiled kernel on block 2 of 240x320); 192x256 and 224x224 are sizes the schedule was not tuned for (wave variants
+    by width / the tiled kernel on blocks 2-5 and 8, generic unfused blocks).
     (End to end the two evaluations decorrelate with depth -- see TorchRef.extract_features_emulated -- which is why the
     comparison is local.)"""
     B = 3
     x = np.random.RandomState(40 + hw[0]).random_sample((B, 6) + tuple(hw)).astype(np.float32)
     h, plan = _block_plan(model, hw, dtype, B)
     kinds = [p[7] for p in plan]
-    if hw != (192, 256):     # blocks 3-17 wave (block 2 too at 256x256; its 160-pixel rows at 240x320 are not built), 19-25 small
+    if hw in ((256, 256), (240, 320)):     # blocks 3-17 wave, 19-25 small; block 2: wave at 256x256, tiled at 240x320 (160-pixel rows)
         assert all(k == 1 for k in kinds[3:18]) and all(k == 2 for k in kinds[19:26]) and kinds[18] == 0, kinds
-        assert kinds[2] == (1 if hw == (256, 256) else 0)
+        assert kinds[2] == (1 if hw == (256, 256) else 3)
+    if hw == (224, 224):                   # widths 112 / 56 / 28: no wave variant -> the tiled kernel on blocks 2-5 and 8 (all four k / stride forms)
+        assert [i for i, k in enumerate(kinds) if k == 3] == [2, 3, 4, 5, 8] and not any(k in (1, 2) for k in kinds), kinds
     from cosypose_amd._lib import lib, check, ptr, stream
     check(lib().cosy_effnet_b3_set_input_nchw(h, ptr(dev(x)), B, stream()))
     tr = oracle.TorchRef(golden_sd)
@@ -263,7 +266,7 @@ def test_fused_kernels_vs_storage_emulation(model, oracle, golden_sd, dtype, hw)
         compare('head', head, tr.head_emulated(T(cur), dtype))
     print(f'{dtype} {hw} fronts {"".join(str(k) for k in kinds)} | tensor: L2 / max storage ulps | ' + ' '.join(f'{l}:{a:.1e}/{u:.1f}' for l, a, u in rows))
     assert not bad, bad
-    if hw != (192, 256):
+    if hw in ((256, 256), (240, 320)):
         name = '%dx%d' % hw
         # and where the storage type itself puts the result relative to the reference's fp32 (informative; bound = 3x measured)
         x2 = np.random.RandomState(21 if hw == (240, 320) else 22).random_sample((2, 6) + tuple(hw)).astype(np.float32)
