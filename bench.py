@@ -29,6 +29,7 @@ that file was collected for the same kernel sources (its `csrc_sha` matches the 
 median of 5 repeats, at 1 thread (the reference pins OMP_NUM_THREADS=1) and at N threads.
 """
 import argparse
+import gc
 import hashlib
 import json
 import os
@@ -44,6 +45,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s 
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0, 'fp32': 157.3}
 ALGO_MB_PER_POSE_ITER = {('bf16', 256): 10.7, ('fp16', 256): 10.7, ('fp32', 256): 21.3, ('bf16', 240): 12.4, ('fp16', 240): 12.4, ('fp32', 240): 24.9}
 SKEW = [512, 384, 320, 256, 224, 160, 128, 64]
+DEFAULT_STREAMS = 1
 
 
 class SyntheticRenderer:
@@ -162,6 +164,9 @@ def main():
     ap.add_argument('--bsz-objects', type=int, default=None,
                     help='crops per forward: default 256 for config 1 (BASELINE configs[1] names batch=256), 512 for configs 2 and 3 '
                          '(their batches are 1024 / 2048 candidates; 512 per forward measured +9 %% over 256, profiles/r02_batch_sweep.txt)')
+    ap.add_argument('--streams', type=int, default=None,
+                    help='HIP streams the chunks of a stage run on concurrently (CoarseRefinePosePredictor n_streams); with N > 1 and no '
+                         '--bsz-objects the candidates of a rank are cut into N equal chunks')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-dtypes', action='store_true', help='skip the bf16 / fp32 repeats of the timed loop and the deviation pass')
     ap.add_argument('--no-profile', action='store_true', help='skip the per-kernel HIP-event pass (no roofline object)')
@@ -225,9 +230,12 @@ def main():
         per_rank = [len(p) for p in plan_shards(D, world, **plan_kw)]
         desc = (f'BASELINE configs[3]: {D} candidates over 7 datasets (5x 640x480, 720x540, 1280x960 frames), {n_obj} objects, '
                 f'{args.split} shares {per_rank}')
+    full_bsz = 256 if cfg_i == 1 else 512          # crops per forward of the single-stream schedule (and of the per-kernel event pass)
+    if args.streams is None:
+        args.streams = DEFAULT_STREAMS
     if args.bsz_objects is None:
-        args.bsz_objects = 256 if cfg_i == 1 else 512
-    cap = min(max(per_rank), args.bsz_objects)
+        args.bsz_objects = full_bsz if args.streams <= 1 else max(16, -(-min(max(per_rank), full_bsz) // args.streams))
+    cap = min(max(per_rank), max(args.bsz_objects, full_bsz))
     g = torch.Generator(device='cuda'); g.manual_seed(1 + rank)
     renders = [torch.rand(cap, 3, H, W, device='cuda', generator=g) for _ in range(5)]
     renderer = SyntheticRenderer(renders)
@@ -237,7 +245,7 @@ def main():
         renderer = HipBatchRenderer(RenderMeshes(labels, mv, mf, mc).cuda())
     coarse = build_model(0, mesh_db, (H, W), dtype, renderer)
     refiner = build_model(1, mesh_db, (H, W), dtype, renderer)
-    predictor = CoarseRefinePosePredictor(coarse_model=coarse, refiner_model=refiner, bsz_objects=args.bsz_objects)
+    predictor = CoarseRefinePosePredictor(coarse_model=coarse, refiner_model=refiner, bsz_objects=args.bsz_objects, n_streams=args.streams)
     iters_total = total * (n_coarse + n_refine)
     gather_us = []
     use_dist = dist.is_available() and dist.is_initialized()     # world > 1, or a forced 1-rank RCCL group (COSY_FORCE_DIST=1)
@@ -266,9 +274,14 @@ def main():
         out = step()
     assert torch.isfinite(out).all(), 'non-finite refined poses'
     assert out.shape == (total, 4, 4)
-    nets = [m._net(cap, out.device) for m in ([refiner] if cfg_i == 2 else [coarse, refiner])]
     profile = not args.no_profile
     gather_us.clear()
+    # Python's cyclic collector: a full (generation 2) pass over the process's ~10^6 long-lived objects (torch, pandas) takes
+    # ~60 ms of host time on this box (profiles/exp/gcprobe.py) -- 2.5 steps of GPU work, and the host only leads the GPU by
+    # a few steps.  The long-lived objects are moved to the permanent generation, so passes during the steps only look at what
+    # the steps allocate.
+    gc.collect()
+    gc.freeze()
     sync()
     t0 = time.perf_counter()
     host_ms = []
@@ -294,13 +307,19 @@ def main():
     # Per-kernel timing for `roofline`: the SAME steps again with a HIP event recorded on the launch stream after every
     # backbone launch.  Kept out of the timed region on purpose: one event per kernel serialises back-to-back
     # launches and costs ~6 % of the headline value (measured 34.4k vs 32.3k pose-iter/s).
+    # With --streams > 1 this pass runs the single-stream schedule (one launch of `full_bsz` crops per kernel): under
+    # concurrency a kernel's start-to-end time includes the other chunks' kernels sharing the chip and is not a kernel property.
     prof_steps = min(args.steps, 4)
+    prof_bsz = min(max(per_rank), full_bsz)
     if profile:
+        predictor.n_streams, predictor.bsz_objects = 1, prof_bsz
+        nets = [m._net(prof_bsz, out.device) for m in ([refiner] if cfg_i == 2 else [coarse, refiner])]
         for n_ in nets:
             _lib.check(_lib.lib().cosy_effnet_b3_set_profiling(n_, 1))
         for _ in range(prof_steps):
             step()
         sync()
+        predictor.n_streams, predictor.bsz_objects = args.streams, args.bsz_objects
 
     roofline = None
     if profile and rank == 0:
@@ -360,6 +379,9 @@ def main():
                 note = 'profiles/r03_pmc_traffic.json was collected for other kernel sources: not reported'
         roofline['traffic_source'] = note
         roofline['backbone_ms_per_forward'] = round(total_ms / max(n_fw, 1), 3)
+        roofline['launch'] = (f'{prof_bsz} crops per launch, timed with one HIP event per launch in a single-stream pass after the timed region' +
+                              (f'; the timed region runs the same kernels as {args.streams} concurrent streams of {args.bsz_objects}-crop launches'
+                               if args.streams > 1 else ''))
 
     # ---- the same timed loop in the other storage types, and the benched type's pose deviation from the fp32 HIP path
     other, deviation = {}, None
@@ -421,7 +443,7 @@ def main():
             'config': {'workload': desc + f', coarse {n_coarse} + refiner {n_refine} iterations, {H}x{W} crops, ' +
                                    ('synthetic on-device renders' if args.renderer == 'pregenerated' else
                                     'renders by the on-device HIP rasteriser (6k-triangle meshes) inside the loop'),
-                       'pose_iterations_per_step': iters_total, 'candidates_per_rank': per_rank, 'bsz_objects': args.bsz_objects,
+                       'pose_iterations_per_step': iters_total, 'candidates_per_rank': per_rank, 'bsz_objects': args.bsz_objects, 'streams': args.streams,
                        'parallelism': f'candidate-sharded x{world}, 1 all-gather of refined poses per step' + (' (RCCL, forced 1-rank group)' if use_dist and world == 1 else ''),
                        'all_gather_us': round(float(np.median(gather_us)), 1) if gather_us else None},
             'roofline': roofline,

@@ -62,10 +62,10 @@ class EfficientNet(nn.Module):
 
     def forward(self, inputs):
         """(B,6,H,W) fp32 NCHW -> (B,1536,h,w) fp32, via a standalone engine (no pose head)."""
-        eng = getattr(self, '_engine', None)
-        if eng is None:
-            eng = self.__dict__['_engine'] = NetEngine(self, None)
-        return eng.features(inputs)
+        pool = getattr(self, '_engines', None)
+        if pool is None:
+            pool = self.__dict__['_engines'] = EnginePool(self, None)
+        return pool.current(inputs.device).features(inputs)
 
 
 def flat_params(backbone, pose_fc):
@@ -89,6 +89,28 @@ def flat_params(backbone, pose_fc):
     blob = torch.cat([p.detach().reshape(-1).to('cpu', torch.float32) for p in parts]).contiguous()
     assert blob.numel() == arch.param_count()
     return blob, parts
+
+
+class EnginePool:
+    """One NetEngine per HIP stream: an engine's activations and workspaces are private to the forward that is running on
+    it, so forwards issued on different streams (CoarseRefinePosePredictor's concurrent chunks, or a caller's own streams)
+    each get their own and may overlap on the device.  Keyed by the raw stream handle (0 = the default stream)."""
+
+    def __init__(self, backbone, pose_fc):
+        self.backbone, self.pose_fc = backbone, pose_fc
+        self.engines = {}
+
+    def current(self, device=None):
+        key = (torch.device(device).index if device is not None else None, torch.cuda.current_stream(device).cuda_stream)
+        eng = self.engines.get(key)
+        if eng is None:
+            eng = self.engines[key] = NetEngine(self.backbone, self.pose_fc)
+        return eng
+
+    def release(self):
+        for eng in self.engines.values():
+            eng.release()
+        self.engines.clear()
 
 
 class NetEngine:

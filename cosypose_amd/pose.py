@@ -15,7 +15,7 @@ from torch import nn
 
 from . import lib3d, arch, train_engine
 from ._lib import lib, check, ptr, stream, require_device, ints_to_device, CosyHipError, COSY_F32
-from .efficientnet import NetEngine
+from .efficientnet import EnginePool
 
 
 class PosePredictor(nn.Module):
@@ -36,7 +36,7 @@ class PosePredictor(nn.Module):
         self.tmp_debug = dict()
         self.compute_dtype = 'fp32'
         self.drop_connect_rate = train_engine.DROP_CONNECT_RATE   # train mode only (efficientnet.py:182-185)
-        self.__dict__['_engine'] = NetEngine(backbone, self.pose_fc)
+        self.__dict__['_engines'] = EnginePool(backbone, self.pose_fc)   # one engine per HIP stream
 
     def enable_debug(self):
         self.debug = True
@@ -72,7 +72,7 @@ class PosePredictor(nn.Module):
 
     def _net(self, B, device):
         H, W = self.render_size
-        return self._engine.ensure(B, H, W, self.compute_dtype, device)
+        return self._engines.current(device).ensure(B, H, W, self.compute_dtype, device)
 
     def net_forward(self, x, return_features=False):
         """x = cat(images_crop, renders) (B,6,H,W) -> {'pose': (B,9)}."""

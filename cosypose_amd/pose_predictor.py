@@ -5,7 +5,12 @@ same PandasTensorCollections under the same keys ('coarse/iteration=k', 'refiner
 MI355X-first differences, invisible to callers: detections are processed in chunks of `bsz_objects` in their given order as
 in the reference (:30-33), but the frames are handed over ONCE and indexed per object on the device (the reference
 replicates them with images[im_ids], :41); consecutive-row chunks are tensor views; the default of 64 objects per chunk is
-kept for drop-in parity and can be raised (288 GB of HBM holds thousands of crops in flight).
+kept for drop-in parity and can be raised (288 GB of HBM holds thousands of crops in flight).  With `n_streams` > 1 the
+chunks run CONCURRENTLY, round-robin on that many HIP streams, each chunk through coarse and refiner on its own stream
+(every stream has its own engine: activations and workspaces are per stream, cosypose_amd/efficientnet.py EnginePool): a
+forward is ~100 dependent kernel launches, and the ramp-up / drain of each overlaps with another chunk's kernels instead of
+idling the chip.  The chunks are independent (the kernels are batch-invariant), so the results are bit-identical to the
+sequential order.  Keep n_streams <= 3: ROCm maps streams onto 4 hardware queues, the caller's stream holds one.
 """
 import numpy as np
 import torch
@@ -18,17 +23,33 @@ _ITERATION_FIELDS = (('poses', 'TCO_output'), ('poses_input', 'TCO_input'), ('K_
                      ('boxes_rend', 'boxes_rend'), ('boxes_crop', 'boxes_crop'))
 
 
+_ITERATION_SHAPES = (('poses', (4, 4)), ('poses_input', (4, 4)), ('K_crop', (3, 3)), ('boxes_rend', (4,)), ('boxes_crop', (4,)))
+
+
 def _iteration_key(n):
     return f'iteration={n}'
 
 
+def _iteration_collection(infos, outputs):
+    return tc.PandasTensorCollection(infos, **{name: outputs[source] for name, source in _ITERATION_FIELDS})
+
+
 class CoarseRefinePosePredictor(torch.nn.Module):
-    def __init__(self, coarse_model=None, refiner_model=None, bsz_objects=64):
+    def __init__(self, coarse_model=None, refiner_model=None, bsz_objects=64, n_streams=1):
         super().__init__()
         self.coarse_model = coarse_model
         self.refiner_model = refiner_model
         self.bsz_objects = bsz_objects
+        self.n_streams = n_streams
+        self.__dict__['_lanes'] = {}
         self.eval()
+
+    def _lane_streams(self, device, n):
+        """n side streams of `device` (created once, reused by every call)"""
+        lanes = self._lanes.setdefault(torch.device(device).index, [])
+        while len(lanes) < n:
+            lanes.append(torch.cuda.Stream(device=device))
+        return lanes[:n]
 
     @torch.no_grad()
     def batched_model_predictions(self, model, images, K, obj_data, n_iterations=1):
@@ -40,9 +61,41 @@ class CoarseRefinePosePredictor(torch.nn.Module):
             outputs = model(images=images, K=K, TCO=chunk.poses, n_iterations=n_iterations,
                             labels=chunk.infos['label'].values, im_ids=chunk.infos['batch_im_id'].values)
             for key, collected in per_iteration.items():
-                fields = {name: outputs[key][source] for name, source in _ITERATION_FIELDS}
-                collected.append(tc.PandasTensorCollection(chunk.infos, **fields))
+                collected.append(_iteration_collection(chunk.infos, outputs[key]))
         return {key: tc.concatenate(parts) for key, parts in per_iteration.items()}
+
+    @torch.no_grad()
+    def _concurrent_predictions(self, images, K, start, stages):
+        """The chunks of `start` each run ALL `stages` = [(name, model, n_iterations)] on their own HIP stream (round-robin over
+        n_streams side streams): a chunk's refiner input is its own coarse output, so nothing crosses streams until the one
+        join at the end.  Every chunk writes its rows straight into the full-size result tensors (allocated up front on the
+        caller's stream), so the caller's stream has nothing to do behind the join: no per-key concatenation on the critical
+        path between two calls.  Returns {'stage/iteration=k': collection}."""
+        n_objects = len(start)
+        firsts = range(0, n_objects, self.bsz_objects)
+        device = start.poses.device
+        lanes = self._lane_streams(device, min(int(self.n_streams), len(firsts)))
+        main = torch.cuda.current_stream(device)
+        keys = [f'{name}/{_iteration_key(n)}' for name, _, n_it in stages for n in range(1, n_it + 1)]
+        full = {key: {name: torch.empty((n_objects,) + shape, device=device) for name, shape in _ITERATION_SHAPES} for key in keys}
+        for lane in lanes:
+            lane.wait_stream(main)             # frames, K and the initial poses are ready on `main`
+        for i, first in enumerate(firsts):
+            last = min(first + self.bsz_objects, n_objects)
+            chunk = start[np.arange(first, last)]
+            labels, im_ids = chunk.infos['label'].values, chunk.infos['batch_im_id'].values
+            with torch.cuda.stream(lanes[i % len(lanes)]):
+                poses = chunk.poses
+                for name, model, n_it in stages:
+                    outputs = model(images=images, K=K, TCO=poses, n_iterations=n_it, labels=labels, im_ids=im_ids)
+                    for n in range(1, n_it + 1):
+                        out_n, rows = outputs[_iteration_key(n)], full[f'{name}/{_iteration_key(n)}']
+                        for field, source in _ITERATION_FIELDS:
+                            rows[field][first:last].copy_(out_n[source])
+                    poses = outputs[_iteration_key(n_it)]['TCO_output']
+        for lane in lanes:
+            main.wait_stream(lane)
+        return {key: tc.PandasTensorCollection(start.infos, **full[key]) for key in keys}
 
     def make_TCO_init(self, detections, K):
         """Initial poses from 2D boxes: 'v0' (identity rotation at 1 m) or 'z-up+auto-depth' (cosypose_ops.py:121-173)."""
@@ -58,6 +111,21 @@ class CoarseRefinePosePredictor(torch.nn.Module):
     def get_predictions(self, images, K, detections=None, data_TCO_init=None,
                         n_coarse_iterations=1, n_refiner_iterations=1):
         preds = dict()
+        n_objects = len(detections if data_TCO_init is None else data_TCO_init)
+        if self.n_streams > 1 and n_objects > self.bsz_objects:
+            if data_TCO_init is None:
+                assert detections is not None and self.coarse_model is not None and n_coarse_iterations > 0
+                start = self.make_TCO_init(detections, K)
+                stages = [('coarse', self.coarse_model, n_coarse_iterations)]
+            else:
+                assert n_coarse_iterations == 0
+                start = preds['external_coarse'] = data_TCO_init
+                stages = []
+            if n_refiner_iterations >= 1:
+                assert self.refiner_model is not None
+                stages.append(('refiner', self.refiner_model, n_refiner_iterations))
+            preds.update(self._concurrent_predictions(images, K, start, stages))
+            return (preds[f'{stages[-1][0]}/{_iteration_key(stages[-1][2])}'] if stages else start), preds
 
         def run_stage(stage, model, start, n_iterations):
             out = self.batched_model_predictions(model, images, K, start, n_iterations=n_iterations)

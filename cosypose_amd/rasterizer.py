@@ -96,7 +96,7 @@ class HipBatchRenderer:
         self.light = tuple(float(v) for v in l)
         self.shade = Shade(self.ambient, self.diffuse, float(cfg['specular']), float(cfg['shininess']), (ctypes.c_float * 3)(*self.light),
                            1 if cfg['light_frame'] == 'object' else 0, int(bool(cfg['smooth'])), int(bool(cfg['quantize'])))
-        self._scratch = None
+        self._scratch = {}       # per HIP stream: renders issued on different streams may overlap
 
     def _prepare(self, obj_infos, TCO, K, H, W):
         m = self.meshes
@@ -108,30 +108,32 @@ class HipBatchRenderer:
         dev = TCO.device
         obj = ints_to_device(np.fromiter((m.label_to_id[o['name']] for o in obj_infos), dtype=np.int32, count=bsz), dev)
         need = lib().cosy_render_scratch_bytes(bsz, m.verts.shape[1], H, W)
-        if self._scratch is None or self._scratch.numel() < need or self._scratch.device != dev:
-            self._scratch = torch.empty(need, dtype=torch.uint8, device=dev)
-        return TCO, K, obj, bsz, dev
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        scratch = self._scratch.get(key)
+        if scratch is None or scratch.numel() < need:
+            scratch = self._scratch[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+        return TCO, K, obj, bsz, dev, scratch
 
     def render(self, obj_infos, TCO, K, resolution=(240, 320), render_depth=False):
         H, W = min(resolution), max(resolution)          # bullet_batch_renderer.py:34: images are (min(res), max(res))
-        TCO, K, obj, bsz, dev = self._prepare(obj_infos, TCO, K, H, W)
+        TCO, K, obj, bsz, dev, scratch = self._prepare(obj_infos, TCO, K, H, W)
         rgb = torch.empty(bsz, 3, H, W, device=dev)
         depth = torch.empty(bsz, H, W, device=dev) if render_depth else None
         mesh = self.meshes.c_struct()
         check(lib().cosy_render_meshes_ex(ctypes.byref(mesh), ctypes.byref(self.shade), ptr(obj), ptr(TCO), ptr(K), bsz, H, W, ptr(rgb),
-                                          ptr(depth), ptr(self._scratch), stream()))
+                                          ptr(depth), ptr(scratch), stream()))
         return (rgb, depth) if render_depth else rgb
 
     def render_crop_pack(self, obj_infos, TCO, K_crop, frames4, im_ids, boxes_crop, resolution, net=None, x8=None, dtype=None):
         """Render + crop + pack in one pass (cosy_render_crop_pack): writes the network's NHWC8 input -- of the inference
         engine `net`, or the caller's buffer `x8` of element type `dtype` -- without materialising the render."""
         H, W = resolution
-        TCO, K_crop, obj, bsz, dev = self._prepare(obj_infos, TCO, K_crop, H, W)
+        TCO, K_crop, obj, bsz, dev, scratch = self._prepare(obj_infos, TCO, K_crop, H, W)
         n_im, h, w = frames4.shape[0], frames4.shape[1], frames4.shape[2]
         mesh = self.meshes.c_struct()
         if net is not None:
             check(lib().cosy_render_crop_pack(net, ctypes.byref(mesh), ctypes.byref(self.shade), ptr(obj), ptr(TCO), ptr(K_crop), ptr(frames4),
-                                              ptr(im_ids), ptr(boxes_crop), bsz, n_im, h, w, ptr(self._scratch), stream()))
+                                              ptr(im_ids), ptr(boxes_crop), bsz, n_im, h, w, ptr(scratch), stream()))
         else:
             check(lib().cosy_render_crop_pack_to(ptr(x8), dtype, ctypes.byref(mesh), ctypes.byref(self.shade), ptr(obj), ptr(TCO), ptr(K_crop),
-                                                 ptr(frames4), ptr(im_ids), ptr(boxes_crop), bsz, n_im, h, w, H, W, ptr(self._scratch), stream()))
+                                                 ptr(frames4), ptr(im_ids), ptr(boxes_crop), bsz, n_im, h, w, H, W, ptr(scratch), stream()))

@@ -19,6 +19,9 @@ python bench.py --config 3 --no-cpu-baseline > $OUT/bench_config3_skewed.json 2>
 python bench.py --config 3 --split balanced --no-cpu-baseline > $OUT/bench_config3_balanced.json 2> /dev/null
 python bench.py --crop 240x320 --no-cpu-baseline > $OUT/bench_240x320.json 2> /dev/null
 python bench.py --renderer hip --no-cpu-baseline > $OUT/bench_renderer_hip.json 2> /dev/null
+# 3b. chunks on concurrent HIP streams (CoarseRefinePosePredictor n_streams): opt-in, measured beside the single-stream default
+python bench.py --streams 2 --no-cpu-baseline --no-other-dtypes --no-profile > $OUT/bench_streams2.json 2> /dev/null
+python bench.py --config 3 --split balanced --streams 3 --bsz-objects 128 --no-cpu-baseline --no-other-dtypes --no-profile > $OUT/bench_config3_balanced_streams3.json 2> /dev/null
 python bench_train.py --kernels > $OUT/bench_train.json 2> $OUT/bench_train_kernels.txt
 # 4. rocprofv3 stats + PMC passes of the headline command
 bash profiles/collect.sh $TAG > $OUT/collect.log 2>&1

@@ -1112,6 +1112,22 @@ def test_refinement_loop_with_on_device_renderer(golden_sd):
     m.renderer = RenderOnly(renderer)
     final2, _ = pred.get_predictions(images, K, detections=det, n_coarse_iterations=1, n_refiner_iterations=2)
     assert torch.equal(final2.poses, final.poses)
+    # chunks of a stage on concurrent HIP streams (n_streams): 7 detections as 4 chunks of 2 on 3 streams, each stream with its
+    # own engine and render scratch -> bit-identical to the sequential schedule above, also when the streams' engines are reused
+    m.renderer = renderer
+    pred3 = CoarseRefinePosePredictor(coarse_model=m, refiner_model=m, bsz_objects=2, n_streams=3)
+    for dtype in ('fp32', 'fp16'):
+        m.compute_dtype = dtype
+        want, want_all = pred.get_predictions(images, K, detections=det, n_coarse_iterations=1, n_refiner_iterations=2)
+        for _ in range(2):
+            got, got_all = pred3.get_predictions(images, K, detections=det, n_coarse_iterations=1, n_refiner_iterations=2)
+            torch.cuda.synchronize()
+            assert list(got_all) == list(want_all) and list(got.infos['label']) == list(want.infos['label'])
+            for k in want_all:
+                for tname in ('poses', 'poses_input', 'K_crop', 'boxes_rend', 'boxes_crop'):
+                    assert torch.equal(getattr(got_all[k], tname), getattr(want_all[k], tname)), (dtype, k, tname)
+    m.compute_dtype = 'fp32'
+    assert len(m._engines.engines) >= 4          # the default stream's engine + one per side stream
 
 
 def test_crop_pack_all_window_paths(oracle):
