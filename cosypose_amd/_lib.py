@@ -106,8 +106,10 @@ def lib():
     global _lib
     if _lib is None:
         path = LIB
-        if os.environ.get('COSY_TUNE_LIB'):       # experiments only: the -DCOSY_TUNE build that reads COSY_* knobs
-            from .build import TUNE_LIB as path
+        if os.environ.get('COSY_TUNE_LIB'):       # experiments only: the -DCOSY_TUNE build that reads COSY_* knobs (or, for A/B
+            from .build import TUNE_LIB as path   # runs inside one gpurun call, another build of it given by its path)
+            if os.environ['COSY_TUNE_LIB'].endswith('.so'):
+                path = os.environ['COSY_TUNE_LIB']
         if not os.path.exists(path):
             raise CosyHipError(f'{path} not found: build it with `python -m cosypose_amd.build` '
                                '(or __graft_entry__.build()); cosypose_amd has no CPU / eager fallback')

@@ -12,9 +12,13 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libcosyhip.so')
 SOURCES = ['kernels_geom.hip', 'kernels_dist.hip', 'kernels_raster.hip', 'kernels_train.hip', 'kernels_net.hip',
-           'kernels_wave.hip', 'effnet.hip']
+           'kernels_dw.hip', 'kernels_wave.hip', 'effnet.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+# Per-file flags.  kernels_wave.hip: hipcc's SLP vectoriser pairs the depthwise FMAs of the wave front into v_pk_fma_f32 -- which
+# issues no faster than two v_fma_f32 on gfx950 (profiles/exp/valu_bench.hip: 5.85 vs 2 x 3.1 cycles) -- and pays for the pairing
+# with register shuffles (61 v_mov_b32 per row of the k=5 shape) and un-fused multiply + add tails.  Scalar FMAs, no moves.
+FILE_FLAGS = {'kernels_wave.hip': ['-fno-slp-vectorize'], 'kernels_dw.hip': ['-fno-slp-vectorize']}   # kernels_dw.hip: see its header
 
 
 def _headers():
@@ -30,7 +34,7 @@ def _obj(src, tune=False):
 
 
 def _stale_sources(force, tune=False):
-    hdr_t = max(os.path.getmtime(h) for h in _headers())
+    hdr_t = max([os.path.getmtime(h) for h in _headers()] + [os.path.getmtime(os.path.abspath(__file__))])   # build.py holds the flags
     out = []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), _obj(s, tune)
@@ -48,7 +52,7 @@ def build(force=False, verbose=False, tune=False):
         return LIB
 
     def compile_one(s):
-        cmd = [HIPCC] + FLAGS + (['-DCOSY_TUNE'] if tune else []) + ['-c', os.path.join(CSRC, s), '-o', _obj(s, tune)]
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(s, []) + (['-DCOSY_TUNE'] if tune else []) + ['-c', os.path.join(CSRC, s), '-o', _obj(s, tune)]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -70,7 +74,7 @@ def _wave_src_sha():
     h = hashlib.sha256()
     for f in ['kernels_wave.hip', 'net_device.h', 'kernels_net.h', 'cosy_common.h']:
         h.update(open(os.path.join(CSRC, f), 'rb').read())
-    h.update(' '.join(FLAGS).encode())
+    h.update(' '.join(FLAGS + FILE_FLAGS.get('kernels_wave.hip', [])).encode())
     return h.hexdigest()[:16]
 
 

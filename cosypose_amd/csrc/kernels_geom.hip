@@ -397,7 +397,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void crop_pack_kernel(T* __restrict__ x, const float* __restrict__ frames4,
                                                         const int* __restrict__ im_id, const float* __restrict__ boxes,
                                                         const float* __restrict__ renders, const CropTap* __restrict__ taps, int B, int h,
-                                                        int w, int PH, int PW) {
+                                                        int w, int PH, int PW, int dbg) {
     // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2.  All pixel blocks of
     // one crop get ids of the same residue, so the frame region under a crop's box is fetched into ONE L2, once
     // (crop-major ids had every XCD fetch every region: 1.2 GB of L2 fills per launch for 0.36 GB of distinct data).
@@ -409,9 +409,12 @@ __global__ __launch_bounds__(256) void crop_pack_kernel(T* __restrict__ x, const
     const int ph = pix / PW, pw = pix % PW;
     const f32x4* img = (const f32x4*)frames4 + (size_t)(im_id ? im_id[b] : b) * h * w;
     float v[6];
-    crop_pixel(img, boxes + (size_t)b * 4, taps, b, h, w, PH, PW, ph, pw, v);
+    if (COSY_DBG(dbg & 1)) { const f32x4 q = img[pix % (h * w)]; v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; }   // dbg 1: one coalesced load, no window
+    else crop_pixel(img, boxes + (size_t)b * 4, taps, b, h, w, PH, PW, ph, pw, v);
     const float* r = renders + (size_t)b * 3 * PH * PW + pix;
-    v[3] = r[0]; v[4] = r[(size_t)PH * PW]; v[5] = r[(size_t)2 * PH * PW];
+    if (COSY_DBG(dbg & 2)) v[3] = v[4] = v[5] = 0.f;                                                      // dbg 2: no render loads
+    else { v[3] = r[0]; v[4] = r[(size_t)PH * PW]; v[5] = r[(size_t)2 * PH * PW]; }
+    if (COSY_DBG(dbg & 4) && v[0] != 123.f) return;                                                      // dbg 4: no stores
     store_px8<T>(x + ((size_t)b * PH * PW + pix) * 8, v);
 }
 
@@ -461,7 +464,7 @@ int launch_crop_pack(void* x, int dtype, const float* frames4, const int* im_id,
     if (taps_ws && (rc = launch_crop_taps(boxes, B, h, w, H, W, taps_ws, s))) return rc;
     dim3 grid((unsigned)(cdiv(H * W, 256) * cdiv(B, 8) * 8));
     COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(crop_pack_kernel<T>, grid, dim3(256), 0, s, (T*)x, frames4, im_id, boxes, renders,
-                                                 (const CropTap*)taps_ws, B, h, w, H, W));
+                                                 (const CropTap*)taps_ws, B, h, w, H, W, tune_int("COSY_CROP_DBG", 0)));
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }

@@ -27,6 +27,12 @@
 #include <type_traits>
 #include <utility>
 
+#ifdef COSY_KO_TAPS          // knock-out build (timing only): every tap of a row reads the same quad, i.e. one LDS read per row
+#define COSY_KO_TAP_INDEX(i) 0
+#else
+#define COSY_KO_TAP_INDEX(i) (i)
+#endif
+
 namespace cosy {
 
 struct WaveKArgs {
@@ -131,6 +137,9 @@ template <typename F, int... Us>
 __device__ __forceinline__ void unroll_seq(F&& f, std::integer_sequence<int, Us...>) { (f(std::integral_constant<int, Us>{}), ...); }
 
 constexpr int wave_lcm(int a, int b) { int x = a; while (x % b) x += a; return x; }
+// shapes whose straight-line interior row does not fit the register budget (the scheduler hoists every tap read: spills, and
+// temporaries in the reserved fragment range -- profiles/check_wave_isa.py) keep the branchy boundary form for every row
+constexpr bool wave_interior_form(int ks, int s, int kbn, int ppl, int minw) { return !(ks == 3 && s == 1 && kbn == 1 && ppl == 4 && minw == 3); }
 constexpr bool wave_wlds(int kbn, int minw) { return (kbn >= 5 && minw >= 4) || kbn >= 9; }
 
 template <typename T, int KS, int S, int KBN, int PPL, int NI, bool FULLW, int MINW>
@@ -283,15 +292,19 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
         }
     };
 
-    for (int base = (iy_first / U) * U; base <= iy_last; base += U) {
-        unroll_seq([&](auto uc) {
+    // One input row.  IN = true is the INTERIOR form: the row lies inside the map, a next row exists, and every output row it feeds
+    // belongs to this job -- all of that is known at compile time there, so the body is straight-line code: without it every tap
+    // row sits behind a wave-uniform branch, the accumulators are copied at each merge (24 v_mov_b64 per row of the k=5 shape)
+    // and the tap reads cannot be scheduled across the blocks (one exposed LDS latency per tap row).
+    auto row = [&](auto uc, auto inc, const int base) {
             constexpr int u = decltype(uc)::value;
+            constexpr bool IN = decltype(inc)::value;
             const int iy = base + u;
-            if (iy < iy_first || iy > iy_last) return;
+            if constexpr (!IN) { if (iy < iy_first || iy > iy_last) return; }
             // ---- A. expanded row iy (transient registers); its global loads were issued one row ago
             float Er[RP][NCH];
             wait_row();
-            if (iy < a.H) {
+            if (IN || iy < a.H) {
                 float sc0[NCH], bi0[NCH];
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) { load4(Pl + 0 * 16 * NI + ni * 16, sc0 + ni * 4); load4(Pl + 1 * 16 * NI + ni * 16, bi0 + ni * 4); }
@@ -341,7 +354,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
             }
             // ---- global memory, issued HERE (between the expansion and the depthwise work): the next input row's loads, then
             // the previous output row's stores; both have this row's whole depthwise phase to complete, and the stores longer.
-            if (iy + 1 <= iy_last && !COSY_DBG(a.dbg & 2)) load_row(iy + 1);     // dbg 2: the first row's fragments are reused
+            if ((IN || iy + 1 <= iy_last) && !COSY_DBG(a.dbg & 2)) load_row(iy + 1);     // dbg 2: the first row's fragments are reused
             flush();
             oy_pending = -1;
             // ---- B. scatter the row into the output rows it feeds: input row iy is tap row ky of output row (iy + LO - ky) / S
@@ -355,13 +368,13 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
                 if (((num % S) + S) % S != 0) continue;
                 const int os = (((num - (((num % S) + S) % S)) / S) % NOPEN + NOPEN) % NOPEN;   // accumulator slot of that output row
                 const int oy = (iy + LO - ky) / S;
-                if (iy + LO - ky < 0 || oy < oy_a || oy >= oy_b) continue;   // wave-uniform
-                if (iy < a.H) {
+                if constexpr (!IN) { if (iy + LO - ky < 0 || oy < oy_a || oy >= oy_b) continue; }   // wave-uniform
+                if (IN || iy < a.H) {
 #pragma unroll
                     for (int kx = 0; kx < KS; ++kx) {
                         float w[NCH];
 #pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) load4(taps + (ky * KSc + kx) * 16 * NI + ni * 16, w + ni * 4);
+                        for (int ni = 0; ni < NI; ++ni) load4(taps + COSY_KO_TAP_INDEX((ky * KSc + kx) * 16 * NI) + ni * 16, w + ni * 4);
 #pragma unroll
                         for (int t = 0; t < TO; ++t)
 #pragma unroll
@@ -401,6 +414,17 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
                     for (int ni = 0; ni < NI; ++ni) yv[t][ni] = ynew[t][ni];
                 oy_pending = oy_done;
             }
+    };
+    // interior rows: iy + LO - (KS-1) >= oy_a * S (every tap row's output row is >= oy_a), iy + LO < oy_b * S (... < oy_b),
+    // iy < H, iy + 1 <= iy_last
+    const int in_lo = oy_a * S + KS - 1 - LO, in_hi = min(min(oy_b * S - 1 - LO, a.H - 1), iy_last - 1);
+    for (int base = (iy_first / U) * U; base <= iy_last; base += U) {
+        unroll_seq([&](auto uc) {
+            const int iy = base + decltype(uc)::value;
+            if constexpr (wave_interior_form(KS, S, KBN, PPL, MINW)) {
+                if (iy >= in_lo && iy <= in_hi && !COSY_DBG(a.dbg & 16)) { row(uc, std::true_type{}, base); return; }   // dbg 16: boundary form everywhere
+            }
+            row(uc, std::false_type{}, base);
         }, std::make_integer_sequence<int, U>{});
     }
     flush();

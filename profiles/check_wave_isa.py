@@ -28,7 +28,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def compile_to_isa(out, tune=False):
     src = os.path.join(REPO, 'cosypose_amd', 'csrc', 'kernels_wave.hip')
-    cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-S', '--cuda-device-only', '-o', out, src]
+    sys.path.insert(0, REPO)
+    from cosypose_amd.build import HIPCC, FLAGS, FILE_FLAGS        # the shipping flags, from the one place that defines them
+    cmd = [HIPCC] + [f for f in FLAGS if not f.startswith('-W')] + FILE_FLAGS.get('kernels_wave.hip', []) + ['-S', '--cuda-device-only', '-o', out, src]
     if tune:
         cmd.insert(1, '-DCOSY_TUNE')
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
