@@ -64,8 +64,11 @@ def main():
     uv = (Kc.unsqueeze(1) @ cam.unsqueeze(-1)).squeeze(-1)
     uv = uv[..., :2] / uv[..., 2:]
     bboxes = torch.cat([uv.min(1)[0], uv.max(1)[0]], 1)
-    data = types.SimpleNamespace(images=torch.from_numpy(frames), K=torch.from_numpy(K), TCO=torch.from_numpy(TCO),
-                                 objects=[dict(name=l) for l in labels[obj]], bboxes=bboxes.cpu())
+    # the batch arrives as the reference's DataLoader delivers it (train_pose.py:242: pin_memory=True): page-locked host tensors,
+    # uploaded inside the step by h_pose's non-blocking .cuda()
+    pin = lambda t: t.contiguous().pin_memory()
+    data = types.SimpleNamespace(images=pin(torch.from_numpy(frames)), K=pin(torch.from_numpy(K)), TCO=pin(torch.from_numpy(TCO)),
+                                 objects=[dict(name=l) for l in labels[obj]], bboxes=pin(bboxes.cpu()))
     cfg = argparse.Namespace(n_points_loss=2600, loss_disentangled=True, n_pose_dims=9, init_method='v0')
     opt = train_engine.FlatAdam(model, lr=3e-4, clip_grad_norm=0.5)
     meters = defaultdict(Meter)
