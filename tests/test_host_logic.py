@@ -87,6 +87,10 @@ def test_tensor_collections():
     cat = tc.concatenate([c[[0]], c[[]], c[[1, 2]]])
     assert list(cat.infos['label']) == ['a', 'b', 'c'] and torch.equal(cat.poses, c.poses)
     assert len(tc.concatenate([c[[]]])) == 0
+    # a single non-empty part is handed on as it is (fresh index, same tensors: no row copies), empty parts beside it are dropped
+    one = tc.concatenate([c[[]], c[[1, 2]], c[[]]])
+    assert list(one.infos['label']) == ['b', 'c'] and list(one.infos.index) == [0, 1] and torch.equal(one.poses, c.poses[1:])
+    assert set(one.tensors) == {'poses', 'bboxes'}
     c.register_tensor('K_crop', torch.ones(3, 3, 3))
     import pickle
     c2 = pickle.loads(pickle.dumps(c))
