@@ -91,7 +91,7 @@ def check_wave_isa(verbose=False):
     if verbose:
         print(r.stdout[-3000:], flush=True)
     ver = subprocess.run([HIPCC, '--version'], capture_output=True, text=True).stdout.strip().split('\n')
-    clean = r.returncode == 0 and 'checked 41 wave kernels' in r.stdout
+    clean = r.returncode == 0 and 'checked 55 wave kernels' in r.stdout
     json.dump(dict(clean=clean, src_sha=_wave_src_sha(), hipcc=[l for l in ver if l][:2], summary=r.stdout.strip().split('\n')[-1]),
               open(ISA_STAMP, 'w'), indent=1)
     if not clean:

@@ -39,6 +39,11 @@ struct WaveKArgs {
     const void* X; const void* Wp; const float* s0; const float* b0; const float* dww; const float* s1; const float* b1;
     void* D; float* partial; const void* zeros;
     int B, H, W, Cin, Cmid, Ho, Wo, nkb_total, nchunks, rsplit, rows_per, dbg;   // rsplit row bands per (sample, chunk), rows_per output rows each
+    // H / W / Ho / Wo are the WALKED axes: the wave walks H "rows" of W pixels.  For a transposed job (host: wave_plan) the rows are the
+    // map's columns; only the four strides below and the order of the taps know: the map is addressed through them.
+    int xs_pix, xs_row;      // bytes between two neighbouring pixels of a row / between two rows of the block input
+    int ds_pix, ds_row;      // elements between two neighbouring pixels of a row / between two rows inside a D chunk
+    int transposed;          // taps are read as w[kx][ky]
 };
 
 template <int CTRL> __device__ __forceinline__ float dpp_mov0(float v) {   // lanes without a source read 0 (bound_ctrl:0)
@@ -180,13 +185,13 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     // changes.  Lanes outside the row / channel range read a valid neighbour instead of a zero page: pixels beyond the row
     // end are forced to zero after the expansion anyway, and the channel tail of the last k-block meets the zero padding of the
     // packed weights (finite * 0).
-    const size_t xrow_bytes = (size_t)a.W * a.Cin * sizeof(T);
+    const size_t xrow_bytes = (size_t)a.xs_row;
     int xoff[PPL][KBN];
 #pragma unroll
     for (int kb = 0; kb < KBN; ++kb) {
         const int k = kb * KB + kg * EPL;
 #pragma unroll
-        for (int q = 0; q < PPL; ++q) xoff[q][kb] = (min(p * PPL + q, a.W - 1) * a.Cin + min(k, a.Cin - EPL)) * (int)sizeof(T);
+        for (int q = 0; q < PPL; ++q) xoff[q][kb] = min(p * PPL + q, a.W - 1) * a.xs_pix + min(k, a.Cin - EPL) * (int)sizeof(T);
     }
     // The input fragments are loaded by inline asm and waited for with a COUNTED s_waitcnt: vmcnt retires loads and stores
     // in order, and hipcc, which cannot count stores across this loop's control flow, waits with vmcnt(0) -- i.e. for the
@@ -246,7 +251,8 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     if (active) {
         for (int i = lane; i < PF / 4; i += 64) {
             const int arr = i / (4 * NI), q4 = i - arr * (4 * NI);
-            const float* src = arr == 0 ? a.s0 : arr == 1 ? a.b0 : arr == 2 ? a.s1 : arr == 3 ? a.b1 : a.dww + (size_t)(arr - 4) * a.Cmid;
+            const int tap = arr - 4, tsrc = a.transposed ? (tap % KS) * KS + tap / KS : tap;     // walked (ky, kx) -> stored w[ky][kx]
+            const float* src = arr == 0 ? a.s0 : arr == 1 ? a.b0 : arr == 2 ? a.s1 : arr == 3 ? a.b1 : a.dww + (size_t)tsrc * a.Cmid;
             // The expansion's SiLU runs on t = log2(e) * v: t / (1 + 2^-t) = log2(e) * silu(v) -- one multiply fewer per expanded
             // element (v_exp_f32 takes the negation as a source modifier).  log2(e) is folded into BN0 here and its inverse into
             // the depthwise taps, which are the only consumers of the expanded values.
@@ -275,8 +281,9 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     // the 4 MB L2 evicted them quarter by quarter -- 25 % of block 3's time by knock-out timing.)  The project GEMM reads
     // this layout directly (PwArgs::a_chunked).
     static_assert(NI == 1, "chunked D: one 16-channel chunk per job");
-    T* __restrict__ Dlane = (T*)a.D + ((size_t)(b * a.nchunks + ch) * a.Ho * a.Wo + p * TO) * 16 + kg * 4;   // + uniform row offset
-    const size_t drow = (size_t)a.Wo * 16;
+    T* __restrict__ Dlane = (T*)a.D + (size_t)(b * a.nchunks + ch) * a.Ho * a.Wo * 16 + (size_t)(p * TO) * a.ds_pix + kg * 4;   // + uniform row offset
+    const size_t drow = (size_t)a.ds_row;
+    const int dpix = a.ds_pix;
     auto flush = [&]() {                     // store the pending output row
         if (oy_pending >= 0 && !COSY_DBG(a.dbg & 1)) {      // dbg 1: no output stores (timing experiments)
             T* o = Dlane + (size_t)(COSY_DBG(a.dbg & 8) ? 0 : oy_pending) * drow;      // dbg 8: every row lands on row 0
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
                 if (COSY_DBG(a.dbg & 4) && t > 0) break;                                 // dbg 4: one store per row
                 if (FULLW || p * TO + t < a.Wo) {
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) *(out_t*)(o + t * 16) = yv[t][ni];
+                    for (int ni = 0; ni < NI; ++ni) *(out_t*)(o + t * dpix) = yv[t][ni];
                 }
             }
             st_in_flight = 1;
@@ -456,7 +463,10 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     X(3, 2, 1, 8, 1, true, 2, 4) X(3, 1, 1, 4, 1, true, 3, 2) X(5, 2, 1, 4, 1, true, 3, 1) X(5, 1, 2, 2, 1, true, 3, 2)      \
     X(3, 2, 2, 2, 1, true, 4, 2) X(3, 1, 3, 1, 1, true, 4, 1) X(5, 1, 3, 1, 1, true, 4, 1) X(5, 1, 5, 1, 1, true, 4, 1)      \
     X(3, 1, 1, 5, 1, true, 2, 2) X(5, 2, 1, 6, 1, false, 2, 1) X(5, 1, 2, 3, 1, false, 2, 2) X(3, 2, 2, 4, 1, false, 3, 1)   \
-    X(3, 1, 3, 2, 1, false, 3, 1) X(5, 1, 3, 2, 1, false, 2, 1) X(5, 1, 5, 2, 1, false, 2, 1)
+    X(3, 1, 3, 2, 1, false, 3, 1) X(5, 1, 3, 2, 1, false, 2, 1) X(5, 1, 5, 2, 1, false, 2, 1)                                \
+    /* rows that do not fill their 16 * PPL lanes, reached by walking the map's COLUMNS (wave_plan: transposed): 240x320 crops */ \
+    X(3, 2, 1, 8, 1, false, 2, 4) X(5, 2, 1, 4, 1, false, 3, 1) X(5, 1, 2, 2, 1, false, 3, 2) X(3, 2, 2, 2, 1, false, 4, 2)   \
+    X(3, 1, 3, 1, 1, false, 4, 1) X(5, 1, 3, 1, 1, false, 4, 1) X(5, 1, 5, 1, 1, false, 4, 1)
 // fp32 (parity mode): k-blocks are 16 deep (v_mfma_f32_16x16x4_f32 x 4 per fragment), so KBN = ceil(Cin / 16).  Same design, same
 // checks; these instantiations are what test_backbone_fp32_vs_reference holds to the reference's own per-stage outputs at <= 1e-4.
 // Not built (the fragment registers do not fit 256): 128- and 80-pixel rows with 2 k-blocks, 40-pixel rows with 3, 20-pixel rows with 9
@@ -467,8 +477,9 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     X(5, 2, 2, 6, 1, false, 2, 1) X(3, 2, 3, 4, 1, false, 2, 1) X(3, 1, 6, 2, 1, false, 2, 1) X(5, 1, 6, 2, 1, false, 2, 1)
 enum { WAVE_MAX_RSPLIT = 4 };
 
-struct WavePlan { int kbn, ppl, ni; bool fullw, ok; };
-static WavePlan wave_plan(int Cin, int Cmid, int H, int W, int k, int s, int dtype) {
+struct WavePlan { int kbn, ppl, ni; bool fullw, ok, transposed; };
+// one orientation: rows of `W` pixels (the lane axis), `H` of them
+static WavePlan wave_plan_1(int Cin, int Cmid, int H, int W, int k, int s, int dtype) {
     WavePlan p{};
     p.kbn = cdiv(Cin, dtype == COSY_F32 ? 16 : 32);
     p.ppl = cdiv(W, 16);
@@ -484,6 +495,22 @@ static WavePlan wave_plan(int Cin, int Cmid, int H, int W, int k, int s, int dty
     if (dtype == COSY_F32) { COSY_WAVE_VARIANTS_F32(X) } else { COSY_WAVE_VARIANTS(X) }
 #undef X
     return p;
+}
+// The wave walks the map row by row with 16 * PPL lanes-pixels per row; a row that does not fill them wastes lanes (240x320 crops:
+// 20-pixel rows on 32, 40 on 48 / 64).  The depthwise conv does not care which axis is walked, so when the map's COLUMNS fill their
+// lanes better (15 on 16, 30 on 32, 120 on 128) the job is transposed: rows := columns, taps read as w[kx][ky], the map addressed through
+// strides (WaveKArgs).  Stride 2 only with even H and W (the static "same" padding is then the same on both axes).  Square maps are
+// never transposed.
+static WavePlan wave_plan(int Cin, int Cmid, int H, int W, int k, int s, int dtype) {
+    WavePlan n = wave_plan_1(Cin, Cmid, H, W, k, s, dtype);
+    static const int allow = tune_int("COSY_WAVE_TRANSPOSE", 1);
+    if (H == W || dtype == COSY_F32 || !allow || (s == 2 && ((H | W) & 1))) return n;
+    WavePlan t = wave_plan_1(Cin, Cmid, W, H, k, s, dtype);
+    if (!t.ok) return n;
+    const long cost_n = (long)16 * n.ppl * H, cost_t = (long)16 * t.ppl * W;      // lane-slots x steps
+    if (n.ok && cost_t * 108 >= cost_n * 100) return n;
+    t.transposed = true;
+    return t;
 }
 bool wave_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W) {
     if (H <= 0) return false;
@@ -523,6 +550,11 @@ static int launch_wave_t(const FuseArgs& a, int* n_tiles_out, hipStream_t s) {
     WaveKArgs k;
     k.X = a.X; k.Wp = a.Wp; k.s0 = a.s0; k.b0 = a.b0; k.dww = a.dww; k.s1 = a.s1; k.b1 = a.b1; k.D = a.D; k.partial = a.partial;
     k.zeros = a.zeros; k.B = a.B; k.H = a.H; k.W = a.W; k.Cin = a.Cin; k.Cmid = a.Cmid; k.Ho = a.Ho; k.Wo = a.Wo;
+    k.xs_pix = a.Cin * (int)sizeof(T); k.xs_row = a.W * a.Cin * (int)sizeof(T); k.ds_pix = 16; k.ds_row = a.Wo * 16; k.transposed = 0;
+    if (p.transposed) {
+        k.H = a.W; k.W = a.H; k.Ho = a.Wo; k.Wo = a.Ho;
+        k.xs_pix = a.W * a.Cin * (int)sizeof(T); k.xs_row = a.Cin * (int)sizeof(T); k.ds_pix = a.Wo * 16; k.ds_row = 16; k.transposed = 1;
+    }
     k.nkb_total = (p.kbn + 1) & ~1; k.nchunks = a.Cmid / (16 * p.ni); k.rsplit = 1; k.rows_per = a.Ho;
     const int ks_ = a.k, st_ = a.s, kbn_ = p.kbn, ppl_ = p.ppl, ni_ = p.ni;
     const bool fw_ = p.fullw;

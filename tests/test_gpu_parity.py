@@ -210,10 +210,11 @@ def _probe(model, h, x, layer, shape):
 
 # storage ulp relative to a value: bf16 has 8 significant bits, fp16 11
 ULP = {'bf16': 2.0 ** -7, 'fp16': 2.0 ** -10}
-L2_TOL = {'bf16': 6e-4, 'fp16': 1.5e-4}   # relative L2 per tensor, block-local comparison (measured worst: 3.4e-4 / 7.7e-5)
+L2_TOL = {'bf16': 6e-4, 'fp16': 4e-4}   # relative L2 per tensor, block-local comparison (measured worst: 3.4e-4 / 2.0e-4 -- block 13's project output at 416x416, whose
+                                          # sums cancel heavily: every element within 0.7 storage ulps; 7.7e-5 at the other sizes); a halo or padding slip is >= 1e-2
 
 
-@pytest.mark.parametrize('hw', [(256, 256), (240, 320), (192, 256), (224, 224)], ids=['256x256', '240x320', '192x256', '224x224'])
+@pytest.mark.parametrize('hw', [(256, 256), (240, 320), (192, 256), (224, 224), (416, 416)], ids=['256x256', '240x320', '192x256', '224x224', '416x416'])
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
 def test_fused_kernels_vs_storage_emulation(model, oracle, golden_sd, dtype, hw):
     """The kernels that set the headline (mbconv_wave_kernel, mbconv_small_kernel, the gated pw_gemm_dma, stem, dwconv in their
@@ -224,20 +225,23 @@ def test_fused_kernels_vs_storage_emulation(model, oracle, golden_sd, dtype, hw)
     fp32 summation order / transcendental approximation in front of a rounding, i.e. isolated values one storage ulp apart:
     asserted as (1) relative L2 error per tensor (a one-pixel halo or padding slip in any variant shows up as >= 1e-2), (2) no
     element further than 1.5 storage ulps of the tensor's scale away (measured: < 0.8), (3) gates (fp32 on both sides) within 5e-6.  256x256 and
-    240x320 reach every fused variant (FULLW and !FULLW wave kernels, row-mapped and plain small kernels, weight- and
-    row-side gates, the tiled kernel on block 2 of 240x320); 192x256 and 224x224 are sizes the schedule was not tuned for (wave variants
-    by width / the tiled kernel on blocks 2-5 and 8, generic unfused blocks).
+    240x320 reach every fused variant (FULLW and !FULLW wave kernels -- at 240x320 the TRANSPOSED walk of blocks 2 and 5-17, whose
+    columns fill the lanes better than their rows --, row-mapped and plain small kernels, weight- and row-side gates); 192x256,
+    224x224 and 416x416 are sizes the schedule was not tuned for (wave variants by width, at 224x224 the !FULLW ones in the plain
+    orientation; the tiled kernel on blocks 3 / 4 of 224x224 and on blocks 2-5 of 416x416: every k / stride form it is built for;
+    generic unfused blocks).
     (End to end the two evaluations decorrelate with depth -- see TorchRef.extract_features_emulated -- which is why the
     comparison is local.)"""
     B = 3
     x = np.random.RandomState(40 + hw[0]).random_sample((B, 6) + tuple(hw)).astype(np.float32)
     h, plan = _block_plan(model, hw, dtype, B)
     kinds = [p[7] for p in plan]
-    if hw in ((256, 256), (240, 320)):     # blocks 3-17 wave, 19-25 small; block 2: wave at 256x256, tiled at 240x320 (160-pixel rows)
-        assert all(k == 1 for k in kinds[3:18]) and all(k == 2 for k in kinds[19:26]) and kinds[18] == 0, kinds
-        assert kinds[2] == (1 if hw == (256, 256) else 3)
-    if hw == (224, 224):                   # widths 112 / 56 / 28: no wave variant -> the tiled kernel on blocks 2-5 and 8 (all four k / stride forms)
-        assert [i for i, k in enumerate(kinds) if k == 3] == [2, 3, 4, 5, 8] and not any(k in (1, 2) for k in kinds), kinds
+    if hw in ((256, 256), (240, 320)):     # blocks 2-17 wave (240x320: block 2's 160-pixel rows are walked as 120-pixel columns), 19-25 small
+        assert all(k == 1 for k in kinds[2:18]) and all(k == 2 for k in kinds[19:26]) and kinds[18] == 0, kinds
+    if hw == (224, 224):                   # 56-pixel rows of blocks 3 / 4: no wave variant -> tiled; every other front has a !FULLW wave variant
+        assert [i for i, k in enumerate(kinds) if k == 3] == [3, 4] and [i for i, k in enumerate(kinds) if k == 1] == [2] + list(range(5, 18)), kinds
+    if hw == (416, 416):                   # 208 / 104-pixel rows: the tiled kernel in all its k / stride forms (k3 s2, k3 s1, k5 s2)
+        assert [i for i, k in enumerate(kinds) if k == 3] == [2, 3, 4, 5] and [i for i, k in enumerate(kinds) if k == 1] == list(range(8, 18)), kinds
     from cosypose_amd._lib import lib, check, ptr, stream
     check(lib().cosy_effnet_b3_set_input_nchw(h, ptr(dev(x)), B, stream()))
     tr = oracle.TorchRef(golden_sd)
