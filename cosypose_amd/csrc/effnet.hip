@@ -66,6 +66,7 @@ struct Block {
     PwLayer exp, proj;
     void* exp_wp_fused;   // expand weights packed in 16- (wave) or 48-channel (small) tiles for the fused front
     float *dw_w, *dw_scale, *dw_bias, *se_wr, *se_br, *se_we, *se_be;
+    float* wave_params;           // wave kernel: BN0 / BN1 / taps packed per 16-channel chunk (wave_pack_params)
     float *b0_fold, *dw_w_fold;   // small kernel: log2(e) * BN0 bias; taps * BN1 scale * ln 2 (the BN0 scale is inside exp_wp_fused)
     bool se_batched;      // squeeze-excite as two batched GEMM kernels (late blocks) instead of one workgroup per sample
     float *se_wr_p, *se_br_p, *se_we_p;   // zero-padded copies for the batched form: (CseP, Cmid), (CseP), (Cmid, CseP)
@@ -175,6 +176,8 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         b.tiled = !b.wave && !b.small && n->fuse && b.d.e != 1 && ((n->tile_mask >> i) & 1) && tile_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype);
         b.fused = b.wave || b.small || b.tiled;
         b.exp_wp_fused = nullptr;
+        b.wave_params = nullptr;
+        std::vector<float> exp_sc, exp_bi;       // folded BatchNorm 0 of the expansion (host copy for wave_pack_params)
         if (b.d.e != 1) {
             mk_pw(b.exp, p, b.d.cin, b.cmid, p + (size_t)b.cmid * b.d.cin, b.H * b.W, false);
             if (b.fused) {
@@ -204,6 +207,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
                     if (e2 != hipSuccess) *herr = e2;
                 }
                 b.b0_fold = up_f32(b0f);
+                if (b.wave) { if (fill) fold_bn(p + (size_t)b.cmid * b.d.cin, b.cmid, b.cmid, exp_sc, exp_bi); else { exp_sc.assign(b.cmid, 0.f); exp_bi.assign(b.cmid, 0.f); } }
                 b.n_tiles = b.wave ? wave_max_tiles() : b.tiled ? tile_num_tiles(b.d.cin, b.Ho, b.Wo, b.d.k, b.d.s, n->dtype) : 1;
             }
             p += (size_t)b.cmid * b.d.cin + 4 * b.cmid;
@@ -218,6 +222,11 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
             if (fill) fold_bn(p, b.cmid, b.cmid, sc, bi); else { sc.assign(b.cmid, 0.f); bi.assign(b.cmid, 0.f); }
             p += 4 * b.cmid;
             b.dw_w = up_f32(w); b.dw_scale = up_f32(sc); b.dw_bias = up_f32(bi);
+            if (b.wave) {
+                std::vector<float> wp(wave_params_floats(b.cmid, b.d.k), 0.f);
+                if (fill) wave_pack_params(exp_sc.data(), exp_bi.data(), w.data(), sc.data(), bi.data(), b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W, wp.data());
+                b.wave_params = up_f32(wp);
+            }
             b.dw_w_fold = nullptr;
             if (b.small) {
                 std::vector<float> wf(w.size(), 0.f);
@@ -355,7 +364,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
             FuseArgs f{};
             f.X = in; f.Wp = b.exp_wp_fused;
             if (b.small) { f.b0 = b.b0_fold; f.dww = b.dw_w_fold; f.b1 = b.dw_bias; }
-            else { f.s0 = b.exp.scale; f.b0 = b.exp.bias; f.dww = b.dw_w; f.s1 = b.dw_scale; f.b1 = b.dw_bias; }
+            else { f.s0 = b.exp.scale; f.b0 = b.exp.bias; f.dww = b.dw_w; f.s1 = b.dw_scale; f.b1 = b.dw_bias; f.wparams = b.wave_params; }
             f.D = Dbuf; f.partial = w.partial; f.zeros = n->zeros;
             f.B = Bc; f.H = b.H; f.W = b.W; f.Cin = b.d.cin; f.Cmid = b.cmid; f.Ho = b.Ho; f.Wo = b.Wo; f.k = b.d.k; f.s = b.d.s; f.pad_lo = b.pad_lo;
             if ((rc = b.wave ? launch_mbconv_wave(f, n->dtype, &se_tiles, s) : b.tiled ? launch_mbconv_tile(f, n->dtype, s) : launch_mbconv_small(f, n->dtype, s))) return rc;

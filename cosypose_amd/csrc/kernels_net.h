@@ -57,6 +57,7 @@ struct FuseArgs {
     const float* s0; const float* b0;
     const float* dww;
     const float* s1; const float* b1;
+    const float* wparams;   // wave kernel only: the five arrays above packed per 16-channel chunk (wave_pack_params); it reads nothing else
     void* D;             // (B,Ho,Wo,Cmid)
     float* partial;      // (B, n_tiles, Cmid)
     const void* zeros;
@@ -74,6 +75,9 @@ bool small_writes_chunked(int Cin, int Cmid, int H, int W, int Ho, int Wo, int k
 // wave-autonomous variant (kernels_wave.hip): expanded rows in registers, no LDS ring / barriers; expand weights packed with
 // PwCfg{1,1} (16-channel tiles, natural row order); partial has ONE tile per sample
 bool wave_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W);
+size_t wave_params_floats(int Cmid, int k);
+void wave_pack_params(const float* s0, const float* b0, const float* dww, const float* s1, const float* b1, int Cin, int Cmid, int k, int s,
+                      int dtype, int H, int W, float* dst);
 void wave_kernel_name(int Cin, int Cmid, int k, int s, int dtype, int H, int W, char* buf, size_t n);
 int wave_max_tiles();   // upper bound of the row bands (partial-sum tiles per sample) a launch may use
 int launch_mbconv_wave(const FuseArgs& a, int dtype, int* n_tiles_out, hipStream_t s);

@@ -36,14 +36,13 @@
 namespace cosy {
 
 struct WaveKArgs {
-    const void* X; const void* Wp; const float* s0; const float* b0; const float* dww; const float* s1; const float* b1;
+    const void* X; const void* Wp; const float* wparams;     // wparams: wave_pack_params()
     void* D; float* partial; const void* zeros;
     int B, H, W, Cin, Cmid, Ho, Wo, nkb_total, nchunks, rsplit, rows_per, dbg;   // rsplit row bands per (sample, chunk), rows_per output rows each
     // H / W / Ho / Wo are the WALKED axes: the wave walks H "rows" of W pixels.  For a transposed job (host: wave_plan) the rows are the
     // map's columns; only the four strides below and the order of the taps know: the map is addressed through them.
     int xs_pix, xs_row;      // bytes between two neighbouring pixels of a row / between two rows of the block input
     int ds_pix, ds_row;      // elements between two neighbouring pixels of a row / between two rows inside a D chunk
-    int transposed;          // taps are read as w[kx][ky]
 };
 
 template <int CTRL> __device__ __forceinline__ float dpp_mov0(float v) {   // lanes without a source read 0 (bound_ctrl:0)
@@ -231,13 +230,29 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     // row (asm loads, oldest), the chunk's expand-weight fragments, the parameter block (staged to LDS: its wait is a vmcnt(0)
     // that covers all three).  Issued one after the other they cost three memory latencies per job -- 15 % of a 16-row job.
     raw_t wf[NI][KBN];
+    // The chunk's parameters arrive PACKED (host: wave_pack_params): one contiguous block [s0*log2e][b0*log2e][s1][b1][taps*ln2 in
+    // walked order] of PF floats per chunk, so a lane fetches its one or two 16-byte pieces without address arithmetic.  (The
+    // expansion's SiLU runs on t = log2(e) * v: t / (1 + 2^-t) = log2(e) * silu(v) -- one multiply fewer per expanded element,
+    // v_exp_f32 takes the negation as a source modifier; the inverse factor rides in the taps, the only consumers of the
+    // expanded values.)  Round 3: these loads used to be issued BEHIND the wait for the weight fragments, one pass of a rolled
+    // loop at a time -- three serial memory latencies per job where the comment above promised one.
+    constexpr int NPL = (PF / 4 + 63) / 64;
+    f32x4 pv[NPL];
     if (active) {
+        const f32x4* PP = (const f32x4*)(a.wparams + (size_t)ch * PF);
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) pv[j] = PP[min(lane + 64 * j, PF / 4 - 1)];
         load_row(iy_first);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int kb = 0; kb < KBN; ++kb)
                 wf[ni][kb] = *(const raw_t*)((const T*)a.Wp + ((size_t)(ch * NI + ni) * a.nkb_total + kb) * 64 * EPL + lane * EPL);
+        // -> the wave-private LDS block (no workgroup barrier: a wave reads only what it wrote itself, and LDS operations of one
+        // wave execute in order)
+#pragma unroll
+        for (int j = 0; j < NPL; ++j)
+            if (lane + 64 * j < PF / 4) *(f32x4*)(P + (lane + 64 * j) * 4) = pv[j];
         if constexpr (WLDS) {
             // 4 * KBN registers that a 4-waves-per-SIMD budget does not have: parked in the wave's LDS block and re-read in front
             // of every row's MFMAs (one conflict-free ds_read_b128 per fragment and row)
@@ -247,20 +262,6 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
                 for (int kb = 0; kb < KBN; ++kb) *(raw_t*)(Wl + (ni * KBN + kb) * 1024 + lane * 16) = wf[ni][kb];
         }
     }
-    // ---- parameters of the chunk -> wave-private LDS block [s0][b0][s1][b1][taps], 16*NI floats each
-    if (active) {
-        for (int i = lane; i < PF / 4; i += 64) {
-            const int arr = i / (4 * NI), q4 = i - arr * (4 * NI);
-            const int tap = arr - 4, tsrc = a.transposed ? (tap % KS) * KS + tap / KS : tap;     // walked (ky, kx) -> stored w[ky][kx]
-            const float* src = arr == 0 ? a.s0 : arr == 1 ? a.b0 : arr == 2 ? a.s1 : arr == 3 ? a.b1 : a.dww + (size_t)tsrc * a.Cmid;
-            // The expansion's SiLU runs on t = log2(e) * v: t / (1 + 2^-t) = log2(e) * silu(v) -- one multiply fewer per expanded
-            // element (v_exp_f32 takes the negation as a source modifier).  log2(e) is folded into BN0 here and its inverse into
-            // the depthwise taps, which are the only consumers of the expanded values.
-            const float f = arr < 2 ? 1.4426950408889634f : arr >= 4 ? 0.6931471805599453f : 1.f;
-            *(f32x4*)(P + arr * 16 * NI + q4 * 4) = *(const f32x4*)(src + c0 + q4 * 4) * f;
-        }
-    }
-    __syncthreads();
     if (!active) return;
 
     float acc[NOPEN][TO][NCH];               // output rows in flight (input-stationary accumulation)
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
 // Not built (the fragment registers do not fit 256): 128- and 80-pixel rows with 2 k-blocks, 40-pixel rows with 3, 20-pixel rows with 9
 // -- those blocks run unfused in fp32.
 #define COSY_WAVE_VARIANTS_F32(X)                                                                                  \
-    X(3, 1, 2, 4, 1, true, 2, 2) X(5, 2, 2, 4, 1, true, 3, 1) X(5, 1, 3, 2, 1, true, 2, 2)      \
+    X(3, 1, 2, 4, 1, true, 2, 2) X(5, 2, 2, 4, 1, true, 2, 1) X(5, 1, 3, 2, 1, true, 2, 2)      \
     X(3, 2, 3, 2, 1, true, 3, 2) X(3, 1, 6, 1, 1, true, 3, 1) X(5, 1, 6, 1, 1, true, 3, 1) X(5, 1, 9, 1, 1, true, 3, 1)      \
     X(5, 2, 2, 6, 1, false, 2, 1) X(3, 2, 3, 4, 1, false, 2, 1) X(3, 1, 6, 2, 1, false, 2, 1) X(5, 1, 6, 2, 1, false, 2, 1)
 enum { WAVE_MAX_RSPLIT = 4 };
@@ -512,6 +513,26 @@ static WavePlan wave_plan(int Cin, int Cmid, int H, int W, int k, int s, int dty
     t.transposed = true;
     return t;
 }
+// Per-chunk parameter blocks of the wave kernel: [chunk][4 + k*k][16] fp32 = s0 * log2(e), b0 * log2(e), s1, b1, then the taps
+// * ln 2 in the order the job walks them (w[kx][ky] for a transposed job).  The products are single-precision, exactly what the
+// kernel used to compute per job.
+size_t wave_params_floats(int Cmid, int k) { return (size_t)(Cmid / 16) * (4 + k * k) * 16; }
+void wave_pack_params(const float* s0, const float* b0, const float* dww, const float* s1, const float* b1, int Cin, int Cmid, int k, int s,
+                      int dtype, int H, int W, float* dst) {
+    const WavePlan p = wave_plan(Cin, Cmid, H, W, k, s, dtype);
+    const float L2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    const int pf = (4 + k * k) * 16;
+    for (int ch = 0; ch < Cmid / 16; ++ch)
+        for (int c = 0; c < 16; ++c) {
+            float* d = dst + (size_t)ch * pf + c;
+            const int cc = ch * 16 + c;
+            d[0 * 16] = s0[cc] * L2E; d[1 * 16] = b0[cc] * L2E; d[2 * 16] = s1[cc]; d[3 * 16] = b1[cc];
+            for (int t = 0; t < k * k; ++t) {
+                const int tsrc = p.transposed ? (t % k) * k + t / k : t;     // walked (ky, kx) -> stored w[ky][kx]
+                d[(4 + t) * 16] = dww[(size_t)tsrc * Cmid + cc] * LN2;
+            }
+        }
+}
 bool wave_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W) {
     if (H <= 0) return false;
     return wave_plan(Cin, Cmid, H, W, k, s, dtype).ok;
@@ -548,12 +569,13 @@ static int launch_wave_t(const FuseArgs& a, int* n_tiles_out, hipStream_t s) {
     const WavePlan p = wave_plan(a.Cin, a.Cmid, a.H, a.W, a.k, a.s, sizeof(T) == 4 ? COSY_F32 : COSY_BF16);
     COSY_REQUIRE(p.ok, "mbconv_wave: unsupported shape Cin=%d Cmid=%d %dx%d k=%d s=%d", a.Cin, a.Cmid, a.H, a.W, a.k, a.s);
     WaveKArgs k;
-    k.X = a.X; k.Wp = a.Wp; k.s0 = a.s0; k.b0 = a.b0; k.dww = a.dww; k.s1 = a.s1; k.b1 = a.b1; k.D = a.D; k.partial = a.partial;
+    k.X = a.X; k.Wp = a.Wp; k.wparams = a.wparams; k.D = a.D; k.partial = a.partial;
+    COSY_REQUIRE(a.wparams != nullptr, "mbconv_wave: packed parameters missing (wave_pack_params)%s", "");
     k.zeros = a.zeros; k.B = a.B; k.H = a.H; k.W = a.W; k.Cin = a.Cin; k.Cmid = a.Cmid; k.Ho = a.Ho; k.Wo = a.Wo;
-    k.xs_pix = a.Cin * (int)sizeof(T); k.xs_row = a.W * a.Cin * (int)sizeof(T); k.ds_pix = 16; k.ds_row = a.Wo * 16; k.transposed = 0;
+    k.xs_pix = a.Cin * (int)sizeof(T); k.xs_row = a.W * a.Cin * (int)sizeof(T); k.ds_pix = 16; k.ds_row = a.Wo * 16;
     if (p.transposed) {
         k.H = a.W; k.W = a.H; k.Ho = a.Wo; k.Wo = a.Ho;
-        k.xs_pix = a.W * a.Cin * (int)sizeof(T); k.xs_row = a.Cin * (int)sizeof(T); k.ds_pix = a.Wo * 16; k.ds_row = 16; k.transposed = 1;
+        k.xs_pix = a.W * a.Cin * (int)sizeof(T); k.xs_row = a.Cin * (int)sizeof(T); k.ds_pix = a.Wo * 16; k.ds_row = 16;
     }
     k.nkb_total = (p.kbn + 1) & ~1; k.nchunks = a.Cmid / (16 * p.ni); k.rsplit = 1; k.rows_per = a.Ho;
     const int ks_ = a.k, st_ = a.s, kbn_ = p.kbn, ppl_ = p.ppl, ni_ = p.ni;
