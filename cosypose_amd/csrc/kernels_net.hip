@@ -469,7 +469,7 @@ int tile_num_tiles(int Cin, int Ho, int Wo, int k, int s, int dtype) {
 // shapes the tiled kernel is built for: up to 2 k-blocks of input channels (the high-resolution blocks), 48-channel chunks
 bool tile_supported(int Cin, int Cmid, int k, int s, int dtype) {
     const int kbn = cdiv(Cin, dtype == COSY_F32 ? 16 : 32);
-    return dtype != COSY_F32 && Cmid % 48 == 0 && kbn <= 2 && (k == 3 || k == 5) && (s == 1 || s == 2);
+    return Cmid % 48 == 0 && kbn <= 2 && (k == 3 || k == 5) && (s == 1 || s == 2);
 }
 
 struct FuseKArgs {
@@ -669,12 +669,13 @@ static int launch_tile_t(const FuseArgs& a, hipStream_t s) {
 }
 
 void tile_kernel_name(int Cin, int k, int s, int dtype, char* buf, size_t n) {
-    snprintf(buf, n, "mbconv_tile_kernel<%s, float, %d, %d, %d, %d>", dtype == COSY_BF16 ? "__bf16" : "_Float16", k, s, s == 1 ? 4 : 2, cdiv(Cin, 32));
+    snprintf(buf, n, "mbconv_tile_kernel<%s, float, %d, %d, %d, %d>", dtype == COSY_BF16 ? "__bf16" : dtype == COSY_F16 ? "_Float16" : "float", k, s, s == 1 ? 4 : 2,
+             cdiv(Cin, dtype == COSY_F32 ? 16 : 32));
 }
 int launch_mbconv_tile(const FuseArgs& a, int dtype, hipStream_t s) {
     if (a.B == 0) return COSY_OK;
     COSY_REQUIRE(tile_supported(a.Cin, a.Cmid, a.k, a.s, dtype), "mbconv_tile: unsupported shape Cin=%d Cmid=%d k=%d s=%d", a.Cin, a.Cmid, a.k, a.s);
-    return dtype == COSY_BF16 ? launch_tile_t<bf16_t>(a, s) : launch_tile_t<f16_t>(a, s);
+    return dtype == COSY_BF16 ? launch_tile_t<bf16_t>(a, s) : dtype == COSY_F16 ? launch_tile_t<f16_t>(a, s) : launch_tile_t<float>(a, s);
 }
 
 // ==========================================================================================

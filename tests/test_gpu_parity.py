@@ -167,6 +167,8 @@ def test_backbone_fp32_vs_reference(model, golden, name, hw, seed):
     kinds = [p[7] for p in plan]
     fused = [i for i, k in enumerate(kinds) if k == 1]
     assert fused == (list(range(3, 18)) if hw == (256, 256) else [5, 8, 9, 10, 11, 12, 13]), kinds
+    # the blocks no fp32 wave variant holds run the tiled front (fp32 since round 3): block 2 at 256x256, blocks 2-4 at 240x320
+    assert [i for i, k in enumerate(kinds) if k == 3] == ([2] if hw == (256, 256) else [2, 3, 4]), kinds
     model.render_size = (240, 320)
 
 
