@@ -169,8 +169,9 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         int hi; static_pad(b.d.k, b.d.s, &b.pad_lo, &hi);
         b.skip = (b.d.s == 1 && b.d.cin == b.d.cout);  // id_skip, efficientnet.py:94
         b.n_tiles = b.dw_tiles = dw_num_tiles(b.cmid, b.Ho, b.Wo, b.d.k);
-        // fused fronts exist for the shapes of the two supported crop sizes (256x256, 240x320) in the 2-byte types; every other
-        // shape (and fp32) runs the generic unfused kernels, which are shape-agnostic
+        // fused fronts by shape: the wave kernel where a variant holds the block's rows (or columns: transposed walk), the small-map kernel
+        // on 8x8 / 7x10 maps (2-byte types), the tiled kernel on blocks 2-5 / 8 otherwise; whatever is left runs the shape-agnostic
+        // unfused kernels (pw_gemm_dma -> E -> dwconv)
         b.wave = n->fuse && b.d.e != 1 && ((n->wave_mask >> i) & 1) && wave_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
         b.small = !b.wave && n->fuse && b.d.e != 1 && ((n->small_mask >> i) & 1) && small_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
         b.tiled = !b.wave && !b.small && n->fuse && b.d.e != 1 && ((n->tile_mask >> i) & 1) && tile_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype);
