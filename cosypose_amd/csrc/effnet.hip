@@ -231,9 +231,13 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
             b.dw_w_fold = nullptr;
             if (b.small) {
                 std::vector<float> wf(w.size(), 0.f);
+                const bool xp = small_transposed(b.d.cin, b.cmid, b.H, b.W, b.d.k, b.d.s, n->dtype);
                 if (fill)
                     for (int t = 0; t < kk; ++t)
-                        for (int c = 0; c < b.cmid; ++c) wf[t * b.cmid + c] = (float)((double)w[t * b.cmid + c] * (double)sc[c] * 0.6931471805599453);
+                        for (int c = 0; c < b.cmid; ++c) {
+                            const int ts = xp ? (t % b.d.k) * b.d.k + t / b.d.k : t;      // walked (ky, kx) -> stored w[ky][kx]
+                            wf[t * b.cmid + c] = (float)((double)w[ts * b.cmid + c] * (double)sc[c] * 0.6931471805599453);
+                        }
                 b.dw_w_fold = up_f32(wf);
             }
         }

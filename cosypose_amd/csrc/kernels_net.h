@@ -71,6 +71,7 @@ void tile_kernel_name(int Cin, int k, int s, int dtype, char* buf, size_t n);
 // whole-image variant for the small maps of the late blocks (kernels_net.hip: mbconv_small_kernel); partial has ONE tile per sample
 bool small_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W);
 int launch_mbconv_small(const FuseArgs& a, int dtype, hipStream_t s);
+bool small_transposed(int Cin, int Cmid, int H, int W, int k, int s, int dtype);   // taps wanted as w[kx][ky]
 bool small_writes_chunked(int Cin, int Cmid, int H, int W, int Ho, int Wo, int k, int s, int dtype);   // D layout of launch_mbconv_small
 // wave-autonomous variant (kernels_wave.hip): expanded rows in registers, no LDS ring / barriers; expand weights packed with
 // PwCfg{1,1} (16-channel tiles, natural row order); partial has ONE tile per sample

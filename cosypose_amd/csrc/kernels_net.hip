@@ -412,7 +412,7 @@ void pw_kernel_name(const PwArgs& a, PwCfg c, int dtype, char* buf, size_t n) {
 }
 void small_kernel_name(int Cin, int k, int s, int dtype, int H, int W, char* buf, size_t n) {
     const int mbr = cdiv(H * W, 16), mpw = cdiv(mbr, (mbr <= 4 ? 256 : 512) / 64);
-    snprintf(buf, n, "mbconv_small_kernel<%s, %d, %d, %d, %d, %d>", tname(dtype), k, s, s == 1 ? 4 : 2, cdiv(Cin, 32), mpw);
+    snprintf(buf, n, "mbconv_small_kernel<%s, %d, %d, %d, %d, %d>", tname(dtype), k, s, s == 1 ? (H == 7 && W == 10 ? 5 : 4) : 2, cdiv(Cin, 32), mpw);
 }
 
 int launch_pw_gemm(const PwArgs& a, PwCfg cfg, int dtype, hipStream_t s) {
@@ -711,6 +711,8 @@ struct FuseSKArgs {
     void* D; float* partial; const void* zeros;
     int H, W, NP, Cin, Cmid, Ho, Wo, lo, THin, TWin, nkb_total, MBr, ncg, cpw, dbg;
     unsigned rcp_w;   // ceil(2^16 / W): p / W == (p * rcp_w) >> 16 for p < MBr*16 (checked on the host)
+    int xpose;        // the depthwise phase walks the TRANSPOSED map (7x10 maps: 10 rows of 7 pixels): Ho / Wo / THin / TWin are the walked
+                      // dimensions, the taps arrive as w[kx][ky]; H / W stay the stored map (the expansion decodes pixels with them)
 };
 
 template <typename T, int KS, int S, int R, int KBN, int MPW, bool ROWMAP = false>
@@ -785,8 +787,8 @@ __global__ __launch_bounds__(512) void mbconv_small_kernel(FuseSKArgs a) {
     // all 32 banks once, conflict-free; quad-fastest had 2-way conflicts on every second half-row), and with D in the chunked
     // layout a wave's store covers 16 pixels x 32 bytes contiguously.
     const int cq = ROWMAP ? tid >> 4 : tid % NG;
-    const bool has_unit = (ROWMAP ? tid < 16 * NG : tid < units) && !COSY_DBG(a.dbg & 1);
     const int uq = ROWMAP ? (tid & 15) : tid / NG, ux = uq % a.Wo, uyq = uq / a.Wo;
+    const bool has_unit = (ROWMAP ? tid < 16 * NG && uq < a.Wo * nyq : tid < units) && !COSY_DBG(a.dbg & 1);   // ROWMAP: up to 16 units per quad
     // Global stores count in vmcnt on this ISA and retire in order with the loads: a wait for the NEXT chunk's DMA issued
     // after this chunk's output stores would also wait for the stores' acknowledgements (~2-3 us per chunk, measured).
     // So per chunk: [barrier] expand -> [barrier] issue DMA(ch+1) -> depthwise COMPUTE -> wait DMA -> output stores.
@@ -826,7 +828,8 @@ __global__ __launch_bounds__(512) void mbconv_small_kernel(FuseSKArgs a) {
                                 const float t = acc[ni][r];               // = log2(e) * BN0(expand)
                                 v12[ni * 4 + r] = t * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-t));   // = log2(e) * silu
                             }
-                        float* dst = (float*)(Et + (size_t)((y + a.lo) * TWin + x + a.lo) * PITCH) + kg * 4 * NI;
+                        const int ey = a.xpose ? x : y, ex = a.xpose ? y : x;      // position in the (walked) expanded image
+                        float* dst = (float*)(Et + (size_t)((ey + a.lo) * TWin + ex + a.lo) * PITCH) + kg * 4 * NI;
                         store4(dst, v12); store4(dst + 4, v12 + 4); store4(dst + 8, v12 + 8);
                     }
                 }
@@ -894,9 +897,8 @@ __global__ __launch_bounds__(512) void mbconv_small_kernel(FuseSKArgs a) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int oy = uyq * R + r;
-                    if (oy < a.Ho) store4(out + ((size_t)oy * a.Wo + ux) * 16, yv[r]);
+                    if (oy < a.Ho) store4(out + (a.xpose ? (size_t)ux * a.Ho + oy : (size_t)oy * a.Wo + ux) * 16, yv[r]);
                 }
-                if ((tid & 15) == 15) *(f32x4*)(a.partial + (size_t)b * a.Cmid + ch * CC + cq * CPT) = f32x4{sum[0], sum[1], sum[2], sum[3]};
             } else {
                 T* __restrict__ out = (T*)a.D + (size_t)b * a.Ho * a.Wo * a.Cmid + ch * CC + cq * CPT;
 #pragma unroll
@@ -906,15 +908,29 @@ __global__ __launch_bounds__(512) void mbconv_small_kernel(FuseSKArgs a) {
                 }
             }
         }
+        if constexpr (ROWMAP) {            // lane 15 of every quad row holds the quad's sums (it may have no unit of its own: 14-unit maps)
+            if (tid < 16 * NG && (tid & 15) == 15 && !COSY_DBG(a.dbg & 1))
+                *(f32x4*)(a.partial + (size_t)b * a.Cmid + ch * CC + cq * CPT) = f32x4{sum[0], sum[1], sum[2], sum[3]};
+        }
         __syncthreads();   // red complete; everybody's DMA(ch+1) landed; all Et / parameter reads of this chunk are done
         if constexpr (!ROWMAP) reduce_squeeze_sums(red, stride, NG, CPT, tid, nthr, a.partial + (size_t)b * a.Cmid + ch * CC);
     }
 }
 
-struct FuseSmallPlan { int kbn, MBr, mpw, threads, THin, TWin, ncg, cpw; size_t lds; bool ok; };
+struct FuseSmallPlan { int kbn, MBr, mpw, threads, THin, TWin, ncg, cpw; size_t lds; bool ok; int xpose, R, Ho, Wo; };
+// 7x10 maps (240x320 crops) are walked TRANSPOSED with 5 output rows per unit: 7 columns x 2 row-units = 14 of the 16 lanes of a DPP row,
+// i.e. the row-mapped form of the 8x8 maps (no LDS reduction, conflict-free tile reads, chunked D) instead of the plain one (113 vs ~75 us)
+static bool fuse_small_xpose(int H, int W, int k, int s) {
+    static const int on = tune_int("COSY_SMALL_XPOSE", 1);
+    return on && s == 1 && H == 7 && W == 10 && (k == 3 || k == 5);
+}
 static FuseSmallPlan fuse_small_plan(int Cin, int Cmid, int H, int W, int Ho, int Wo, int k, int s, int esz) {
     FuseSmallPlan p{};
-    const int R = s == 1 ? 4 : 2;
+    p.xpose = fuse_small_xpose(H, W, k, s);
+    if (p.xpose) { const int t = Ho; Ho = Wo; Wo = t; const int u = H; H = W; W = u; }      // walked dimensions from here on
+    p.Ho = Ho; p.Wo = Wo;
+    const int R = p.xpose ? 5 : s == 1 ? 4 : 2;
+    p.R = R;
     p.kbn = cdiv(Cin, 32);
     p.MBr = cdiv(H * W, 16);
     p.threads = p.MBr <= 4 ? 256 : 512;
@@ -933,7 +949,7 @@ static FuseSmallPlan fuse_small_plan(int Cin, int Cmid, int H, int W, int Ho, in
     // built for the 8x8 (7x10) maps of blocks 19-25: stride 1, one 16-pixel block per wave, 232 or 384 input channels.
     // (On the 16x16 maps the input registers + a 400-pixel fp32 tile leave one workgroup per CU: not built.)
     p.ok = esz == 2 && Cmid % 48 == 0 && (p.kbn == 8 || p.kbn == 12) && p.mpw == 1 && p.lds <= 80 * 1024 && (k == 3 || k == 5) && s == 1 &&
-           12 * Wo * cdiv(Ho, 4) <= p.threads && ((H == 8 && W == 8) || (H == 7 && W == 10));    // the two maps it is tested on
+           12 * Wo * nyq <= p.threads && ((H == 8 && W == 8) || (H == 7 && W == 10) || (p.xpose && H == 10 && W == 7));    // the two maps it is tested on
     return p;
 }
 static int fuse_small_enabled() { static const int v = tune_int("COSY_FUSE_SMALL", 1); return v; }
@@ -943,6 +959,7 @@ static bool fuse_small_rowmap(int Ho, int Wo, int threads) {
     static const int on = tune_int("COSY_SMALL_ROWMAP", 1);
     return on && Wo * cdiv(Ho, 4) == 16 && Ho % 4 == 0 && threads >= 192;
 }
+static bool fuse_small_rowmap(const FuseSmallPlan& p) { return p.xpose || fuse_small_rowmap(p.Ho, p.Wo, p.threads); }
 template <typename T, int KS, int KBN>
 static int launch_fuse_small_m(const FuseSmallPlan& p, const FuseSKArgs& k, int B, hipStream_t s) {
     const dim3 grid((unsigned)(B * k.ncg)), block(p.threads);
@@ -950,9 +967,13 @@ static int launch_fuse_small_m(const FuseSmallPlan& p, const FuseSKArgs& k, int 
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     static const hipError_t attr_rc1 = hipFuncSetAttribute((const void*)mbconv_small_kernel<T, KS, 1, 4, KBN, 1, true>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static const hipError_t attr_rc2 = hipFuncSetAttribute((const void*)mbconv_small_kernel<T, KS, 1, 5, KBN, 1, true>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     COSY_CHECK_HIP(attr_rc0);
     COSY_CHECK_HIP(attr_rc1);
-    if (fuse_small_rowmap(k.Ho, k.Wo, p.threads)) hipLaunchKernelGGL((mbconv_small_kernel<T, KS, 1, 4, KBN, 1, true>), grid, block, p.lds, s, k);
+    COSY_CHECK_HIP(attr_rc2);
+    if (p.xpose) hipLaunchKernelGGL((mbconv_small_kernel<T, KS, 1, 5, KBN, 1, true>), grid, block, p.lds, s, k);
+    else if (fuse_small_rowmap(k.Ho, k.Wo, p.threads)) hipLaunchKernelGGL((mbconv_small_kernel<T, KS, 1, 4, KBN, 1, true>), grid, block, p.lds, s, k);
     else hipLaunchKernelGGL((mbconv_small_kernel<T, KS, 1, 4, KBN, 1, false>), grid, block, p.lds, s, k);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
@@ -964,6 +985,7 @@ static int launch_fuse_small_t(const FuseArgs& a, hipStream_t s) {
     k.X = a.X; k.Wp = a.Wp; k.b0 = a.b0; k.dww = a.dww; k.b1 = a.b1; k.D = a.D; k.partial = a.partial;
     k.zeros = a.zeros; k.H = a.H; k.W = a.W; k.NP = a.H * a.W; k.Cin = a.Cin; k.Cmid = a.Cmid; k.Ho = a.Ho; k.Wo = a.Wo; k.lo = a.pad_lo;
     k.THin = p.THin; k.TWin = p.TWin; k.nkb_total = pw_nkb_total(a.Cin, COSY_BF16); k.MBr = p.MBr; k.ncg = p.ncg; k.cpw = p.cpw;
+    k.xpose = p.xpose; k.Ho = p.Ho; k.Wo = p.Wo;       // walked dimensions (== a.Ho / a.Wo unless transposed)
     k.rcp_w = (65536u + a.W - 1) / a.W;
     static const int dbg = tune_int("COSY_SMALL_DBG", 0);   // timing experiments only
     k.dbg = dbg;
@@ -987,7 +1009,11 @@ static bool fuse_use_small(int Cin, int Cmid, int H, int W, int Ho, int Wo, int 
 bool small_writes_chunked(int Cin, int Cmid, int H, int W, int Ho, int Wo, int k, int s, int dtype) {
     if (!fuse_use_small(Cin, Cmid, H, W, Ho, Wo, k, s, dtype)) return false;
     const FuseSmallPlan p = fuse_small_plan(Cin, Cmid, H, W, Ho, Wo, k, s, 2);
-    return fuse_small_rowmap(Ho, Wo, p.threads);
+    return fuse_small_rowmap(p);
+}
+// are the depthwise taps of this block to be handed over as w[kx][ky] (launch_mbconv_small walks the map transposed)?
+bool small_transposed(int Cin, int Cmid, int H, int W, int k, int s, int dtype) {
+    return small_supported(Cin, Cmid, k, s, dtype, H, W) && fuse_small_xpose(H, W, k, s);
 }
 int launch_mbconv_small(const FuseArgs& a, int dtype, hipStream_t s) {
     if (a.B == 0) return COSY_OK;
