@@ -366,6 +366,9 @@ def main():
         inst_name, inst = max(members.items(), key=lambda kv: kv[1]['ms'])
         roofline = line(inst_name, inst)                       # the dominant instantiation of the dominant family
         roofline['family'] = line(fam_name, fam)               # ... and the whole family (every instantiation together)
+        # the family's next instantiations by time (blocks 3 / 4 and blocks 14-17 of the wave front are within 1 % of each other: which of
+        # them leads changes from build to build, so both are always in the line)
+        roofline['next_instantiations'] = [line(n_, k_) for n_, k_ in sorted(members.items(), key=lambda kv: -kv[1]['ms']) if n_ != inst_name][:2]
         roofline['traffic'] = None
         tfile = os.path.join(REPO, 'profiles', 'r03_pmc_traffic.json')
         note = 'HBM counters need rocprofv3 (separate process): see profiles/collect.sh'
