@@ -20,7 +20,7 @@ at <= 1e-4 by the parity tests) on this very workload, per parameter group (rota
 to each pose's own translation).
 
 One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel FAMILY of the backbone (all instantiations of one
-kernel template together; the dominant single instantiation is reported beside it), timed live with HIP events recorded on
+kernel template together; the dominant single instantiation and the next two are reported beside it), timed live with HIP events recorded on
 the launch stream after every launch (cosy_effnet_b3_set_profiling) in a second pass over the same steps right after the
 timed region (an event per kernel costs ~6 % of throughput, so not inside it).  `roofline.traffic` (HBM bytes per launch
 from PMC counters) cannot be measured from inside this process: it is taken from profiles/r03_pmc_traffic.json ONLY when
