@@ -97,6 +97,7 @@ struct PwKArgs {
     const void* zeros;
     int nsamp, rowgate;   // DMA kernel gate: samples under one m-tile; 1 = gate the activation fragments per row
     int a_chunked;        // A is [sample][K/16][HW][16] (see PwArgs)
+    int a_nt;             // A is read exactly once (one n-tile) and is large: its DMAs carry the non-temporal hint
 };
 
 // ------------------------------------------------------------------------------------------
@@ -160,8 +161,12 @@ __global__ __launch_bounds__(NWV * 64) void pw_gemm_dma_kernel(PwKArgs a) {
                     src = Wp + ((size_t)(nt * NW + (blk - NA)) * a.nkb_total + kb) * 64 * EPL + lane * EPL;
                 }
             }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            if (a.a_nt && blk < NA)     // wave-uniform
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 2);      // aux 2 = nt
+            else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
 
@@ -394,6 +399,11 @@ static int launch_pw_t(const PwArgs& a, PwCfg c, int dtype, hipStream_t s) {
     k.nkb_total = pw_nkb_total(a.K, dtype); k.nkb_valid = cdiv(a.K, pw_kb(dtype));
     const int grid = cdiv(k.MT, 8) * 8 * k.NT;
     k.zeros = a.zeros; k.nsamp = 2; k.rowgate = 0;
+    // A = the depthwise output D of a wave-front block (chunked layout), read exactly once (a single n-tile) and far larger than the L2:
+    // its DMAs carry the non-temporal hint, so the stream does not evict what the neighbouring kernels keep there.  Measured at 256
+    // crops: project GEMMs of blocks 3 / 4 130.5 -> 112.4 us and the wave fronts that follow them 210 -> 196-200 us, block 2 91 -> 87;
+    // NOT for the NHWC outputs of the unfused depthwise kernel (blocks 0 / 1: 131.6 -> 154.9, 127.9 -> 133.8 us with the hint).
+    k.a_nt = tune_int("COSY_PW_ANT", 1) && a.a_chunked && k.NT == 1 && (size_t)a.M * a.K * sizeof(T) >= ((size_t)64 << 20);
     COSY_REQUIRE(a.zeros, "pw_gemm: the zero page is missing");
     if (a.a_chunked && a.K % 16) { set_error("pw_gemm: the chunked activation layout needs K %% 16 == 0 (K=%d)", a.K); return COSY_EINVAL; }
     return a.gate ? launch_pw_dma<T, true>(k, c, grid, s) : launch_pw_dma<T, false>(k, c, grid, s);
