@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     if (i >= n4) return;
     const int c4 = (int)(i % C4);
     const long row = i / C4;
-    const f32x4 v = ((const f32x4*)x)[i], m = ((const f32x4*)mean)[c4], r = ((const f32x4*)rstd)[c4];
+    const f32x4 v = __builtin_nontemporal_load((const f32x4*)x + i), m = ((const f32x4*)mean)[c4], r = ((const f32x4*)rstd)[c4];
     const f32x4 g = ((const f32x4*)gamma)[c4], b = ((const f32x4*)beta)[c4];
     const float rs = rowscale ? rowscale[row / HW] : 1.f;
     f32x4 o;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     if (i >= n4) return;
     const int c4 = (int)(i % C4);
     const long row = i / C4;
-    const f32x4 v = ((const f32x4*)x)[i], d0 = ((const f32x4*)dout)[i], m = ((const f32x4*)mean)[c4], r = ((const f32x4*)rstd)[c4];
+    const f32x4 v = __builtin_nontemporal_load((const f32x4*)x + i), d0 = __builtin_nontemporal_load((const f32x4*)dout + i), m = ((const f32x4*)mean)[c4], r = ((const f32x4*)rstd)[c4];
     const f32x4 g = ((const f32x4*)gamma)[c4], b = ((const f32x4*)beta)[c4], s1 = ((const f32x4*)sum_dy)[c4], s2 = ((const f32x4*)sum_dyx)[c4];
     const float rs = rowscale ? rowscale[row / HW] : 1.f;
     f32x4 o;
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void rows_scale_kernel(const float* __restrict
     if (i >= n4) return;
     const int c4 = (int)(i % C4);
     const long b = i / C4 / HW;
-    const f32x4 v = ((const f32x4*)a)[i], gg = ((const f32x4*)g)[b * C4 + c4];
+    const f32x4 v = __builtin_nontemporal_load((const f32x4*)a + i), gg = ((const f32x4*)g)[b * C4 + c4];   // a streams through once
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = v[k] * gg[k];

@@ -9,8 +9,6 @@ TAG=${1:-r03}
 OUT=gpurun_out/all_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-# 1. headline line, exactly the driver's command
-python bench.py > $OUT/bench.json 2> $OUT/bench.err
 # 2. per-layer HIP-event table
 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --layers > $OUT/bench_layers.json 2> $OUT/layers_events.txt
 # 3. other configurations on one GPU
@@ -27,6 +25,10 @@ python bench_train.py --kernels > $OUT/bench_train.json 2> $OUT/bench_train_kern
 bash profiles/collect.sh $TAG > $OUT/collect.log 2>&1
 cp -r gpurun_out/prof_$TAG/summary.txt gpurun_out/prof_$TAG/pmc_traffic.json gpurun_out/prof_$TAG/rccl_kernels.csv $OUT/ 2>/dev/null
 cp gpurun_out/prof_$TAG/stats/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+# 1. headline line, exactly the driver's command -- after the PMC passes, with this call's traffic file in place (bench.py reports
+#    roofline.traffic only from a file collected for the same kernel sources)
+cp $OUT/pmc_traffic.json profiles/${TAG%[a-z]}_pmc_traffic.json 2>/dev/null
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
 # 5. batch sweep: throughput and matrix-core utilisation of the GEMM kernels at 256..2048 crops per forward
 for B in 256 512 1024 2048; do
   python bench.py --steps 4 --warmup 2 --detections $B --bsz-objects $B --no-cpu-baseline --no-profile --no-other-dtypes > $OUT/sweep_B$B.json 2> /dev/null
