@@ -23,7 +23,7 @@ One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel FAMILY 
 kernel template together; the dominant single instantiation and the next two are reported beside it), timed live with HIP events recorded on
 the launch stream after every launch (cosy_effnet_b3_set_profiling) in a second pass over the same steps right after the
 timed region (an event per kernel costs ~6 % of throughput, so not inside it).  `roofline.traffic` (HBM bytes per launch
-from PMC counters) cannot be measured from inside this process: it is taken from profiles/r03_pmc_traffic.json ONLY when
+from PMC counters) cannot be measured from inside this process: it is taken from the newest profiles/r*_pmc_traffic.json ONLY when
 that file was collected for the same kernel sources (its `csrc_sha` matches the tree); otherwise null.
 `cpu_baseline` is the CPU oracle (a port of the reference's PyTorch-CPU arithmetic) on a bounded sample: warm-up, then the
 median of 5 repeats, at 1 thread (the reference pins OMP_NUM_THREADS=1) and at N threads.
@@ -46,6 +46,42 @@ MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0, 'fp32': 157.3}
 ALGO_MB_PER_POSE_ITER = {('bf16', 256): 10.7, ('fp16', 256): 10.7, ('fp32', 256): 21.3, ('bf16', 240): 12.4, ('fp16', 240): 12.4, ('fp32', 240): 24.9}
 SKEW = [512, 384, 320, 256, 224, 160, 128, 64]
 DEFAULT_STREAMS = 1
+NAMED_DTYPE = {1: 'bf16', 2: 'fp16', 3: 'bf16'}     # the storage type BASELINE.json's configs[i] names (3: the docstring's choice)
+
+
+# VALU issue costs measured on MI355X (profiles/exp/valu_bench.hip, >= 4 waves per SIMD), cycles per wave64 instruction
+VALU_CYC = dict(fma=3.1, trans=8.7, cvt_pk=4.7)
+GPU_CLOCK_GHZ, N_SIMD = 2.4, 1024
+
+
+def valu_bound(name, k, batch, crop):
+    """Issue-slot floor of a fused-front launch (mbconv_wave_kernel / mbconv_small_kernel): these kernels are bound by the vector
+    ALU beside the matrix cores, not by HBM or MFMA, so the line prices them against THAT roof too.  Model, per 64
+    elements: BN + SiLU = fma + (exp, rcp) + add + mul = 3 x 3.1 + 2 x 8.7 = 26.7 cycles, once per EXPANDED element (S^2 per
+    output element) and once per output element; k^2 tap FMAs, one packed convert per two outputs and one squeeze add per
+    output element.  floor = instruction-cycles / (1024 SIMDs x 2.4 GHz); `frac` = floor / measured launch time."""
+    import re
+    from cosypose_amd import arch
+    m = re.match(r'mbconv_(wave|small)_kernel<[^,]+, (\d), (\d)', name)
+    if not m:
+        return None
+    ks, st = int(m.group(2)), int(m.group(3))
+    silu = 3 * VALU_CYC['fma'] + 2 * VALU_CYC['trans']
+    per_out = st * st * silu + ks * ks * VALU_CYC['fma'] + silu + VALU_CYC['cvt_pk'] / 2 + VALU_CYC['fma']
+    h, w = arch.conv_out(crop[0], 3, 2), arch.conv_out(crop[1], 3, 2)
+    elems, n_layers = 0.0, 0
+    for i, (bk, bs, e, cin, cout) in enumerate(arch.B3_BLOCKS):
+        ho, wo = arch.conv_out(h, bk, bs), arch.conv_out(w, bk, bs)
+        if i in k['layers']:
+            elems += float(batch) * ho * wo * cin * e
+            n_layers += 1
+        h, w = ho, wo
+    if not n_layers:
+        return None
+    floor_us = elems / n_layers / 64.0 * per_out / (N_SIMD * GPU_CLOCK_GHZ * 1e3)
+    return dict(floor_us=round(floor_us, 1), frac=round(floor_us / (k['ms'] / k['n'] * 1e3), 3), cycles_per_64_outputs=round(per_out, 1),
+                model='issue cycles of BN+SiLU on the expanded and the output elements, k*k tap FMAs, convert, squeeze add at the measured '
+                      'per-instruction costs (fma 3.1, exp / rcp 8.7, cvt_pk 4.7 cycles per wave64 instruction), 1024 SIMDs at 2.4 GHz')
 
 
 class SyntheticRenderer:
@@ -184,13 +220,17 @@ def main():
     from cosypose_amd.mesh_db import BatchedMeshes
     from cosypose_amd.pose_predictor import CoarseRefinePosePredictor
     from cosypose_amd.distributed import (init_distributed_mode, all_gather_rows, local_device_index, get_predictions_sharded,
-                                          get_predictions_sharded_scenes, plan_shards)
+                                          get_predictions_sharded_scenes, plan_shards, self_launch, process_group_info)
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    # `python bench.py --gpus N` (the driver's command shape) launches its own N ranks; under torch.distributed.run it is a rank
+    rc = self_launch(args.gpus)
+    if rc is not None:
+        raise SystemExit(rc)
     rank, world = init_distributed_mode('nccl')
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree')
     torch.cuda.set_device(local_device_index())
     H, W = (int(v) for v in args.crop.split('x'))
     cfg_i = args.config
@@ -331,8 +371,9 @@ def main():
         def agg(key):
             out = {}
             for r in recs:
-                k = out.setdefault(key(r), dict(ms=0.0, bytes=0.0, flops=0.0, n=0))
+                k = out.setdefault(key(r), dict(ms=0.0, bytes=0.0, flops=0.0, cbytes=0.0, n=0, layers=set()))
                 k['ms'] += r['ms_avg'] * r['n']; k['bytes'] += r['bytes'] * r['n']; k['flops'] += r['flops'] * r['n']; k['n'] += r['n']
+                k['cbytes'] += r['cbytes'] * r['n']; k['layers'].add(r['layer'])
             return out
         kinds = agg(lambda r: r['name'])
         fams = agg(lambda r: r['name'].split('<')[0].split('+')[0])
@@ -360,6 +401,13 @@ def main():
             d.update(kernel=name, launches_timed=k['n'], avg_launch_us=round(k['ms'] / k['n'] * 1e3, 2),
                      algorithmic_bytes_per_launch=round(k['bytes'] / k['n']), algorithmic_flops_per_launch=round(k['flops'] / k['n']),
                      share_of_backbone_time=round(k['ms'] / total_ms, 4))
+            # the same launch priced by its COMPULSORY bytes only (SURVEY 8(d)'s block-fused model: block inputs / outputs / residuals and
+            # weights; the depthwise output D and the other block-internal tensors count as 0) -- what `frac` would be if D never left the chip
+            d['compulsory_bytes_per_launch'] = round(k['cbytes'] / k['n'])
+            d['compulsory_frac'] = round(k['cbytes'] / k['ms'] / 1e6 / HBM_PEAK_GBS, 4)
+            vb = valu_bound(name, k, prof_bsz, (H, W))
+            if vb:
+                d['valu_bound'] = vb
             return d
         fam_name, fam = max(fams.items(), key=lambda kv: kv[1]['ms'])
         members = {n: k for n, k in kinds.items() if n.split('<')[0].split('+')[0] == fam_name}
@@ -370,16 +418,20 @@ def main():
         # them leads changes from build to build, so both are always in the line)
         roofline['next_instantiations'] = [line(n_, k_) for n_, k_ in sorted(members.items(), key=lambda kv: -kv[1]['ms']) if n_ != inst_name][:2]
         roofline['traffic'] = None
-        tfile = os.path.join(REPO, 'profiles', 'r03_pmc_traffic.json')
-        note = 'HBM counters need rocprofv3 (separate process): see profiles/collect.sh'
-        if os.path.exists(tfile) and cfg_i == 1 and args.crop == '256x256' and (args.detections or 256) == 256:
-            tj = json.load(open(tfile))
-            if tj.get('csrc_sha') == csrc_sha() and tj.get('dtype', 'bf16') == dtype and inst_name in tj.get('kernels', {}):
-                t = tj['kernels'][inst_name]
-                roofline['traffic'] = round(t['read_bytes'] + t['write_bytes'])
-                note = f"profiles/r03_pmc_traffic.json (PMC passes of this command on kernel sources {tj['csrc_sha']})"
+        # HBM bytes per launch from PMC counters cannot be measured from inside this process (rocprofv3 = separate process): taken from the
+        # newest profiles/r*_pmc_traffic.json that was collected for exactly these kernel sources and this dtype, else null
+        import glob
+        note = 'HBM counters need rocprofv3 (separate process): see profiles/collect_all.sh'
+        if cfg_i == 1 and args.crop == '256x256' and (args.detections or 256) == 256:
+            for tfile in sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
+                tj = json.load(open(tfile))
+                if tj.get('csrc_sha') == csrc_sha() and tj.get('dtype', 'bf16') == dtype and inst_name in tj.get('kernels', {}):
+                    t = tj['kernels'][inst_name]
+                    roofline['traffic'] = round(t['read_bytes'] + t['write_bytes'])
+                    note = f"profiles/{os.path.basename(tfile)} (PMC passes of this command on kernel sources {tj['csrc_sha']})"
+                    break
             else:
-                note = 'profiles/r03_pmc_traffic.json was collected for other kernel sources: not reported'
+                note = 'no profiles/r*_pmc_traffic.json was collected for these kernel sources: not reported'
         roofline['traffic_source'] = note
         roofline['backbone_ms_per_forward'] = round(total_ms / max(n_fw, 1), 3)
         roofline['launch'] = (f'{prof_bsz} crops per launch, timed with one HIP event per launch in a single-stream pass after the timed region' +
@@ -424,10 +476,12 @@ def main():
             if dtype != 'fp32':
                 deviation = dict(dev_of(got_main, ref), vs='fp32 HIP path, same workload, refined poses after all iterations, worst of '
                                  f'{got_main.shape[0]} candidates', bound=1e-4)
+                deviation['conforms'] = bool(max(deviation['rotation_abs'], deviation['translation_rel']) <= 1e-4)
             for od, v in other.items():
                 p_ = v.pop('poses')
                 if od != 'fp32':
                     v['pose_deviation'] = dev_of(p_, ref)
+                    v['conforms'] = bool(max(v['pose_deviation'].values()) <= 1e-4)     # north_star: <= 1e-4 on pose parameters
         for v in other.values():
             v.pop('poses', None)
 
@@ -442,13 +496,18 @@ def main():
             'dtype': dtype, 'data': 'synthetic',
             'dtype_note': 'BASELINE configs[1] names bf16; bf16 storage misses north_star\'s 1e-4 pose bound, fp16 (same bytes, same MFMA '
                           'rate) meets it: the headline is fp16, bf16 / fp32 are timed beside it in other_dtypes',
+            'config_deviation': ({'field': 'dtype', 'baseline': NAMED_DTYPE[cfg_i], 'benched': dtype,
+                                  'reason': 'the named type misses north_star\'s 1e-4 pose bound (see other_dtypes.%s: conforms false); same bytes, same '
+                                            'MFMA rate; do not compare `value` with a number quoted on the named type without reading other_dtypes' % NAMED_DTYPE[cfg_i]}
+                                 if NAMED_DTYPE[cfg_i] != dtype else None),
             'pose_deviation': deviation, 'other_dtypes': other or None,
             'config': {'workload': desc + f', coarse {n_coarse} + refiner {n_refine} iterations, {H}x{W} crops, ' +
                                    ('synthetic on-device renders' if args.renderer == 'pregenerated' else
                                     'renders by the on-device HIP rasteriser (6k-triangle meshes) inside the loop'),
                        'pose_iterations_per_step': iters_total, 'candidates_per_rank': per_rank, 'bsz_objects': args.bsz_objects, 'streams': args.streams,
                        'parallelism': f'candidate-sharded x{world}, 1 all-gather of refined poses per step' + (' (RCCL, forced 1-rank group)' if use_dist and world == 1 else ''),
-                       'all_gather_us': round(float(np.median(gather_us)), 1) if gather_us else None},
+                       'all_gather_us': round(float(np.median(gather_us)), 1) if gather_us else None,
+                       'process_group': process_group_info()},
             'roofline': roofline,
             'path_hbm_frac': round(value / world * mb * 1e6 / (HBM_PEAK_GBS * 1e9), 5) if mb else None,
             'cpu_baseline': None,

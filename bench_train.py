@@ -40,13 +40,16 @@ def main():
     from bench import SyntheticRenderer, build_model
     from cosypose_amd import synthetic as syn, train_engine, pose_forward_loss as pfl
     from cosypose_amd.mesh_db import BatchedMeshes
-    from cosypose_amd.distributed import init_distributed_mode, local_device_index
+    from cosypose_amd.distributed import init_distributed_mode, local_device_index, self_launch, process_group_info
 
     if not torch.cuda.is_available():
         raise SystemExit('bench_train.py needs an MI355X (no CPU fallback)')
+    rc = self_launch(args.gpus)          # `python bench_train.py --gpus N` launches its own N ranks
+    if rc is not None:
+        raise SystemExit(rc)
     rank, world = init_distributed_mode('nccl')
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree')
     torch.cuda.set_device(local_device_index())
     B, n_obj, h, w, H, W = args.batch, 21, 480, 640, 240, 320
     labels = np.array([f'obj_{i:06d}' for i in range(1, n_obj + 1)])
@@ -142,7 +145,7 @@ def main():
             'crops_per_s': round(world * B * args.steps / dt, 1),
             'config': {'workload': f'BASELINE configs[4]: {B} crops/GPU from {h}x{w} uint8 frames, {H}x{W} crops, h_pose forward + disentangled '
                                    f'loss + backward + gradient all-reduce ({opt.grad.numel() * 4 / 1e6:.1f} MB fp32) + clip 0.5 + Adam',
-                       'n_points_loss': 2600, 'drop_connect_rate': model.drop_connect_rate},
+                       'n_points_loss': 2600, 'drop_connect_rate': model.drop_connect_rate, 'process_group': process_group_info()},
             'split_ms': {k: round(v / nsp, 2) for k, v in split.items()},
             'peak_memory_gb': round(torch.cuda.max_memory_allocated() / 1e9, 2),
         }))

@@ -85,7 +85,7 @@ class Shade(ctypes.Structure):         # cosy_shade_t
 
 class ProfRec(ctypes.Structure):
     _fields_ = [('name', _c.c_char * 64), ('layer', _I), ('n', _I), ('ms_avg', _F), ('ms_min', _F),
-                ('bytes', _c.c_double), ('flops', _c.c_double)]
+                ('bytes', _c.c_double), ('flops', _c.c_double), ('cbytes', _c.c_double)]
 
 
 def profile_read(handle):
@@ -93,7 +93,7 @@ def profile_read(handle):
     recs = (ProfRec * 1100)()
     n = _I(0)
     check(lib().cosy_effnet_b3_profile_read(handle, recs, 1100, ctypes.byref(n)))
-    return [dict(name=r.name.decode(), layer=r.layer, n=r.n, ms_avg=r.ms_avg, ms_min=r.ms_min, bytes=r.bytes, flops=r.flops)
+    return [dict(name=r.name.decode(), layer=r.layer, n=r.n, ms_avg=r.ms_avg, ms_min=r.ms_min, bytes=r.bytes, flops=r.flops, cbytes=r.cbytes)
             for r in recs[:n.value]]
 
 
@@ -113,6 +113,13 @@ def lib():
         if not os.path.exists(path):
             raise CosyHipError(f'{path} not found: build it with `python -m cosypose_amd.build` '
                                '(or __graft_entry__.build()); cosypose_amd has no CPU / eager fallback')
+        if path == LIB:
+            # the wave kernels keep values in registers hipcc is not told about; only a library whose ISA was checked at build time
+            # (cosypose_amd/build.py stamps the verdict with the library's hash) is loaded -- never a lazily rebuilt, unchecked one
+            from .build import stamp_matches, ISA_STAMP
+            if not stamp_matches(path):
+                raise CosyHipError(f'{path} has no matching clean wave-kernel ISA stamp ({ISA_STAMP}): it was not produced by '
+                                   '`python -m cosypose_amd.build` / __graft_entry__.build() as it stands -- rebuild')
         l = ctypes.CDLL(path)
         for name, (args, res) in _SIGNATURES.items():
             fn = getattr(l, name)

@@ -43,16 +43,54 @@ def _stale_sources(force, tune=False):
     return out
 
 
+WAVE_ISA = os.path.join(LIBDIR, 'kernels_wave.gfx950.s')     # device assembly of THE compile that produced kernels_wave.o
+ISA_STAMP = os.path.join(LIBDIR, 'wave_isa_check.json')
+
+
+def _sha16(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, 'rb') as f:
+        for blk in iter(lambda: f.read(1 << 20), b''):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=False, tune=False):
-    """The shipping library, or with tune=True the experiment build (reads COSY_* environment knobs)."""
+    """The shipping library, or with tune=True the experiment build (reads COSY_* environment knobs).
+    The shipping build ALWAYS ends with the wave-kernel ISA check (on the assembly hipcc wrote while compiling the shipped
+    object) and a stamp that binds the verdict to the linked library's hash: _lib.lib() refuses a library without a matching
+    clean stamp, so neither a lazy rebuild nor a different hipcc can put unchecked wave kernels in front of a caller."""
+    import shutil
+    import tempfile
+    from . import wave_isa
     os.makedirs(LIBDIR, exist_ok=True)
+    if wave_isa.write_fence_include() and verbose:     # csrc/wave_fence.inc follows the variant tables of kernels_wave.hip
+        print('regenerated', wave_isa.FENCE_INC, flush=True)
     stale = _stale_sources(force, tune)
+    if not tune and 'kernels_wave.hip' not in stale and not os.path.exists(WAVE_ISA):
+        stale.append('kernels_wave.hip')
     LIB = TUNE_LIB if tune else globals()['LIB']
     if not stale and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(_obj(s, tune)) for s in SOURCES):
+        if not tune and not stamp_matches(LIB):
+            check_wave_isa(verbose=verbose)
         return LIB
 
     def compile_one(s):
         cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(s, []) + (['-DCOSY_TUNE'] if tune else []) + ['-c', os.path.join(CSRC, s), '-o', _obj(s, tune)]
+        if s == 'kernels_wave.hip' and not tune:
+            # keep the device assembly of this very compile: the ISA check reads what was linked, not a second compile
+            tmp = tempfile.mkdtemp(prefix='cosy_wave_')
+            try:
+                cmd = cmd[:-1] + [os.path.join(tmp, 'kernels_wave.o'), '-save-temps=obj']
+                if verbose:
+                    print(' '.join(cmd), flush=True)
+                subprocess.check_call(cmd)
+                shutil.move(os.path.join(tmp, 'kernels_wave-hip-amdgcn-amd-amdhsa-gfx950.s'), WAVE_ISA)
+                shutil.move(os.path.join(tmp, 'kernels_wave.o'), _obj(s, tune))
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+            return
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -63,45 +101,60 @@ def build(force=False, verbose=False, tune=False):
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
+    if not tune:
+        check_wave_isa(verbose=verbose)
     return LIB
-
-
-ISA_STAMP = os.path.join(LIBDIR, 'wave_isa_check.json')
 
 
 def _wave_src_sha():
     import hashlib
     h = hashlib.sha256()
-    for f in ['kernels_wave.hip', 'net_device.h', 'kernels_net.h', 'cosy_common.h']:
+    for f in ['kernels_wave.hip', 'wave_fence.inc', 'net_device.h', 'kernels_net.h', 'cosy_common.h']:
         h.update(open(os.path.join(CSRC, f), 'rb').read())
     h.update(' '.join(FLAGS + FILE_FLAGS.get('kernels_wave.hip', [])).encode())
     return h.hexdigest()[:16]
 
 
+def read_stamp():
+    import json
+    try:
+        return json.load(open(ISA_STAMP))
+    except (OSError, ValueError):
+        return None
+
+
+def stamp_matches(lib_path=None):
+    """True when the stamp says `clean` for exactly this library file (and, where the sources are present, these sources)."""
+    st = read_stamp()
+    lib_path = lib_path or LIB
+    if not st or not st.get('clean') or not os.path.exists(lib_path) or st.get('lib_sha') != _sha16(lib_path):
+        return False
+    return not os.path.exists(os.path.join(CSRC, 'kernels_wave.hip')) or st.get('src_sha') == _wave_src_sha()
+
+
 def check_wave_isa(verbose=False):
     """kernels_wave.hip keeps its input fragments in registers the compiler is not told about (see the file); that is sound
-    only while no compiler-generated instruction touches them.  profiles/check_wave_isa.py verifies it on the ISA hipcc
-    generates with the shipping flags; the build FAILS when it is not clean (a different hipcc may allocate differently).
-    The verdict is stamped next to the library (source hash + compiler version) so that a GPU-side test can tell whether
-    the library it loads was checked."""
+    only while no compiler-generated instruction touches them.  wave_isa.check_file verifies it on the assembly of the
+    compile that produced the shipped object; the build FAILS when it is not clean (a different hipcc may allocate
+    differently).  The verdict is stamped next to the library: source hash, hash of the linked library, compiler version."""
     import json
-    import sys
-    script = os.path.join(HERE, '..', 'profiles', 'check_wave_isa.py')
-    r = subprocess.run([sys.executable, script] + (['-v'] if verbose else []), capture_output=True, text=True)
+    from . import wave_isa
+    if not os.path.exists(WAVE_ISA) or os.path.getmtime(WAVE_ISA) < os.path.getmtime(os.path.join(CSRC, 'kernels_wave.hip')):
+        raise RuntimeError(f'{WAVE_ISA} is missing or older than kernels_wave.hip: rebuild with build(force=True)')
+    log = []
+    problems, n, _ = wave_isa.check_file(WAVE_ISA, verbose=verbose, out=log.append)
     if verbose:
-        print(r.stdout[-3000:], flush=True)
+        print('\n'.join(log)[-3000:], flush=True)
     ver = subprocess.run([HIPCC, '--version'], capture_output=True, text=True).stdout.strip().split('\n')
-    clean = r.returncode == 0 and 'checked 55 wave kernels' in r.stdout
-    json.dump(dict(clean=clean, src_sha=_wave_src_sha(), hipcc=[l for l in ver if l][:2], summary=r.stdout.strip().split('\n')[-1]),
+    clean = not problems
+    json.dump(dict(clean=clean, src_sha=_wave_src_sha(), lib_sha=_sha16(LIB), kernels=n, hipcc=[l for l in ver if l][:2],
+                   checked='device assembly of the compile that produced kernels_wave.o (-save-temps=obj)', summary=log[-1] if clean else problems[0]),
               open(ISA_STAMP, 'w'), indent=1)
     if not clean:
-        raise RuntimeError('wave-kernel ISA check failed (reserved VGPR range touched, scratch, or wrong allocation):\n' +
-                           r.stdout[-3000:] + r.stderr[-1000:])
+        raise RuntimeError('wave-kernel ISA check failed (reserved VGPR range touched, scratch, wrong allocation or kernel count):\n' + '\n'.join(log)[-3000:])
     return True
 
 
 if __name__ == '__main__':
     import sys
     print(build(force='--force' in sys.argv, verbose=True, tune='--tune' in sys.argv))
-    if '--tune' not in sys.argv:
-        check_wave_isa(verbose=True)

@@ -336,12 +336,14 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
     hipEvent_t* ev = prof ? n->prof_ev + (size_t)n->prof_seg * (PROF_SLOTS + 1) : nullptr;
     int slot = 0;
     if (prof) COSY_CHECK_HIP(hipEventRecord(ev[0], s));
-    auto mark = [&](const char* kname, int layer, double bytes, double flops) -> int {
+    // cbytes: the COMPULSORY part of `bytes` under SURVEY 8(d)'s block-fused model -- block inputs / outputs / residuals and weights
+    // only; the block-internal tensors (expanded E, depthwise output D, squeeze sums, gates, the head activation) count as 0
+    auto mark = [&](const char* kname, int layer, double bytes, double flops, double cbytes) -> int {
         if (!prof || slot >= PROF_SLOTS) return COSY_OK;
         if (n->prof_seg == 0) {
             cosy_prof_rec_t& r = n->prof_rec[slot];
             snprintf(r.name, sizeof(r.name), "%s", kname);
-            r.layer = layer; r.bytes = bytes; r.flops = flops;
+            r.layer = layer; r.bytes = bytes; r.flops = flops; r.cbytes = cbytes;
         }
         ++slot;
         COSY_CHECK_HIP(hipEventRecord(ev[slot], s));
@@ -377,7 +379,8 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
             else if (b.tiled) tile_kernel_name(b.d.cin, b.d.k, b.d.s, n->dtype, kn, sizeof(kn));
             else small_kernel_name(b.d.cin, b.d.k, b.d.s, n->dtype, b.H, b.W, kn, sizeof(kn));
             if ((rc = mark(kn, i, ((double)Bc * b.H * b.W * b.d.cin + (double)Bc * b.Ho * b.Wo * b.cmid + (double)b.d.cin * b.cmid) * esz_d,
-                           2.0 * Bc * b.H * b.W * b.d.cin * b.cmid + 2.0 * Bc * b.Ho * b.Wo * b.cmid * b.d.k * b.d.k))) return rc;
+                           2.0 * Bc * b.H * b.W * b.d.cin * b.cmid + 2.0 * Bc * b.Ho * b.Wo * b.cmid * b.d.k * b.d.k,
+                           ((double)Bc * b.H * b.W * b.d.cin + (double)b.d.cin * b.cmid) * esz_d))) return rc;
         } else {
         if (b.d.e != 1) {
             PwArgs a{};
@@ -385,7 +388,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
             a.M = Bc * b.H * b.W; a.K = b.d.cin; a.N = b.cmid; a.HW = b.H * b.W; a.silu = 1; a.zeros = n->zeros;
             if ((rc = launch_pw_gemm(a, b.exp.cfg, n->dtype, s))) return rc;
             pw_name(b.exp, a);
-            if ((rc = mark(kn, i, pw_bytes(a, Bc), 2.0 * a.M * a.K * a.N))) return rc;
+            if ((rc = mark(kn, i, pw_bytes(a, Bc), 2.0 * a.M * a.K * a.N, ((double)a.M * a.K + (double)a.K * a.N) * esz_d))) return rc;
             src = Ebuf;
         }
         DwArgs d{};
@@ -394,7 +397,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         if ((rc = launch_dwconv(d, n->dtype, s))) return rc;
         snprintf(kn, sizeof(kn), "dwconv_kernel<%s, %d, %d>", dt_name(n->dtype), b.d.k, b.d.s);
         if ((rc = mark(kn, i, ((double)Bc * b.H * b.W * b.cmid + (double)Bc * b.Ho * b.Wo * b.cmid) * esz_d + (double)Bc * b.dw_tiles * b.cmid * 4,
-                       2.0 * Bc * b.Ho * b.Wo * b.cmid * b.d.k * b.d.k))) return rc;
+                       2.0 * Bc * b.Ho * b.Wo * b.cmid * b.d.k * b.d.k, b.d.e == 1 ? (double)Bc * b.H * b.W * b.cmid * esz_d : 0.0))) return rc;
         }
 #ifdef COSY_TUNE
         if (taps && tune_int("COSY_TAP_D", -1) == i) {       // experiment: probe the depthwise output of block i into tap slot 0
@@ -406,7 +409,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         se.gate = w.gate; se.B = Bc; se.C = b.cmid; se.Cse = b.cse; se.HW = b.Ho * b.Wo;
         if ((rc = b.se_batched ? launch_se_batched(se, b.se_wr_p, b.se_br_p, b.se_we_p, w.redv, s) : launch_se(se, s))) return rc;
         if ((rc = mark(b.se_batched ? "se_fc1_kernel+se_fc2_kernel" : "se_kernel", i, (double)Bc * se_tiles * b.cmid * 4 + (double)Bc * b.cmid * 4 + 2.0 * b.cse * b.cmid * 4,
-                       4.0 * Bc * b.cse * b.cmid))) return rc;
+                       4.0 * Bc * b.cse * b.cmid, 2.0 * b.cse * b.cmid * 4))) return rc;
         PwArgs a{};
         a.A = Dbuf; a.Wp = b.proj.Wp; a.out = out; a.scale = b.proj.scale; a.bias = b.proj.bias;
         a.res = b.skip ? in : nullptr; a.gate = w.gate;
@@ -418,7 +421,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
             COSY_CHECK_HIP(hipMemcpyAsync(n->probe_out + (size_t)b0 * b.cmid, w.gate, (size_t)Bc * b.cmid * sizeof(float), hipMemcpyDeviceToDevice, s));
         if ((rc = launch_pw_gemm(a, b.proj.cfg, n->dtype, s))) return rc;
         pw_name(b.proj, a);
-        if ((rc = mark(kn, i, pw_bytes(a, Bc), 2.0 * a.M * a.K * a.N))) return rc;
+        if ((rc = mark(kn, i, pw_bytes(a, Bc), 2.0 * a.M * a.K * a.N, ((double)a.K * a.N + (double)a.M * a.N * (a.res ? 2 : 1)) * esz_d))) return rc;
         return probe(i, out, Bc, b0, b.Ho * b.Wo, b.d.cout, 0);
     };
     auto stage_tap_index = [&](int i) -> int { for (int q = 0; q < 7; ++q) if (STAGE_END[q] == i) return q + 1; return -1; };
@@ -432,7 +435,8 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         const char* x = (const char*)n->X + (size_t)(x_off + b0) * n->H * n->W * 8 * e;
         if ((rc = launch_stem(x, n->stem_w, n->stem_scale, n->stem_bias, w.actc[0], Bc, n->H, n->W, n->Hs, n->Ws, n->dtype, s))) return rc;
         snprintf(kn, sizeof(kn), "stem_kernel<%s>", dt_name(n->dtype));
-        if ((rc = mark(kn, -1, ((double)Bc * n->H * n->W * 8 + (double)Bc * n->Hs * n->Ws * STEM_C) * esz_d, 2.0 * Bc * n->Hs * n->Ws * STEM_C * IN_C * 9))) return rc;
+        if ((rc = mark(kn, -1, ((double)Bc * n->H * n->W * 8 + (double)Bc * n->Hs * n->Ws * STEM_C) * esz_d, 2.0 * Bc * n->Hs * n->Ws * STEM_C * IN_C * 9,
+                       ((double)Bc * n->H * n->W * 8 + (double)Bc * n->Hs * n->Ws * STEM_C) * esz_d))) return rc;
         if ((rc = tap(w.actc[0], Bc, b0, n->Hs * n->Ws, STEM_C, 0))) return rc;
         if ((rc = probe(-1, w.actc[0], Bc, b0, n->Hs * n->Ws, STEM_C, 0))) return rc;
         int cur = 0;
@@ -459,12 +463,12 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
     a.M = B * n->Hf * n->Wf; a.K = HEAD_IN; a.N = HEAD_C; a.HW = n->Hf * n->Wf; a.silu = 1; a.zeros = n->zeros;
     if ((rc = launch_pw_gemm(a, n->head.cfg, n->dtype, s))) return rc;
     pw_name(n->head, a);
-    if ((rc = mark(kn, 26, pw_bytes(a, B), 2.0 * a.M * a.K * a.N))) return rc;
+    if ((rc = mark(kn, 26, pw_bytes(a, B), 2.0 * a.M * a.K * a.N, ((double)a.M * a.K + (double)a.K * a.N) * esz_d))) return rc;
     if ((rc = tap(w.Hd, B, 0, n->Hf * n->Wf, HEAD_C, 8))) return rc;
     if ((rc = probe(26, w.Hd, B, 0, n->Hf * n->Wf, HEAD_C, 0))) return rc;
     if ((rc = launch_pool_fc(w.Hd, n->fc_w, n->fc_b, feat, w.featbuf, pose, B, n->Hf * n->Wf, n->dtype, s))) return rc;
     snprintf(kn, sizeof(kn), "pool_kernel<%s>+fc9_kernel", dt_name(n->dtype));
-    if ((rc = mark(kn, 26, (double)B * n->Hf * n->Wf * HEAD_C * esz_d, 2.0 * B * HEAD_C * (n->Hf * n->Wf + N_POSE)))) return rc;
+    if ((rc = mark(kn, 26, (double)B * n->Hf * n->Wf * HEAD_C * esz_d, 2.0 * B * HEAD_C * (n->Hf * n->Wf + N_POSE), (double)B * (HEAD_C + N_POSE) * 4))) return rc;
     if (prof) { n->prof_nslots = slot; ++n->prof_seg; }
     return COSY_OK;
 }

@@ -100,36 +100,7 @@ template <int TOP, int I> __device__ __forceinline__ f32x4 xfrag_read() {
 // in front of the wait -- keeps every long-lived value of the kernel out of the range by construction; what is left to luck
 // (and to profiles/check_wave_isa.py) are temporaries that live entirely between two fences.
 template <int TOP, int NFRAG> __device__ __forceinline__ void xfrag_fence() {
-    if constexpr (TOP == 256 && NFRAG == 3) asm volatile("; XFENCE" ::: "v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
-    else if constexpr (TOP == 256 && NFRAG == 4) asm volatile("; XFENCE" ::: "v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
-    else if constexpr (TOP == 256 && NFRAG == 5) asm volatile("; XFENCE" ::: "v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
-    else if constexpr (TOP == 256 && NFRAG == 6) asm volatile("; XFENCE" ::: "v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
-    else if constexpr (TOP == 256 && NFRAG == 8) asm volatile("; XFENCE" ::: "v224","v225","v226","v227","v228","v229","v230","v231","v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
-    else if constexpr (TOP == 256 && NFRAG == 9) asm volatile("; XFENCE" ::: "v220","v221","v222","v223","v224","v225","v226","v227","v228","v229","v230","v231","v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
-    else if constexpr (TOP == 256 && NFRAG == 10) asm volatile("; XFENCE" ::: "v216","v217","v218","v219","v220","v221","v222","v223","v224","v225","v226","v227","v228","v229","v230","v231","v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
-    else if constexpr (TOP == 256 && NFRAG == 12) asm volatile("; XFENCE" ::: "v208","v209","v210","v211","v212","v213","v214","v215","v216","v217","v218","v219","v220","v221","v222","v223","v224","v225","v226","v227","v228","v229","v230","v231","v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
-    else if constexpr (TOP == 256 && NFRAG == 16) asm volatile("; XFENCE" ::: "v192","v193","v194","v195","v196","v197","v198","v199","v200","v201","v202","v203","v204","v205","v206","v207","v208","v209","v210","v211","v212","v213","v214","v215","v216","v217","v218","v219","v220","v221","v222","v223","v224","v225","v226","v227","v228","v229","v230","v231","v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
-    else if constexpr (TOP == 256 && NFRAG == 18) asm volatile("; XFENCE" ::: "v184","v185","v186","v187","v188","v189","v190","v191","v192","v193","v194","v195","v196","v197","v198","v199","v200","v201","v202","v203","v204","v205","v206","v207","v208","v209","v210","v211","v212","v213","v214","v215","v216","v217","v218","v219","v220","v221","v222","v223","v224","v225","v226","v227","v228","v229","v230","v231","v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
-    else if constexpr (TOP == 168 && NFRAG == 3) asm volatile("; XFENCE" ::: "v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
-    else if constexpr (TOP == 168 && NFRAG == 4) asm volatile("; XFENCE" ::: "v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
-    else if constexpr (TOP == 168 && NFRAG == 5) asm volatile("; XFENCE" ::: "v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
-    else if constexpr (TOP == 168 && NFRAG == 6) asm volatile("; XFENCE" ::: "v144","v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
-    else if constexpr (TOP == 168 && NFRAG == 8) asm volatile("; XFENCE" ::: "v136","v137","v138","v139","v140","v141","v142","v143","v144","v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
-    else if constexpr (TOP == 168 && NFRAG == 9) asm volatile("; XFENCE" ::: "v132","v133","v134","v135","v136","v137","v138","v139","v140","v141","v142","v143","v144","v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
-    else if constexpr (TOP == 168 && NFRAG == 10) asm volatile("; XFENCE" ::: "v128","v129","v130","v131","v132","v133","v134","v135","v136","v137","v138","v139","v140","v141","v142","v143","v144","v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
-    else if constexpr (TOP == 168 && NFRAG == 12) asm volatile("; XFENCE" ::: "v120","v121","v122","v123","v124","v125","v126","v127","v128","v129","v130","v131","v132","v133","v134","v135","v136","v137","v138","v139","v140","v141","v142","v143","v144","v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
-    else if constexpr (TOP == 168 && NFRAG == 16) asm volatile("; XFENCE" ::: "v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127","v128","v129","v130","v131","v132","v133","v134","v135","v136","v137","v138","v139","v140","v141","v142","v143","v144","v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
-    else if constexpr (TOP == 168 && NFRAG == 18) asm volatile("; XFENCE" ::: "v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127","v128","v129","v130","v131","v132","v133","v134","v135","v136","v137","v138","v139","v140","v141","v142","v143","v144","v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167");
-    else if constexpr (TOP == 128 && NFRAG == 3) asm volatile("; XFENCE" ::: "v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
-    else if constexpr (TOP == 128 && NFRAG == 4) asm volatile("; XFENCE" ::: "v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
-    else if constexpr (TOP == 128 && NFRAG == 5) asm volatile("; XFENCE" ::: "v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
-    else if constexpr (TOP == 128 && NFRAG == 6) asm volatile("; XFENCE" ::: "v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
-    else if constexpr (TOP == 128 && NFRAG == 8) asm volatile("; XFENCE" ::: "v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
-    else if constexpr (TOP == 128 && NFRAG == 9) asm volatile("; XFENCE" ::: "v92","v93","v94","v95","v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
-    else if constexpr (TOP == 128 && NFRAG == 10) asm volatile("; XFENCE" ::: "v88","v89","v90","v91","v92","v93","v94","v95","v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
-    else if constexpr (TOP == 128 && NFRAG == 12) asm volatile("; XFENCE" ::: "v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95","v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
-    else if constexpr (TOP == 128 && NFRAG == 16) asm volatile("; XFENCE" ::: "v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95","v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127");
-    else static_assert(TOP < 0, "xfrag_fence: add the clobber list of this (budget, fragments) pair");
+#include "wave_fence.inc"      // generated from the variant tables below (cosypose_amd/wave_isa.py): one clobber list per (TOP, NFRAG) in use
 }
 template <int MINW> __device__ __forceinline__ void xfrag_reserve() {
     if constexpr (MINW == 2) asm volatile("; XRESERVE" ::: "v255");

@@ -57,6 +57,49 @@ def init_distributed_mode(backend=None, force=None):
     return get_rank(), get_world_size()
 
 
+def self_launch(n_ranks, argv=None):
+    """`python bench.py --gpus N` without a launcher: when WORLD_SIZE is unset and N > 1 the script re-executes itself as N
+    ranks under torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1 at a free port) and returns the launcher's
+    exit code; stdout / stderr pass through, so rank 0's single JSON line is the only line on stdout.  Returns None when
+    nothing has to be launched (N <= 1, or this process already is a rank of a launched job).
+    Replaces the reference's SLURM launch (cosypose/utils/distributed.py:55-69, job-runner/); rank order stays candidate
+    order (cosypose/utils/tensor_collection.py:142-163)."""
+    import socket
+    import subprocess
+    import sys
+    if n_ranks <= 1 or 'WORLD_SIZE' in os.environ:
+        return None
+    argv = list(sys.argv if argv is None else argv)
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    backend = os.environ.get('COSY_DIST_BACKEND', 'nccl')
+    if backend == 'nccl' and n_dev < n_ranks:
+        raise SystemExit(f'--gpus {n_ranks}: {n_dev} GPU(s) visible and RCCL refuses several ranks on one device '
+                         f'(rehearse with COSY_DIST_BACKEND=gloo, which time-slices them on the visible device(s))')
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: the only form the host driver supports
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_ranks}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def process_group_info():
+    """What the bench lines record about the process group: backend, world size and the collective library's version
+    (torch.cuda.nccl.version() is RCCL's on ROCm), so that a record shows RCCL saw N ranks."""
+    info = dict(backend=None, world_size=get_world_size(), rccl_version=None)
+    if dist.is_available() and dist.is_initialized():
+        info['backend'] = dist.get_backend()
+        if info['backend'] == 'nccl':
+            try:
+                info['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:      # noqa: BLE001 -- the version is a label, never a reason to fail a run
+                info['rccl_version'] = f'unavailable ({type(e).__name__})'
+    return info
+
+
 # ---------------------------------------------------------------------------------------------
 # partitioning
 # ---------------------------------------------------------------------------------------------

@@ -5,7 +5,10 @@ Drop-in for `EfficientNet.from_name('efficientnet-b3', in_channels=6)`
 (cosypose/models/efficientnet.py:206-210): `load_state_dict` accepts reference checkpoints
 unchanged (`_conv_stem.weight`, `_bn0.*`, `_blocks.{i}._{expand_conv,bn0,depthwise_conv,bn1,
 se_reduce,se_expand,project_conv,bn2}.*`, `_conv_head.weight`, `_bn1.*`), `forward(x)`
-returns the (B,1536,h,w) feature map.  This module's forward is the inference (eval-mode) engine; the
+returns the (B,1536,h,w) feature map.  ONE restriction the reference does not have: the crop sides must be multiples of 16
+in [128, 1024] (the fused kernels tile the 2x..32x downsampled maps exactly; 240x320 and 256x256 -- what every released CosyPose
+model and the benchmark use -- qualify, EfficientNet-B3's nominal 300x300 does not): other sizes raise ValueError before any
+device work (pad or resize the crop to a supported size).  This module's forward is the inference (eval-mode) engine; the
 train-mode network (batch-statistics BatchNorm, drop_connect, backward: SURVEY 8a-13) runs through
 cosypose_amd.train_engine on the same parameters.
 """
@@ -91,20 +94,38 @@ def flat_params(backbone, pose_fc):
     return blob, parts
 
 
+def check_crop_size(H, W):
+    """cosy_effnet_b3_create's shape rule, raised on the Python side with a message a caller can act on."""
+    if not (128 <= H <= 1024 and 128 <= W <= 1024 and H % 16 == 0 and W % 16 == 0):
+        raise ValueError(f'crop size {H}x{W} not supported by the MI355X backbone: both sides must be multiples of 16 in [128, 1024] '
+                         f'(e.g. 240x320 or 256x256; pad or resize, e.g. to {max(128, min(1024, -(-H // 16) * 16))}x{max(128, min(1024, -(-W // 16) * 16))})')
+
+
 class EnginePool:
     """One NetEngine per HIP stream: an engine's activations and workspaces are private to the forward that is running on
     it, so forwards issued on different streams (CoarseRefinePosePredictor's concurrent chunks, or a caller's own streams)
-    each get their own and may overlap on the device.  Keyed by the raw stream handle (0 = the default stream)."""
+    each get their own and may overlap on the device.  Keyed by the raw stream handle (0 = the default stream).
+    Bounded: at most COSY_ENGINE_POOL_MAX (default 8) engines are kept, the least recently used one is released first
+    (a caller that creates streams without end would otherwise pin one set of weights + workspaces per dead stream)."""
 
     def __init__(self, backbone, pose_fc):
+        import collections
+        import os
         self.backbone, self.pose_fc = backbone, pose_fc
-        self.engines = {}
+        self.engines = collections.OrderedDict()
+        self.max_engines = max(1, int(os.environ.get('COSY_ENGINE_POOL_MAX', '8')))
 
     def current(self, device=None):
         key = (torch.device(device).index if device is not None else None, torch.cuda.current_stream(device).cuda_stream)
         eng = self.engines.get(key)
         if eng is None:
+            while len(self.engines) >= self.max_engines:
+                _, old = self.engines.popitem(last=False)
+                torch.cuda.synchronize()          # the evicted engine's stream may still be running on its workspaces
+                old.release()
             eng = self.engines[key] = NetEngine(self.backbone, self.pose_fc)
+        else:
+            self.engines.move_to_end(key)
         return eng
 
     def release(self):
@@ -133,6 +154,7 @@ class NetEngine:
         if self.backbone.training:
             raise CosyHipError('the inference engine runs eval-mode BatchNorm: call .eval(); the train-mode forward '
                                '(cosypose_amd.train_engine) needs gradients enabled')
+        check_crop_size(H, W)
         key = (H, W, _DTYPES[dtype], device.index, self._weights_version())
         if self.handle is not None and key == self.key and B <= self.capacity:
             return self.handle

@@ -9,7 +9,9 @@ kept for drop-in parity and can be raised (288 GB of HBM holds thousands of crop
 chunks run CONCURRENTLY, round-robin on that many HIP streams, each chunk through coarse and refiner on its own stream
 (every stream has its own engine: activations and workspaces are per stream, cosypose_amd/efficientnet.py EnginePool): a
 forward is ~100 dependent kernel launches, and the ramp-up / drain of each overlaps with another chunk's kernels instead of
-idling the chip.  The chunks are independent (the kernels are batch-invariant), so the results are bit-identical to the
+idling the chip.  HBM cost: every stream that runs a model owns a full engine of it (weights 21 MB in a 16-bit type + workspaces
+sized for the largest chunk it has seen: ~10 MB per crop of 256x256), i.e. (n_streams + 1) x 2 engines for a coarse + refiner pair;
+EnginePool keeps at most COSY_ENGINE_POOL_MAX (default 8) engines per model and evicts the least recently used.  The chunks are independent (the kernels are batch-invariant), so the results are bit-identical to the
 sequential order.  Keep n_streams <= 3: ROCm maps streams onto 4 hardware queues, the caller's stream holds one.
 """
 import numpy as np
@@ -78,11 +80,15 @@ class CoarseRefinePosePredictor(torch.nn.Module):
         main = torch.cuda.current_stream(device)
         keys = [f'{name}/{_iteration_key(n)}' for name, _, n_it in stages for n in range(1, n_it + 1)]
         full = {key: {name: torch.empty((n_objects,) + shape, device=device) for name, shape in _ITERATION_SHAPES} for key in keys}
+        # the chunks are cut on `main` BEFORE the lanes wait for it, and must be views: a gather enqueued on `main` behind the wait
+        # would be read by a lane unsynchronised
+        chunks = [start[np.arange(first, min(first + self.bsz_objects, n_objects))] for first in firsts]
+        base = start.poses.untyped_storage().data_ptr()
+        assert all(c.poses.untyped_storage().data_ptr() == base for c in chunks), 'chunks of consecutive rows must be tensor views'
         for lane in lanes:
-            lane.wait_stream(main)             # frames, K and the initial poses are ready on `main`
-        for i, first in enumerate(firsts):
+            lane.wait_stream(main)             # frames, K, the initial poses and the result buffers are ready on `main`
+        for i, (first, chunk) in enumerate(zip(firsts, chunks)):
             last = min(first + self.bsz_objects, n_objects)
-            chunk = start[np.arange(first, last)]
             labels, im_ids = chunk.infos['label'].values, chunk.infos['batch_im_id'].values
             with torch.cuda.stream(lanes[i % len(lanes)]):
                 poses = chunk.poses
@@ -95,7 +101,8 @@ class CoarseRefinePosePredictor(torch.nn.Module):
                     poses = outputs[_iteration_key(n_it)]['TCO_output']
         for lane in lanes:
             main.wait_stream(lane)
-        return {key: tc.PandasTensorCollection(start.infos, **full[key]) for key in keys}
+        # every result collection owns its infos (as after the sequential path's concatenation): a column added to one is not seen by the others
+        return {key: tc.PandasTensorCollection(start.infos.reset_index(drop=True).copy(), **full[key]) for key in keys}
 
     def make_TCO_init(self, detections, K):
         """Initial poses from 2D boxes: 'v0' (identity rotation at 1 m) or 'z-up+auto-depth' (cosypose_ops.py:121-173)."""
@@ -111,6 +118,7 @@ class CoarseRefinePosePredictor(torch.nn.Module):
     def get_predictions(self, images, K, detections=None, data_TCO_init=None,
                         n_coarse_iterations=1, n_refiner_iterations=1):
         preds = dict()
+        assert detections is not None or data_TCO_init is not None, 'get_predictions needs detections or data_TCO_init'
         n_objects = len(detections if data_TCO_init is None else data_TCO_init)
         if self.n_streams > 1 and n_objects > self.bsz_objects:
             if data_TCO_init is None:

@@ -159,8 +159,9 @@ def concatenate(datas):
         return PandasTensorCollection(infos=pd.DataFrame())
     assert all(d.__class__ is datas[0].__class__ for d in datas)
     if len(datas) == 1:
-        # one chunk (bsz_objects >= the number of objects): the tensors are handed on as they are, not copied row by row
-        return PandasTensorCollection(infos=datas[0].infos, **datas[0].tensors)
+        # one chunk (bsz_objects >= the number of objects): the tensors are handed on as they are (SHARED with the input, not copied row
+        # by row); the infos get the fresh 0..n-1 index every concatenation has (reference :17: reset_index(drop=True))
+        return PandasTensorCollection(infos=datas[0].infos.reset_index(drop=True), **datas[0].tensors)
     infos = pd.concat([d.infos for d in datas], axis=0, sort=False).reset_index(drop=True)
     tensors = {k: torch.cat([getattr(d, k) for d in datas], dim=0) for k in datas[0].tensors.keys()}
     return PandasTensorCollection(infos=infos, **tensors)

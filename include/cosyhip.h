@@ -112,6 +112,8 @@ typedef struct {
     float ms_avg, ms_min;
     double bytes;   /* algorithmic HBM bytes of one launch */
     double flops;   /* algorithmic flops of one launch */
+    double cbytes;  /* the compulsory part of `bytes`: block inputs / outputs / residuals and weights only -- the tensors that stay
+                     * inside an MBConv block (expanded E, depthwise output D, squeeze sums, gates) count as 0 */
 } cosy_prof_rec_t;
 int cosy_effnet_b3_set_profiling(cosy_net_t* net, int enable);
 int cosy_effnet_b3_profile_read(cosy_net_t* net, cosy_prof_rec_t* recs, int cap, int* n_out);

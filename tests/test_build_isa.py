@@ -1,20 +1,49 @@
 """Static checks on the compiled wave kernels (no GPU needed: hipcc cross-compiles gfx950).
 
 kernels_wave.hip loads its input fragments by inline asm into registers the compiler knows nothing about; that is sound
-only while no compiler-generated instruction touches the reserved range and nothing spills.  profiles/check_wave_isa.py
-verifies it on the ISA of the shipping build flags."""
+only while no compiler-generated instruction touches the reserved range and nothing spills.  cosypose_amd/wave_isa.py
+verifies it on the assembly of the compile that produced the shipped object (cosypose_amd/build.py keeps it)."""
 import os
+import re
 import shutil
-import subprocess
-import sys
 
 import pytest
 
 from conftest import REPO
 
+needs_hipcc = pytest.mark.skipif(shutil.which('hipcc') is None and not os.path.exists('/opt/rocm/bin/hipcc'), reason='needs hipcc')
 
-@pytest.mark.skipif(shutil.which('hipcc') is None and not os.path.exists('/opt/rocm/bin/hipcc'), reason='needs hipcc')
+
+@needs_hipcc
 def test_wave_kernels_reserved_registers_and_no_scratch():
-    r = subprocess.run([sys.executable, os.path.join(REPO, 'profiles', 'check_wave_isa.py')], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
-    assert 'checked 55 wave kernels' in r.stdout
+    from cosypose_amd import build, wave_isa
+    lib = build.build()                      # no-op when the tree is built; always leaves a stamp that matches the library
+    assert build.stamp_matches(lib)
+    problems, n, rows = wave_isa.check_file(build.WAVE_ISA)
+    assert not problems, problems[:5]
+    assert n == wave_isa.expected_kernel_count() == len(rows) == build.read_stamp()['kernels']
+
+
+def test_fence_clobber_lists_are_generated_from_the_variant_tables():
+    from cosypose_amd import wave_isa
+    assert open(wave_isa.FENCE_INC).read() == wave_isa.fence_include_text(), 'csrc/wave_fence.inc is stale: python -m cosypose_amd.build'
+    # every variant finds its list, and each list is exactly v[TOP - 4 * NFRAG, TOP)
+    text = wave_isa.fence_include_text()
+    for table in ('COSY_WAVE_VARIANTS', 'COSY_WAVE_VARIANTS_F32'):
+        for v in wave_isa.variant_table(table):
+            top, nfrag = wave_isa.BUDGET[v[6]], v[3] * v[2]
+            line = next(l for l in text.split('\n') if f'TOP == {top} && NFRAG == {nfrag})' in l)
+            regs = [int(r) for r in re.findall(r'"v(\d+)"', line.split(':::')[1])]
+            assert regs == list(range(top - 4 * nfrag, top))
+
+
+def test_loader_refuses_a_library_without_a_matching_stamp(tmp_path, monkeypatch):
+    from cosypose_amd import build, _lib
+    if not os.path.exists(build.LIB):
+        pytest.skip('library not built')
+    stamp = tmp_path / 'stamp.json'
+    stamp.write_text('{"clean": true, "lib_sha": "0000000000000000", "src_sha": "x"}')
+    monkeypatch.setattr(build, 'ISA_STAMP', str(stamp))
+    monkeypatch.setattr(_lib, '_lib', None)
+    with pytest.raises(_lib.CosyHipError, match='ISA stamp'):
+        _lib.lib()

@@ -989,6 +989,15 @@ def test_rasteriser_large_triangles_vs_cpu_twin(oracle):
         renderer.render(infos, dev(TCO), dev(K), resolution=(H, W))
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 5 * 1e3
+    # baseline launch for the timing ratio below: the same batch with the finely tessellated object in every crop
+    infos_fine = [dict(name='fine')] * B
+    renderer.render(infos_fine, dev(TCO), dev(K), resolution=(H, W))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        renderer.render(infos_fine, dev(TCO), dev(K), resolution=(H, W))
+    torch.cuda.synchronize()
+    ms_fine = (time.perf_counter() - t0) / 5 * 1e3
     rgb, depth = rgb.cpu().numpy(), depth.cpu().numpy()
     r_o, d_o, zb = oracle.rasterize(meshes.verts.cpu().numpy(), meshes.colors.cpu().numpy(), meshes.faces.cpu().numpy(),
                                     meshes.n_faces.cpu().numpy(), obj, TCO, K, H, W)
@@ -996,7 +1005,10 @@ def test_rasteriser_large_triangles_vs_cpu_twin(oracle):
     cover = (depth > 0).reshape(B, -1).mean(1)
     print(f'large-triangle batch: coverage per crop {cover.min():.2f}..{cover.max():.2f}, {ms:.2f} ms per 16-crop render')
     assert cover[obj < 3].min() > 0.15           # the coarse objects do fill a good part of their crop
-    assert ms < 5.0                               # 16 crops of 256x256: ~0.2 ms; one thread per big triangle took > 20 ms
+    # one thread per big triangle took > 100x a fine-mesh render of the same batch (> 20 ms against ~0.2 ms); a ratio against a
+    # baseline launch in the same process, not a wall-clock bound: a shared or slow box scales both sides
+    print(f'fine-mesh baseline {ms_fine:.2f} ms')
+    assert ms < 25.0 * max(ms_fine, 0.05), (ms, ms_fine)
 
 
 def _textured_setup(n_obj=4, shading='opengl'):
@@ -1309,16 +1321,49 @@ def test_rccl_single_rank_collectives():
     assert r.returncode == 0 and 'RCCL_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-def test_wave_isa_stamp_matches_loaded_library():
-    """kernels_wave.hip relies on a register range hipcc is not told about; build() verifies it on the generated ISA and
-    stamps the verdict (cosypose_amd/build.py: check_wave_isa).  The library loaded here must be the one that was checked:
-    the stamp exists, says clean, and carries the hash of the kernel sources in this tree."""
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` (the driver's command shape, no launcher around it) spawns its N ranks itself and prints ONE
+    JSON line with n_gpus = N; rehearsed on the 1-GPU box with gloo (RCCL refuses two ranks on one device).  --gpus 1 stays a
+    plain single process; with the nccl backend and too few GPUs the command fails with a message instead of hanging."""
     import json
-    from cosypose_amd import build as hipbuild
-    assert os.path.exists(hipbuild.ISA_STAMP), 'no ISA-check stamp next to libcosyhip.so: build it with __graft_entry__.build()'
-    st = json.load(open(hipbuild.ISA_STAMP))
-    assert st['clean'] is True and st['src_sha'] == hipbuild._wave_src_sha(), st
-    assert os.path.getmtime(hipbuild.LIB) <= os.path.getmtime(hipbuild.ISA_STAMP) + 3600
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', COSY_DIST_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'):
+        env.pop(k, None)
+    fast = ['--steps', '2', '--warmup', '1', '--detections', '32', '--no-cpu-baseline', '--no-other-dtypes', '--no-profile']
+    r = subprocess.run([sys.executable, bench, '--gpus', '2'] + fast, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.split('\n') if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['config']['process_group'] == dict(backend='gloo', world_size=2, rccl_version=None), rec['config']
+    assert rec['config']['candidates_per_rank'] == [32, 32] and rec['value'] > 0
+    # the training bench takes the same route
+    btrain = os.path.join(os.path.dirname(bench), 'bench_train.py')
+    r = subprocess.run([sys.executable, btrain, '--gpus', '2', '--steps', '1', '--warmup', '1', '--batch', '8'], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rec = json.loads([l for l in r.stdout.split('\n') if l.startswith('{')][0])
+    assert rec['n_gpus'] == 2 and rec['config']['process_group']['world_size'] == 2
+    if torch.cuda.device_count() < 2:
+        env_nccl = {k: v for k, v in env.items() if k != 'COSY_DIST_BACKEND'}
+        r = subprocess.run([sys.executable, bench, '--gpus', '2'] + fast, capture_output=True, text=True, timeout=300, env=env_nccl)
+        assert r.returncode != 0 and 'RCCL refuses several ranks on one device' in r.stderr
+
+
+def test_wave_isa_stamp_matches_loaded_library():
+    """kernels_wave.hip relies on a register range hipcc is not told about; build() verifies it on the assembly of the compile
+    that produced the shipped object and stamps the verdict with the hash of the LINKED library (cosypose_amd/build.py).  The
+    library loaded here must be the one that was checked -- _lib.lib() refuses any other -- and the stamp names the sources of
+    this tree and the number of wave kernels the variant tables instantiate."""
+    from cosypose_amd import build as hipbuild, wave_isa, _lib
+    _lib.lib()                                    # raises CosyHipError without a matching clean stamp
+    st = hipbuild.read_stamp()
+    assert st and st['clean'] is True and st['src_sha'] == hipbuild._wave_src_sha(), st
+    assert st['lib_sha'] == hipbuild._sha16(hipbuild.LIB) and st['kernels'] == wave_isa.expected_kernel_count(), st
+    assert hipbuild.stamp_matches()
 
 
 def test_training_reference_loop_unchanged_and_deterministic(golden_train, golden_sd):
