@@ -69,6 +69,7 @@ struct Block {
     float* wave_params;           // wave kernel: BN0 / BN1 / taps packed per 16-channel chunk (wave_pack_params)
     float *b0_fold, *dw_w_fold;   // small kernel: log2(e) * BN0 bias; taps * BN1 scale * ln 2 (the BN0 scale is inside exp_wp_fused)
     bool se_batched;      // squeeze-excite as two batched GEMM kernels (late blocks) instead of one workgroup per sample
+    bool se_fused;        // squeeze-excite inside the project GEMM's prologue: no launch of its own (blocks with small FC matrices)
     float *se_wr_p, *se_br_p, *se_we_p;   // zero-padded copies for the batched form: (CseP, Cmid), (CseP), (Cmid, CseP)
 };
 
@@ -86,6 +87,7 @@ struct cosy_net {
     unsigned tile_mask;   // bit i: ... the LDS-tiled front kernel (mbconv_tile_kernel) when neither of the others is built for its shape
     unsigned wave_mask;   // bit i: ... the wave-autonomous front kernel (mbconv_wave_kernel); both only where the shape is built
     int se_batch_from;    // blocks >= this run the batched squeeze-excite kernels
+    unsigned se_fuse_mask; // bit i: block i may compute its squeeze-excite gate in the project GEMM's prologue (Block::se_fused)
     int probe_layer;      // test probe (cosy_effnet_b3_set_probe): -2 = off
     float* probe_out;
     // activation workspaces: ws[0] holds max_batch samples; ws[1] (half size) serves the second half-batch when the
@@ -255,6 +257,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
             p += b.cmid;
             b.se_wr = up_f32(wr); b.se_br = up_f32(br); b.se_we = up_f32(we); b.se_be = up_f32(be);
             b.se_batched = i >= n->se_batch_from && se_batched_supported(b.cmid, b.cse);
+            b.se_fused = ((n->se_fuse_mask >> i) & 1) && (size_t)b.cse * b.cmid * 8 <= ((size_t)256 << 10) && b.cse <= 128;
             b.se_wr_p = b.se_br_p = b.se_we_p = nullptr;
             if (b.se_batched) {
                 const int csep = (b.cse + 15) & ~15;
@@ -407,19 +410,24 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         SeArgs se{};
         se.partial = w.partial; se.n_tiles = se_tiles; se.w_red = b.se_wr; se.b_red = b.se_br; se.w_exp = b.se_we; se.b_exp = b.se_be;
         se.gate = w.gate; se.B = Bc; se.C = b.cmid; se.Cse = b.cse; se.HW = b.Ho * b.Wo;
-        if ((rc = b.se_batched ? launch_se_batched(se, b.se_wr_p, b.se_br_p, b.se_we_p, w.redv, s) : launch_se(se, s))) return rc;
-        if ((rc = mark(b.se_batched ? "se_fc1_kernel+se_fc2_kernel" : "se_kernel", i, (double)Bc * se_tiles * b.cmid * 4 + (double)Bc * b.cmid * 4 + 2.0 * b.cse * b.cmid * 4,
-                       4.0 * Bc * b.cse * b.cmid, 2.0 * b.cse * b.cmid * 4))) return rc;
+        // Squeeze-excite: blocks 5-17 (b.se_fused; FC matrices <= 222 KB, project GEMMs of <= 2048 workgroups) have NO launch of their own -- every
+        // workgroup of the project GEMM computes the gates of its samples in its prologue (kernels_net.hip); the late blocks (0.65 / 1.77 MB
+        // of FC weights per gate) keep the batched kernels, where a 16-sample tile shares one read of them.
+        if (!b.se_fused) {
+            if ((rc = b.se_batched ? launch_se_batched(se, b.se_wr_p, b.se_br_p, b.se_we_p, w.redv, s) : launch_se(se, s))) return rc;
+            if ((rc = mark(b.se_batched ? "se_fc1_kernel+se_fc2_kernel" : "se_kernel", i, (double)Bc * se_tiles * b.cmid * 4 + (double)Bc * b.cmid * 4 + 2.0 * b.cse * b.cmid * 4,
+                           4.0 * Bc * b.cse * b.cmid, 2.0 * b.cse * b.cmid * 4))) return rc;
+        }
         PwArgs a{};
         a.A = Dbuf; a.Wp = b.proj.Wp; a.out = out; a.scale = b.proj.scale; a.bias = b.proj.bias;
-        a.res = b.skip ? in : nullptr; a.gate = w.gate;
+        a.res = b.skip ? in : nullptr; a.gate = w.gate; a.se_fused = b.se_fused ? &se : nullptr;
         a.M = Bc * b.Ho * b.Wo; a.K = b.cmid; a.N = b.d.cout; a.HW = b.Ho * b.Wo; a.silu = 0; a.zeros = n->zeros;
         // the wave front (and the row-mapped 8x8 kernel) write D as [sample][Cmid/16][HW][16]
         a.a_chunked = b.wave || (b.small && small_writes_chunked(b.d.cin, b.cmid, b.H, b.W, b.Ho, b.Wo, b.d.k, b.d.s, n->dtype));
         if ((rc = probe(100 + i, Dbuf, Bc, b0, b.Ho * b.Wo, b.cmid, a.a_chunked))) return rc;
-        if (n->probe_layer == 200 + i && n->probe_out)
-            COSY_CHECK_HIP(hipMemcpyAsync(n->probe_out + (size_t)b0 * b.cmid, w.gate, (size_t)Bc * b.cmid * sizeof(float), hipMemcpyDeviceToDevice, s));
         if ((rc = launch_pw_gemm(a, b.proj.cfg, n->dtype, s))) return rc;
+        if (n->probe_layer == 200 + i && n->probe_out)      // behind the GEMM: with the squeeze-excite in its prologue that is where the gate is written
+            COSY_CHECK_HIP(hipMemcpyAsync(n->probe_out + (size_t)b0 * b.cmid, w.gate, (size_t)Bc * b.cmid * sizeof(float), hipMemcpyDeviceToDevice, s));
         pw_name(b.proj, a);
         if ((rc = mark(kn, i, pw_bytes(a, Bc), 2.0 * a.M * a.K * a.N, ((double)a.K * a.N + (double)a.M * a.N * (a.res ? 2 : 1)) * esz_d))) return rc;
         return probe(i, out, Bc, b0, b.Ho * b.Wo, b.d.cout, 0);
@@ -536,6 +544,13 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
         // measured (256 crops): batched from block 19: +1.5 %, from 9: another +1.1 % over one-workgroup-per-sample everywhere; the early
         // blocks (Cmid <= 288, Cse <= 12) stay on se_kernel: two dependent launches cost what its one does
         n->se_batch_from = tune_int("COSY_SE_BATCH_FROM", 9);
+        // round 4: blocks 5-17 compute the gate inside the project GEMM's prologue (no squeeze-excite launch at all).  Measured per block
+        // at 256 crops (profiles/r04_se_fused_ab.txt): the prologue adds 6-11 us to the GEMM (5-8 dependent L2 round trips under the
+        // DMA streams of the co-resident workgroups) against 8-14 us of squeeze-excite kernel(s): -2.3..-6.5 us per block, 13 launches
+        // fewer per forward.  NOT for blocks 0-4 (their project GEMMs stream 8,000-16,000 workgroups and every one would redo the
+        // gate: block 0 160 -> 458 us, blocks 2-4 +13..22 us), block 18 (+3 us) or blocks 19-25 (0.65 / 1.77 MB of FC weights per gate:
+        // the size rule in build_weights keeps them on the batched kernels, where a 16-sample tile shares one read of them).
+        n->se_fuse_mask = (unsigned)tune_int("COSY_SE_FUSE_MASK", 0x3ffe0);
         n->small_mask = (unsigned)tune_int("COSY_SMALL_MASK", 0x3f80000);
         n->tile_mask = (unsigned)tune_int("COSY_TILE_MASK", 0x13c);         // blocks 2-5 and 8 (measured in round 1: it loses on the k=5 stride-1 blocks 6/7)   // blocks 19-25 (8x8 / 7x10 maps): whole-image kernel
         n->wave_mask = (unsigned)tune_int("COSY_WAVE_MASK", 0x3fffc);   // blocks 2-17: maps 16..128 pixels wide, stride per shape table

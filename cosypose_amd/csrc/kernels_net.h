@@ -4,6 +4,8 @@
 
 namespace cosy {
 
+struct SeArgs;
+
 // tile configuration of the pointwise-conv GEMM: WV waves as (WV/WN) x WN, each 64 rows x 16*NI columns:
 // BN = 16*NI*WN, BM = 64*(WV/WN)
 struct PwCfg { int NI, WN, WV = 4; };
@@ -28,6 +30,8 @@ struct PwArgs {
     int silu;
     const void* zeros;   // >= 16 zero bytes (global): source of padded rows/k for the LDS-DMA pipeline
     int a_chunked;       // 1: A is laid out [sample][K/16][HW][16] (what the wave front writes: a wave's row is one contiguous run)
+    const struct SeArgs* se_fused;   // non-null: NO squeeze-excite launch ran -- every workgroup computes the gates of the samples under its
+                                     // m-tile in its prologue from the squeeze partial sums (se_fused->gate == gate, written for probes)
 };
 int launch_pw_gemm(const PwArgs& a, PwCfg cfg, int dtype, hipStream_t s);
 void pw_kernel_name(const PwArgs& a, PwCfg c, int dtype, char* buf, size_t n);

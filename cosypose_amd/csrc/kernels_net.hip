@@ -98,6 +98,10 @@ struct PwKArgs {
     int nsamp, rowgate;   // DMA kernel gate: samples under one m-tile; 1 = gate the activation fragments per row
     int a_chunked;        // A is [sample][K/16][HW][16] (see PwArgs)
     int a_nt;             // A is read exactly once (one n-tile) and is large: its DMAs carry the non-temporal hint
+    // squeeze-excite computed in the prologue (PwArgs::se_fused): squeeze partial sums (B, se_tiles, K), reduce FC (Cse, K) + bias,
+    // expand FC stored (Cse, K) + bias (K); se_wr == nullptr: the gate rows are read from `gate` (a squeeze-excite kernel wrote them)
+    const float* se_partial; const float* se_wr; const float* se_br; const float* se_we; const float* se_be; float* gate_out;
+    int se_tiles, Cse; float inv_hw;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -199,6 +203,92 @@ __global__ __launch_bounds__(NWV * 64) void pw_gemm_dma_kernel(PwKArgs a) {
     }
     if constexpr (GATE) {
         const int b_first = m0 / a.HW;
+        if (a.se_wr) {
+            // ---- squeeze-excite in the prologue (efficientnet.py:85-88): no se launch between the front kernel and this GEMM.  Every
+            // workgroup computes the gate of each sample under its m-tile: pooled = sum of the squeeze partials / HW -> reduce FC + bias
+            // -> swish -> expand FC + bias -> sigmoid, fp32, fixed summation order (deterministic; a sample's gate depends on nothing
+            // but that sample: batch-invariant).  The FC matrices are tiny next to the tile's operands (blocks 0-18: 3-220 KB, L2 hits
+            // shared by all workgroups) and their loads are issued in batches of SEB independent 16-byte loads, so the prologue costs a
+            // few L2 latencies in the shadow of the first DMAs -- against a dependent 8-15 us launch (+ its launch gap) per block.
+            constexpr int NT = NWV * 64;
+            constexpr int SEB = NI * MI >= 20 ? 16 : NI * MI >= 16 ? 12 : 8;     // loads in flight per thread: what the tile's own budget leaves
+            float* pooled = gl + a.nsamp * Kpad;
+            float* redv = pooled + Kpad;
+            const int C4 = K >> 2, Cse = a.Cse;
+            const int P = Cse * 8 <= NT ? 8 : Cse * 4 <= NT ? 4 : Cse * 2 <= NT ? 2 : 1;     // lanes per reduce-FC output
+            const int n_under = (min(m0 + BM, M) - 1) / a.HW - b_first + 1;      // samples that own a row of this m-tile (<= nsamp)
+            for (int i = tid + n_under * (Kpad >> 2); i < a.nsamp * (Kpad >> 2); i += NT)     // rows no pixel selects stay finite (0)
+                ((f32x4*)gl)[HALF_GATE ? i >> 1 : i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int sidx = 0; sidx < n_under; ++sidx) {
+                const int b = b_first + sidx;
+                constexpr bool live = true;
+                if (live) {
+                    const f32x4* part = (const f32x4*)(a.se_partial + (size_t)b * a.se_tiles * K);
+                    for (int c = tid; c < C4; c += NT) {
+                        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+                        int t = 0;
+                        for (; t + 1 < a.se_tiles; t += 2) { s0 += part[(size_t)t * C4 + c]; s1 += part[(size_t)(t + 1) * C4 + c]; }
+                        if (t < a.se_tiles) s0 += part[(size_t)t * C4 + c];
+                        ((f32x4*)pooled)[c] = (s0 + s1) * a.inv_hw;
+                    }
+                }
+                __syncthreads();
+                if (live) {
+                    const int slots = NT / P, prt = tid & (P - 1);
+                    for (int j0 = 0; j0 < Cse; j0 += slots) {
+                        const int j = j0 + tid / P;
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                        const f32x4* wr = (const f32x4*)(a.se_wr + (size_t)min(j, Cse - 1) * K);
+                        for (int c0 = prt; c0 < C4; c0 += P * SEB) {
+                            f32x4 w[SEB];
+#pragma unroll
+                            for (int u = 0; u < SEB; ++u) w[u] = wr[min(c0 + P * u, C4 - 1)];
+#pragma unroll
+                            for (int u = 0; u < SEB; ++u)
+                                if (c0 + P * u < C4) acc += w[u] * ((const f32x4*)pooled)[c0 + P * u];
+                        }
+                        float sv = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                        if (P >= 2) sv += __shfl_xor(sv, 1, 64);
+                        if (P >= 4) sv += __shfl_xor(sv, 2, 64);
+                        if (P >= 8) sv += __shfl_xor(sv, 4, 64);
+                        if (prt == 0 && j < Cse) {
+                            sv += a.se_br[j];
+                            redv[j] = sv * (1.f / (1.f + expf(-sv)));
+                        }
+                    }
+                }
+                __syncthreads();
+                for (int c = tid; c < (Kpad >> 2); c += NT) {
+                    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+                    if (live && c < C4) {
+                        const f32x4* we = (const f32x4*)a.se_we + c;
+                        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+                        for (int j0 = 0; j0 < Cse; j0 += SEB) {
+                            f32x4 w[SEB];
+#pragma unroll
+                            for (int u = 0; u < SEB; ++u) w[u] = we[(size_t)min(j0 + u, Cse - 1) * C4];
+#pragma unroll
+                            for (int u = 0; u < SEB; u += 2) {
+                                if (j0 + u < Cse) s0 += w[u] * redv[j0 + u];
+                                if (u + 1 < SEB && j0 + u + 1 < Cse) s1 += w[u + 1] * redv[j0 + u + 1];
+                            }
+                        }
+                        const f32x4 be = ((const f32x4*)a.se_be)[c];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[e] = 1.f / (1.f + expf(-(s0[e] + s1[e] + be[e])));
+                        // the workgroup that holds the sample's first row (first n-tile) publishes the gate: test probes read it
+                        if (nt == 0 && (long)b * a.HW >= m0) ((f32x4*)(a.gate_out + (size_t)b * K))[c] = g;
+                    }
+                    if constexpr (HALF_GATE) {
+                        typedef f16_t h4_t __attribute__((ext_vector_type(4)));
+                        ((h4_t*)gl)[(sidx * Kpad >> 2) + c] = h4_t{(f16_t)g[0], (f16_t)g[1], (f16_t)g[2], (f16_t)g[3]};
+                    } else {
+                        ((f32x4*)gl)[(sidx * Kpad >> 2) + c] = g;
+                    }
+                }
+                // the next sample's pooled / redv are written behind barriers that every thread reaches after this phase
+            }
+        } else
         for (int i = tid; i < a.nsamp * Kpad; i += NWV * 64) {
             const int sidx = i / Kpad, k = i - sidx * Kpad;
             const long mrow = (long)(b_first + sidx) * a.HW;
@@ -331,7 +421,8 @@ static int launch_pw_dma_mi(PwKArgs k, hipStream_t s) {
     const int grid = cdiv(k.MT, 8) * 8 * k.NT;
     k.rowgate = GATE && (k.HW % 64 != 0);
     k.nsamp = k.rowgate ? pw_gate_nsamp(16 * MI * WM, k.HW) : 2;
-    const size_t lds = (size_t)NS * NB * 1024 + 1024 + (GATE ? (size_t)k.nsamp * k.nkb_total * DT<T>::KB * 4 : 0);
+    const size_t lds = (size_t)NS * NB * 1024 + 1024 + (GATE ? (size_t)k.nsamp * k.nkb_total * DT<T>::KB * 4 : 0) +
+                       (GATE && k.se_wr ? ((size_t)k.nkb_total * DT<T>::KB + 128) * 4 : 0);       // + pooled[Kpad], redv[<= 128]
     COSY_REQUIRE(lds <= 160 * 1024, "pw_gemm_dma: the gate rows of %d samples x K=%d do not fit the LDS (map of %d pixels too small)", k.nsamp, k.K, k.HW);
     // once per instantiation and process, race-free: function-local statics are initialised exactly once (C++11), also when two
     // nets launch from two threads at the same time (the header promises thread-safety across distinct nets / streams)
@@ -399,6 +490,14 @@ static int launch_pw_t(const PwArgs& a, PwCfg c, int dtype, hipStream_t s) {
     k.nkb_total = pw_nkb_total(a.K, dtype); k.nkb_valid = cdiv(a.K, pw_kb(dtype));
     const int grid = cdiv(k.MT, 8) * 8 * k.NT;
     k.zeros = a.zeros; k.nsamp = 2; k.rowgate = 0;
+    k.se_partial = k.se_wr = k.se_br = k.se_we = k.se_be = nullptr; k.gate_out = nullptr; k.se_tiles = 0; k.Cse = 0; k.inv_hw = 0.f;
+    if (a.se_fused) {
+        const SeArgs& se = *a.se_fused;
+        COSY_REQUIRE(a.gate && se.gate == a.gate && se.C == a.K && se.HW == a.HW && se.Cse >= 1 && se.Cse <= 128 && a.K % 4 == 0,
+                     "pw_gemm: fused squeeze-excite arguments do not match the GEMM (C=%d K=%d Cse=%d)", se.C, a.K, se.Cse);
+        k.se_partial = se.partial; k.se_tiles = se.n_tiles; k.se_wr = se.w_red; k.se_br = se.b_red; k.se_we = se.w_exp; k.se_be = se.b_exp;
+        k.gate_out = se.gate; k.Cse = se.Cse; k.inv_hw = 1.f / (float)se.HW;
+    }
     // A = the depthwise output D of a wave-front block (chunked layout), read exactly once (a single n-tile) and far larger than the L2:
     // its DMAs carry the non-temporal hint, so the stream does not evict what the neighbouring kernels keep there.  Measured at 256
     // crops: project GEMMs of blocks 3 / 4 130.5 -> 112.4 us and the wave fronts that follow them 210 -> 196-200 us, block 2 91 -> 87;

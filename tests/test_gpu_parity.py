@@ -298,13 +298,20 @@ def test_backbone_fp32_third_crop_size_vs_oracle(model, oracle, golden_sd, hw):
 
 
 def test_unsupported_crop_size_fails_loudly(model):
+    from cosypose_amd import _lib
     from cosypose_amd._lib import CosyHipError
     model.compute_dtype = 'fp32'
-    for hw in ((100, 100), (250, 250), (64, 64)):
+    for hw in ((100, 100), (250, 250), (64, 64), (300, 300)):
         model.render_size = hw
-        with pytest.raises(CosyHipError, match='not supported'):
+        with pytest.raises(ValueError, match='not supported by the MI355X backbone'):     # raised on the Python side, before any device work
             model._net(1, torch.device('cuda'))
     model.render_size = (240, 320)
+    # ... and the C ABI itself refuses the same sizes (a caller that binds libcosyhip.so directly)
+    import ctypes
+    blob = torch.zeros(16)
+    h = ctypes.c_void_p()
+    rc = _lib.lib().cosy_effnet_b3_create(blob.data_ptr(), 16, _lib.COSY_F32, 250, 250, 1, ctypes.byref(h))
+    assert rc != 0 and b'not supported' in _lib.lib().cosy_last_error()
 
 
 def _emulated_backbone(oracle, golden_sd, dtype, plan):
