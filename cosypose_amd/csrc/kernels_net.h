@@ -8,9 +8,10 @@ struct SeArgs;
 
 // tile configuration of the pointwise-conv GEMM: WV waves as (WV/WN) x WN, each 64 rows x 16*NI columns:
 // BN = 16*NI*WN, BM = 64*(WV/WN)
-struct PwCfg { int NI, WN, WV = 4; };
+// KG > 1: in-workgroup split-K, the WV waves form KG groups of WV/KG waves that share one output tile (kernels_net.hip)
+struct PwCfg { int NI, WN, WV = 4, KG = 1; };
 static inline int pw_bn(PwCfg c) { return 16 * c.NI * c.WN; }
-static inline int pw_bm(PwCfg c) { return 64 * (c.WV / c.WN); }
+static inline int pw_bm(PwCfg c) { return 64 * (c.WV / c.KG / c.WN); }
 PwCfg pw_choose_cfg(int N);
 PwCfg pw_choose_cfg_late(int K, int N, int HW, bool gated);
 int pw_kb(int dtype);                     // k elements per fragment block: 32 (bf16) / 16 (f32)

@@ -54,6 +54,13 @@ PwCfg pw_choose_cfg_late(int K, int N, int HW, bool gated) {
     // head (N = 1536) 43 -> 38 us, N = 384 unchanged; N = 96 unchanged and N = 136 slower (63 us vs 45 us with the one-pass
     // 160-column tile) -> only for N >= 192.
     static const int pw8 = tune_int("COSY_PW8", 1);
+    // K >= 1024 (blocks 19-25 project): 16 waves in two K-groups (see the kernel); N = 384 as two 192-column tiles, so that 256 crops are
+    // 256 workgroups = one per CU (three 128-column tiles are 384 = a second round on half the CUs)
+    // Measured at 256 crops, fp16 (profiles/r04_gemm_splitk.txt): blocks 19-23 33.3 -> 28.4 us, block 24 41.5 -> 39.8, block 25 63.6 -> 57.2.
+    // A 128 x 256 full-N tile (A read once, 128 workgroups) took 65 us for block 19: what bounds these layers is the LDS-DMA rate of ONE CU
+    // (~25 GB/s: 32 KB per 1.3 us interval here, 16 KB per 0.75 us with 8 waves), not a chip-wide byte count -- fewer, larger tiles lose.
+    static const int pw16 = tune_int("COSY_PW16", 1);
+    if (pw16 && gated && K >= 1024 && HW % 64 == 0 && N >= 192) return N > 256 && N <= 384 ? PwCfg{3, 4, 16, 2} : PwCfg{2, 4, 16, 2};
     if (pw8 && K >= 128 && N >= 192 && (!gated || HW % 64 == 0)) return PwCfg{2, 4, 8};
     static const int wide = tune_int("COSY_PW_WIDE", 1);
     if (wide && K >= 96 && HW >= 64 && N > 128 && N <= 160) return PwCfg{5, 2};
@@ -116,20 +123,31 @@ struct PwKArgs {
 // (W[n,k]*g[b,k]) at fragment-read time from a gate row staged in LDS when the 64 pixel rows of a wave belong to one
 // sample (HW % 64 == 0); otherwise (240x320 input) each lane scales its ACTIVATION fragments with its own row's gate.
 // ------------------------------------------------------------------------------------------
-template <typename T, int NI, int WN, int NS, bool GATE, int MI, int NWV = 4>
+// KG = 2 (round 4, the K >= 1024 project convs of the 8x8 maps): IN-WORKGROUP SPLIT-K.  Those layers have only M / 128 = 128 m-tiles
+// at 256 crops, i.e. ONE 8-wave workgroup per CU (2 waves per SIMD) that spends a k-step waiting -- barrier, DMA issue, fragment reads,
+// 8 MFMAs, in sequence: 0.75 us per k-step against 0.11 us of matrix-pipe time.  With KG = 2 the workgroup has 16 waves in two K-groups;
+// a ring stage holds TWO k-blocks, group g multiplies k-block 2 * step + g of the same output tile, so a barrier interval carries twice
+// the MFMA work at 4 waves per SIMD and the loop has half as many barriers.  After the loop group 1 hands its accumulators to group 0
+// through the (now free) ring -- a fixed-order fp32 add, deterministic -- and group 0 runs the epilogue.  No global partials, no combine
+// launch, the activations are still read once per n-tile.
+template <typename T, int NI, int WN, int NS, bool GATE, int MI, int NWV = 4, int KG = 1>
 __global__ __launch_bounds__(NWV * 64) void pw_gemm_dma_kernel(PwKArgs a) {
     using D = DT<T>;
     using raw_t = typename D::raw_t;
     constexpr int EPL = D::EPL, KB = D::KB;
-    constexpr int WM = NWV / WN, BM = 16 * MI * WM, BN = 16 * NI * WN;
+    constexpr int GW = NWV / KG;              // waves of one K-group
+    constexpr int WM = GW / WN, BM = 16 * MI * WM, BN = 16 * NI * WN;
     constexpr int NA = BM / 16, NW = NI * WN, NB = NA + NW;
-    constexpr int L = (NB + NWV - 1) / NWV;   // DMA instructions per wave per k-block
+    constexpr int SB = KG * NB;               // 1 KiB blocks of one ring stage (KG k-blocks)
+    constexpr int L = (SB + NWV - 1) / NWV;   // DMA instructions per wave per stage
+    static_assert(GW * KG == NWV && WM * WN == GW, "wave grid");
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* dummy = lds + NS * NB * 1024;
+    char* dummy = lds + NS * SB * 1024;
     float* gl = (float*)(dummy + 1024);   // GATE: [nsamp][Kpad] gate rows of the samples under this m-tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
+    const int kgp = wave / GW, wq = wave % GW;      // K-group, wave inside the group
+    const int wm = wq / WN, wn = wq % WN;
     const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
     const int mt = (jj / a.NT) * 8 + xcd, nt = jj % a.NT;
     if (mt >= a.MT) return;
@@ -146,18 +164,18 @@ __global__ __launch_bounds__(NWV * 64) void pw_gemm_dma_kernel(PwKArgs a) {
     size_t achunk[L];
 #pragma unroll
     for (int i = 0; i < L; ++i) {
-        const int m = min(m0 + (i * NWV + wave) * 16 + row, M - 1), bs = m / a.HW;
+        const int m = min(m0 + ((i * NWV + wave) % NB) * 16 + row, M - 1), bs = m / a.HW;
         achunk[i] = a.a_chunked ? ((size_t)bs * (K >> 4) * a.HW + (m - bs * a.HW)) * 16 : 0;
     }
-    auto issue = [&](int kb) {
-        char* st = lds + (kb % NS) * NB * 1024;
+    auto issue = [&](int ks) {              // stage ks = the k-blocks ks * KG .. ks * KG + KG - 1
+        char* st = lds + (ks % NS) * SB * 1024;
 #pragma unroll
         for (int i = 0; i < L; ++i) {
-            const int blk = i * NWV + wave;
+            const int sblk = i * NWV + wave, blk = sblk % NB, kb = ks * KG + sblk / NB;
             const void* src = a.zeros;
             char* dst = dummy;
-            if (kb < a.nkb_valid && blk < NB) {
-                dst = st + blk * 1024;
+            if (kb < a.nkb_valid && sblk < SB) {
+                dst = st + sblk * 1024;
                 if (blk < NA) {
                     const int m = m0 + blk * 16 + row, k = kb * KB + kg * EPL;
                     if (m < M && k < K) src = a.a_chunked ? A + achunk[i] + (size_t)(k >> 4) * a.HW * 16 + (k & 15) : A + (size_t)m * K + k;
@@ -189,21 +207,24 @@ __global__ __launch_bounds__(NWV * 64) void pw_gemm_dma_kernel(PwKArgs a) {
     typedef T rv4_t __attribute__((ext_vector_type(4)));
     constexpr bool RES_PREFETCH = sizeof(T) == 2;
     rv4_t rpre[RES_PREFETCH ? MI : 1][RES_PREFETCH ? NI : 1];
-    if constexpr (RES_PREFETCH) {
-        if (a.res) {
-            const int nl_ = n0 + wn * 16 * NI + kg * 4 * NI;
+    auto prefetch_residual = [&]() {
+        if constexpr (RES_PREFETCH) {
+            if (a.res && kgp == 0) {
+                const int nl_ = n0 + wn * 16 * NI + kg * 4 * NI;
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int m = min(m0 + (wm * MI + mi) * 16 + row, M - 1);
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int m = min(m0 + (wm * MI + mi) * 16 + row, M - 1);
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    rpre[mi][ni] = *(const rv4_t*)((const T*)a.res + (size_t)m * N + min(nl_ + ni * 4, N - 4));
+                    for (int ni = 0; ni < NI; ++ni)
+                        rpre[mi][ni] = *(const rv4_t*)((const T*)a.res + (size_t)m * N + min(nl_ + ni * 4, N - 4));
+                }
             }
         }
-    }
+    };
+    if constexpr (KG == 1) prefetch_residual();     // split-K tiles (128 registers per wave): behind the loop, in the shadow of the hand-over
     if constexpr (GATE) {
         const int b_first = m0 / a.HW;
-        if (a.se_wr) {
+        if (KG == 1 && a.se_wr) {     // (the split-K tiles serve blocks 19-25, whose squeeze-excite stays on the batched kernels)
             // ---- squeeze-excite in the prologue (efficientnet.py:85-88): no se launch between the front kernel and this GEMM.  Every
             // workgroup computes the gate of each sample under its m-tile: pooled = sum of the squeeze partials / HW -> reduce FC + bias
             // -> swish -> expand FC + bias -> sigmoid, fp32, fixed summation order (deterministic; a sample's gate depends on nothing
@@ -301,12 +322,15 @@ __global__ __launch_bounds__(NWV * 64) void pw_gemm_dma_kernel(PwKArgs a) {
         __syncthreads();
     }
 
-    for (int kb = 0; kb < a.nkb_valid; ++kb) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * L) : "memory");  // k-block kb has landed (this wave's part)
-        __builtin_amdgcn_s_barrier();                                          // ... and everybody's; stage (kb-1)%NS is free
+    const int nks = (a.nkb_valid + KG - 1) / KG;
+    for (int ks = 0; ks < nks; ++ks) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * L) : "memory");  // stage ks has landed (this wave's part)
+        __builtin_amdgcn_s_barrier();                                          // ... and everybody's; stage (ks-1)%NS is free
         asm volatile("" ::: "memory");
-        issue(kb + NS - 1);
-        const char* st = lds + (kb % NS) * NB * 1024;
+        issue(ks + NS - 1);
+        const int kb = ks * KG + kgp;                                          // this K-group's k-block of the stage
+        if (KG > 1 && kb >= a.nkb_valid) continue;                             // odd number of k-blocks: the last stage is half full (wave-uniform)
+        const char* st = lds + ((ks % NS) * SB + kgp * NB) * 1024;
         raw_t fw[NI], fa[MI];
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) fw[ni] = *(const raw_t*)(st + (NA + wn * NI + ni) * 1024 + lane * 16);
@@ -362,6 +386,25 @@ __global__ __launch_bounds__(NWV * 64) void pw_gemm_dma_kernel(PwKArgs a) {
             for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], fw[ni], fa[mi]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (KG > 1) {
+        // K-group 1 -> K-group 0 through the ring (every wave is past its last fragment read behind this barrier): one fixed-order add
+        static_assert(KG == 2 && GW * MI * NI * 1024 <= NS * SB * 1024, "split-K hand-over fits the ring");
+        prefetch_residual();
+        __syncthreads();
+        f32x4* red = (f32x4*)lds + (size_t)wq * MI * NI * 64 + lane;
+        if (kgp == 1) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) red[(mi * NI + ni) * 64] = acc[mi][ni];
+        }
+        __syncthreads();
+        if (kgp != 0) return;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] += red[(mi * NI + ni) * 64];
+    }
 
     // ---- epilogue: lane holds, for pixel row m, the 4*NI consecutive channels starting at nl
     const int nl = n0 + wn * 16 * NI + kg * 4 * NI;
@@ -414,9 +457,9 @@ __global__ __launch_bounds__(NWV * 64) void pw_gemm_dma_kernel(PwKArgs a) {
     }
 }
 
-template <typename T, int NI, int WN, bool GATE, int NS, int MI, int NWV = 4>
+template <typename T, int NI, int WN, bool GATE, int NS, int MI, int NWV = 4, int KG = 1>
 static int launch_pw_dma_mi(PwKArgs k, hipStream_t s) {
-    constexpr int WM = NWV / WN, NB = MI * WM + NI * WN;
+    constexpr int WM = NWV / KG / WN, NB = KG * (MI * WM + NI * WN);
     k.MT = cdiv(k.M, 16 * MI * WM);
     const int grid = cdiv(k.MT, 8) * 8 * k.NT;
     k.rowgate = GATE && (k.HW % 64 != 0);
@@ -426,10 +469,10 @@ static int launch_pw_dma_mi(PwKArgs k, hipStream_t s) {
     COSY_REQUIRE(lds <= 160 * 1024, "pw_gemm_dma: the gate rows of %d samples x K=%d do not fit the LDS (map of %d pixels too small)", k.nsamp, k.K, k.HW);
     // once per instantiation and process, race-free: function-local statics are initialised exactly once (C++11), also when two
     // nets launch from two threads at the same time (the header promises thread-safety across distinct nets / streams)
-    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)pw_gemm_dma_kernel<T, NI, WN, NS, GATE, MI, NWV>,
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)pw_gemm_dma_kernel<T, NI, WN, NS, GATE, MI, NWV, KG>,
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     COSY_CHECK_HIP(attr_rc);
-    hipLaunchKernelGGL((pw_gemm_dma_kernel<T, NI, WN, NS, GATE, MI, NWV>), dim3(grid), dim3(NWV * 64), lds, s, k);
+    hipLaunchKernelGGL((pw_gemm_dma_kernel<T, NI, WN, NS, GATE, MI, NWV, KG>), dim3(grid), dim3(NWV * 64), lds, s, k);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }
@@ -460,6 +503,16 @@ static int launch_pw_dma_cfg(const PwKArgs& k, int grid, hipStream_t s) {
 template <typename T, bool GATE>
 static int launch_pw_dma(const PwKArgs& k, PwCfg c, int grid, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {   // 8-wave tiles of the late layers: 2 waves per SIMD take turns on the matrix pipe
+        if (c.WV == 16) {        // in-workgroup split-K (KG = 2): the K >= 1024 project convs of the 8x8 maps
+            if constexpr (GATE) {
+                if (k.nkb_valid > 4 && k.HW % 64 == 0 && c.KG == 2 && c.WN == 4) {
+                    if (c.NI == 2) return launch_pw_dma_mi<T, 2, 4, GATE, 3, 4, 16, 2>(k, s);
+                    if (c.NI == 3) return launch_pw_dma_mi<T, 3, 4, GATE, 3, 4, 16, 2>(k, s);
+                }
+            }
+            set_error("pw_gemm_dma: 16-wave split-K tile NI=%d WN=%d KG=%d not built for this layer", c.NI, c.WN, c.KG);
+            return COSY_EINVAL;
+        }
         if (c.WV == 8) {
             const bool wave_gate = !GATE || (k.HW % 64 == 0);    // weight-side gate needs a wave's 64 rows inside one sample
             if (k.nkb_valid > 2 && wave_gate) {
@@ -515,7 +568,8 @@ void pw_kernel_name(const PwArgs& a, PwCfg c, int dtype, char* buf, size_t n) {
     static const int deep = tune_int("COSY_PW_NS", 3);
     static const int mi_env = tune_int("COSY_PW_MI", 4);
     const int mi = (mi_env == 2 && nkb > 2 && (!a.gate || a.HW % 64 == 0)) ? 2 : 4;
-    if (c.WV == 8) snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, 3, %s, 4, 8>", tname(dtype), c.NI, c.WN, a.gate ? "true" : "false");
+    if (c.WV == 16) snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, 3, %s, 4, 16, %d>", tname(dtype), c.NI, c.WN, a.gate ? "true" : "false", c.KG);
+    else if (c.WV == 8) snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, 3, %s, 4, 8>", tname(dtype), c.NI, c.WN, a.gate ? "true" : "false");
     else snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, %d, %s, %d>", tname(dtype), c.NI, c.WN,
                   nkb <= 2 ? 2 : (deep >= 4 && nkb >= 8 ? 4 : 3), a.gate ? "true" : "false", mi);
 }
