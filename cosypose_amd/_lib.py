@@ -64,6 +64,10 @@ _SIGNATURES = {
     'cosy_rows_scale': ([_P, _P, _P, _F, _I, _I, _I, _P, _P], _I),
     'cosy_rows_broadcast': ([_P, _F, _I, _I, _I, _P, _P], _I),
     'cosy_act_forward': ([_P, _L, _I, _P, _P], _I),
+    'cosy_se_train_forward': ([_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P], _I),
+    'cosy_se_train_backward': ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P], _I),
+    'cosy_fc_small_forward': ([_P, _P, _P, _I, _I, _I, _P, _P], _I),
+    'cosy_fc_small_backward': ([_P, _P, _P, _I, _I, _I, _P, _P, _P, _P], _I),
     'cosy_act_backward': ([_P, _P, _L, _I, _P, _P], _I),
     'cosy_stem_im2col': ([_P, _I, _I, _I, _P, _P], _I),
     'cosy_loss_refiner_disentangled_backward': ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P], _I),

@@ -590,6 +590,283 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     else { const float sg = sigmoidf_(v); dx[i] = dy[i] * (sg * (1.f - sg)); }
 }
 
+// ------------------------------------------------------------------------------------------
+// Squeeze-excite FCs and the pose head's Linear layer, forward and backward, as FUSED kernels (round 4).  These are products with
+// 64 rows (the batch): on rocBLAS + elementwise launches they were ~14 launches per MBConv block (addmm, swish, addmm, sigmoid;
+// sigmoid', column sums, three matmuls, swish', column sum, two matmuls) -- 1.3 ms of rocBLAS and ~1.5 ms of tiny launches per step.
+// Weight layouts are the module's own (se_reduce (Cse, C), se_expand (C, Cse), Linear (J, C)): the weights change every step, so
+// nothing is re-packed.  Every sum runs in a fixed order (deterministic).
+//   se_fc1 / se_fc2 (batched MFMA GEMMs):  h_pre = W1 pooled + b1;  g = sigmoid(W2 swish(h_pre) + b2)
+//   se_bwd_x (one workgroup per sample):  dg_pre = dg g (1 - g);  dh_pre = (W2^T dg_pre) swish'(h_pre);  dpooled = W1^T dh_pre
+//   se_bwd_w (one wave per 16 channels, MFMA over the batch): dW2 = dg_pre^T swish(h_pre), db2, dW1 = dh_pre^T pooled, db1
+// ------------------------------------------------------------------------------------------
+// y[j] = sum_c W[j][c] x[c] for j < J (W (J, C) row-major, C % 4 == 0, x in LDS): 8 lanes per output, float4 loads, shuffle combine;
+// calls f(j, y) on one lane per output.  All `nthreads` threads of the workgroup must call it.
+template <typename F>
+__device__ __forceinline__ void fc_rows_reduce(const float* __restrict__ W, const float* xs, int J, int C, int tid, int nthreads, F&& f) {
+    const int C4 = C >> 2, slots = nthreads >> 3, prt = tid & 7;
+    for (int j0 = 0; j0 < J; j0 += slots) {
+        const int j = j0 + (tid >> 3);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const f32x4* wr = (const f32x4*)(W + (size_t)min(j, J - 1) * C);
+        for (int c0 = prt; c0 < C4; c0 += 64) {           // 8 independent 16-byte loads in flight, then the FMAs
+            f32x4 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = wr[min(c0 + 8 * u, C4 - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + 8 * u < C4) acc += w[u] * ((const f32x4*)xs)[c0 + 8 * u];
+        }
+        float sv = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        sv += __shfl_xor(sv, 1, 64); sv += __shfl_xor(sv, 2, 64); sv += __shfl_xor(sv, 4, 64);
+        if (prt == 0 && j < J) f(j, sv);
+    }
+}
+// y[c] = sum_j W[j][c] x[j] (W (J, C) row-major, x in LDS): a thread owns 4 consecutive channels; calls f(c4, y4)
+template <typename F>
+__device__ __forceinline__ void fc_cols_apply(const float* __restrict__ W, const float* xs, int J, int C, int tid, int nthreads, F&& f) {
+    const int C4 = C >> 2;
+    for (int c = tid; c < C4; c += nthreads) {
+        const f32x4* wc = (const f32x4*)W + c;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        for (int j0 = 0; j0 < J; j0 += 8) {
+            f32x4 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = wc[(size_t)min(j0 + u, J - 1) * C4];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                if (j0 + u < J) s0 += w[u] * xs[j0 + u];
+                if (j0 + u + 1 < J) s1 += w[u + 1] * xs[j0 + u + 1];
+            }
+        }
+        f(c, s0 + s1);
+    }
+}
+// Forward as two small GEMMs over the BATCH on the fp32 matrix instruction (v_mfma_f32_16x16x4_f32: an exact fp32 FMA chain per output,
+// columns = samples are independent of each other): a 16-sample tile shares one read of the weights -- one workgroup per sample re-reads
+// both FC matrices (1.77 MB for block 25) per sample at the ~100 GB/s a single CU pulls: 40 us per block.
+//   fc1: grid (sample tiles, 16-row tiles of Cse); the WAVES waves split the C range, fixed-order LDS combine;  h_pre = W1 pooled + b1
+//   fc2: grid (sample tiles, groups of WAVES 16-channel tiles); k = Cse;  gate = sigmoid(W2 swish(h_pre) + b2)
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void se_train_fc1_kernel(const float* __restrict__ pooled, const float* __restrict__ W1, const float* __restrict__ b1,
+                                                                  int B, int C, int Cse, float* __restrict__ h_pre) {
+    __shared__ f32x4 comb[WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kq = lane >> 4;
+    const int b = min((int)blockIdx.x * 16 + i, B - 1), j0 = blockIdx.y * 16;
+    const float* prow = pooled + (size_t)b * C + kq * 4;
+    const float* wrow = W1 + (size_t)min(j0 + i, Cse - 1) * C + kq * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int nsteps = C >> 4, tail = C & 15;          // C % 4 == 0: a tail step has 1-3 valid k-quads
+    for (int st0 = wave; st0 < nsteps + (tail ? 1 : 0); st0 += 4 * WAVES) {
+        f32x4 a[4], w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int st = st0 + u * WAVES;
+            a[u] = f32x4{0.f, 0.f, 0.f, 0.f}; w[u] = a[u];
+            if (st < nsteps || (st == nsteps && kq * 4 < tail)) { w[u] = *(const f32x4*)(wrow + st * 16); a[u] = *(const f32x4*)(prow + st * 16); }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][e], a[u][e], acc, 0, 0, 0);
+    }
+    comb[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+        f32x4 sv = comb[0][lane];
+#pragma unroll
+        for (int q = 1; q < WAVES; ++q) sv += comb[q][lane];
+        if ((int)blockIdx.x * 16 + i < B) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = j0 + kq * 4 + e;
+                if (j < Cse) h_pre[(size_t)b * Cse + j] = sv[e] + b1[j];
+            }
+        }
+    }
+}
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void se_train_fc2_kernel(const float* __restrict__ h_pre, const float* __restrict__ W2, const float* __restrict__ b2,
+                                                                  int B, int C, int Cse, float* __restrict__ gate) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kq = lane >> 4;
+    const int ct = blockIdx.y * WAVES + wave;
+    if (ct * 16 >= C) return;
+    const int b = min((int)blockIdx.x * 16 + i, B - 1), c0 = ct * 16;
+    const float* hrow = h_pre + (size_t)b * Cse;
+    const float* wrow = W2 + (size_t)min(c0 + i, C - 1) * Cse;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j0 = 0; j0 < Cse; j0 += 32) {             // 8 k-steps of 4: 16 independent loads in flight
+        float hv[8], wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * 4 + kq;
+            const bool ok = j < Cse;
+            const float hp = ok ? hrow[j] : 0.f;
+            hv[u] = ok ? hp * sigmoidf_(hp) : 0.f;
+            wv[u] = ok ? wrow[j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u], hv[u], acc, 0, 0, 0);
+    }
+    if ((int)blockIdx.x * 16 + i < B && c0 + kq * 4 < C) {
+        const f32x4 bias = *(const f32x4*)(b2 + c0 + kq * 4);
+        f32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = sigmoidf_(acc[e] + bias[e]);
+        *(f32x4*)(gate + (size_t)b * C + c0 + kq * 4) = g;
+    }
+}
+__global__ __launch_bounds__(512) void se_train_bwd_x_kernel(const float* __restrict__ dg, const float* __restrict__ gate, const float* __restrict__ h_pre,
+                                                             const float* __restrict__ W1, const float* __restrict__ W2, int C, int Cse,
+                                                             float* __restrict__ dg_pre, float* __restrict__ dh_pre, float* __restrict__ dpooled) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* ds = sm;                    // C: dg_pre of this sample
+    float* dhs = sm + C;               // Cse (padded to 128): dh_pre
+    float* red = dhs + 128;            // 32 partial rows x 128
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < (C >> 2); c += 512) {
+        const f32x4 d = ((const f32x4*)(dg + (size_t)b * C))[c], g = ((const f32x4*)(gate + (size_t)b * C))[c];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = d[e] * (g[e] * (1.f - g[e]));
+        ((f32x4*)ds)[c] = o;
+        ((f32x4*)(dg_pre + (size_t)b * C))[c] = o;
+    }
+    __syncthreads();
+    // dh[j] = sum_c dg_pre[c] W2[c][j]: lanes along j (rows of W2 are contiguous), 32 (wave, quarter) groups split the channels
+    {
+        const int jl = tid & 15, grp = tid >> 4;          // 32 groups
+        float acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+        for (int c0 = grp; c0 < C; c0 += 4 * 32) {          // 4 rows of W2 per step: their loads are independent of each other
+            float w[4][8], d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + 32 * u;
+                d[u] = c < C ? ds[c] : 0.f;
+                const float* wr = W2 + (size_t)min(c, C - 1) * Cse;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) w[u][q] = 16 * q < Cse ? wr[min(jl + 16 * q, Cse - 1)] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] += d[u] * w[u][q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) red[grp * 128 + jl + 16 * q] = acc[q];
+    }
+    __syncthreads();
+    if (tid < Cse) {
+        float v = 0.f;
+        for (int r = 0; r < 32; ++r) v += red[r * 128 + tid];
+        v *= swish_grad(h_pre[(size_t)b * Cse + tid]);
+        dhs[tid] = v;
+        dh_pre[(size_t)b * Cse + tid] = v;
+    }
+    __syncthreads();
+    fc_cols_apply(W1, dhs, Cse, C, tid, 512, [&](int c4, f32x4 v) { ((f32x4*)(dpooled + (size_t)b * C))[c4] = v; });
+}
+// weight gradients on the fp32 matrix instruction, k = the batch: a wave owns 16 channels and walks the samples four at a time;
+//   dW2[c][j] = sum_b dg_pre[b][c] swish(h_pre[b][j])   (A = dg_pre^T, B = h),   db2[c] = sum_b dg_pre[b][c]   (B = ones)
+//   dW1[j][c] = sum_b dh_pre[b][j] pooled[b][c]          (A = dh_pre^T, B = pooled),   db1[j] (the wave that owns channels 0-15)
+// Each output is one fp32 FMA chain over the samples in order (deterministic).  Cse <= 128 = 8 column tiles of 16.
+__global__ __launch_bounds__(256) void se_train_bwd_w_kernel(const float* __restrict__ dg_pre, const float* __restrict__ dh_pre, const float* __restrict__ h_pre,
+                                                             const float* __restrict__ pooled, int B, int C, int Cse, float* __restrict__ dW2,
+                                                             float* __restrict__ db2, float* __restrict__ dW1, float* __restrict__ db1) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kq = lane >> 4;
+    const int c0 = (blockIdx.x * 4 + wave) * 16;
+    if (c0 >= C) return;
+    const int njt = (Cse + 15) >> 4;                   // <= 8
+    f32x4 a2[8], a1[8], sb2 = {0.f, 0.f, 0.f, 0.f}, sb1[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { a2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; a1[t] = a2[t]; sb1[t] = a2[t]; }
+    const int cc = min(c0 + i, C - 1);
+    const bool first = c0 == 0;
+    for (int bb = 0; bb < B; bb += 4) {
+        const int b = bb + kq;
+        const bool okb = b < B;
+        const float d = okb ? dg_pre[(size_t)b * C + cc] : 0.f, pv = okb ? pooled[(size_t)b * C + cc] : 0.f;
+        float hv[8], dv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int j = t * 16 + i;
+            const bool ok = okb && t < njt && j < Cse;
+            const float hp = ok ? h_pre[(size_t)b * Cse + j] : 0.f;
+            hv[t] = ok ? hp * sigmoidf_(hp) : 0.f;
+            dv[t] = ok ? dh_pre[(size_t)b * Cse + j] : 0.f;
+        }
+        sb2 = __builtin_amdgcn_mfma_f32_16x16x4f32(d, 1.f, sb2, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (t < njt) {                                 // wave-uniform
+                a2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(d, hv[t], a2[t], 0, 0, 0);          // rows = channels, columns = j
+                a1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[t], pv, a1[t], 0, 0, 0);         // rows = j, columns = channels
+                if (first) sb1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[t], 1.f, sb1[t], 0, 0, 0);
+            }
+    }
+    // accumulator element q of lane (i, kq) = output[row 4 kq + q][column i]
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        if (t < njt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = c0 + 4 * kq + q, j = t * 16 + i;                 // dW2 tile: row = channel, column = j
+                if (c < C && j < Cse) dW2[(size_t)c * Cse + j] = a2[t][q];
+                const int j1 = t * 16 + 4 * kq + q, c1 = c0 + i;               // dW1 tile: row = j, column = channel
+                if (j1 < Cse && c1 < C) dW1[(size_t)j1 * C + c1] = a1[t][q];
+                if (first && i == 0 && j1 < Cse) db1[j1] = sb1[t][q];
+            }
+        }
+    if (i == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (c0 + 4 * kq + q < C) db2[c0 + 4 * kq + q] = sb2[q];
+    }
+}
+// Linear layer with few outputs (the pose head: J = 9): y = x W^T + b;  dx = dy W;  dW = dy^T x, db = column sums of dy
+__global__ __launch_bounds__(256) void fc_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                                                           int C, int J, float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < (C >> 2); c += 256) ((f32x4*)sm)[c] = ((const f32x4*)(x + (size_t)b * C))[c];
+    __syncthreads();
+    fc_rows_reduce(W, sm, J, C, tid, 256, [&](int j, float v) { y[(size_t)b * J + j] = v + bias[j]; });
+}
+__global__ __launch_bounds__(256) void fc_small_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ W, int C, int J, float* __restrict__ dx) {
+    __shared__ float dys[128];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < J) dys[tid] = dy[(size_t)b * J + tid];
+    __syncthreads();
+    fc_cols_apply(W, dys, J, C, tid, 256, [&](int c4, f32x4 v) { ((f32x4*)(dx + (size_t)b * C))[c4] = v; });
+}
+__global__ __launch_bounds__(256) void fc_small_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x, int B, int C, int J,
+                                                             float* __restrict__ dW, float* __restrict__ db) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // dy: B x J
+    const int tid = threadIdx.x, c = blockIdx.x * 256 + tid;
+    for (int i = tid; i < B * J; i += 256) sm[i] = dy[i];
+    __syncthreads();
+    constexpr int NJ = 16;
+    float acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
+    if (c < C)
+        for (int r = 0; r < B; ++r) {
+            const float xv = x[(size_t)r * C + c];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) if (j < J) acc[j] += sm[r * J + j] * xv;
+        }
+    if (c < C) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) if (j < J) dW[(size_t)j * C + c] = acc[j];
+    }
+    if (blockIdx.x == 0 && tid < J) {
+        float sv = 0.f;
+        for (int r = 0; r < B; ++r) sv += sm[r * J + tid];
+        db[tid] = sv;
+    }
+}
+
 // stem: 3x3 stride-2 patches of the 8-channel NHWC input (6 used) as GEMM rows: cols[p][(ky*3+kx)*6 + c]
 __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ x8, int H, int W, int Ho, int Wo, int lo, long n,
                                                           int ld, float* __restrict__ cols) {
@@ -1064,6 +1341,49 @@ int cosy_act_backward(const float* x, const float* dy, long n, int kind, float* 
     COSY_REQUIRE(x && dy && dx && (kind == 0 || kind == 1), "act_backward: bad argument");
     if (n == 0) return COSY_OK;
     LAUNCH1D(act_bwd_kernel, n, (hipStream_t)stream, x, dy, n, kind, dx);
+    return COSY_OK;
+}
+int cosy_se_train_forward(const float* pooled, const float* w_reduce, const float* b_reduce, const float* w_expand, const float* b_expand, int B, int C,
+                          int Cse, float* h_pre, float* gate, cosy_stream_t stream) {
+    COSY_REQUIRE(pooled && w_reduce && b_reduce && w_expand && b_expand && h_pre && gate && B > 0 && C > 0 && C % 4 == 0 && Cse > 0 && Cse <= 128,
+                 "se_train_forward: bad argument (C=%d must be a multiple of 4, Cse=%d <= 128)", C, Cse);
+    constexpr int W1 = 8, W2 = 4;
+    hipLaunchKernelGGL(se_train_fc1_kernel<W1>, dim3(cdiv(B, 16), cdiv(Cse, 16)), dim3(W1 * 64), 0, (hipStream_t)stream, pooled, w_reduce, b_reduce, B, C, Cse, h_pre);
+    COSY_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(se_train_fc2_kernel<W2>, dim3(cdiv(B, 16), cdiv(cdiv(C, 16), W2)), dim3(W2 * 64), 0, (hipStream_t)stream, (const float*)h_pre, w_expand,
+                       b_expand, B, C, Cse, gate);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+int cosy_se_train_backward(const float* dgate, const float* gate, const float* h_pre, const float* pooled, const float* w_reduce, const float* w_expand,
+                           int B, int C, int Cse, float* dpooled, float* dw_reduce, float* db_reduce, float* dw_expand, float* db_expand, void* workspace,
+                           cosy_stream_t stream) {
+    COSY_REQUIRE(dgate && gate && h_pre && pooled && w_reduce && w_expand && dpooled && dw_reduce && db_reduce && dw_expand && db_expand && workspace &&
+                 B > 0 && C > 0 && C % 4 == 0 && Cse > 0 && Cse <= 128, "se_train_backward: bad argument (C=%d, Cse=%d)", C, Cse);
+    COSY_REQUIRE((size_t)B * (C + Cse) * sizeof(float) <= cosy_train_workspace_bytes(), "se_train_backward: batch %d too large for the workspace", B);
+    float* dg_pre = (float*)workspace;                 // (B, C)
+    float* dh_pre = dg_pre + (size_t)B * C;            // (B, Cse)
+    hipLaunchKernelGGL(se_train_bwd_x_kernel, dim3(B), dim3(512), (size_t)(C + 128 + 32 * 128) * sizeof(float), (hipStream_t)stream, dgate, gate, h_pre,
+                       w_reduce, w_expand, C, Cse, dg_pre, dh_pre, dpooled);
+    COSY_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(se_train_bwd_w_kernel, dim3(cdiv(cdiv(C, 16), 4)), dim3(256), 0, (hipStream_t)stream, (const float*)dg_pre, (const float*)dh_pre, h_pre,
+                       pooled, B, C, Cse, dw_expand, db_expand, dw_reduce, db_reduce);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+int cosy_fc_small_forward(const float* x, const float* w, const float* bias, int B, int C, int J, float* y, cosy_stream_t stream) {
+    COSY_REQUIRE(x && w && bias && y && B > 0 && C > 0 && C % 4 == 0 && J > 0 && J <= 16, "fc_small_forward: bad argument (C=%d, J=%d <= 16)", C, J);
+    hipLaunchKernelGGL(fc_small_fwd_kernel, dim3(B), dim3(256), (size_t)C * sizeof(float), (hipStream_t)stream, x, w, bias, C, J, y);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+int cosy_fc_small_backward(const float* dy, const float* x, const float* w, int B, int C, int J, float* dx, float* dw, float* db, cosy_stream_t stream) {
+    COSY_REQUIRE(dy && x && w && dx && dw && db && B > 0 && B * J <= 12288 && C > 0 && C % 4 == 0 && J > 0 && J <= 16,
+                 "fc_small_backward: bad argument (B=%d, C=%d, J=%d)", B, C, J);
+    hipLaunchKernelGGL(fc_small_bwd_x_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dy, w, C, J, dx);
+    COSY_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(fc_small_bwd_w_kernel, dim3(cdiv(C, 256)), dim3(256), (size_t)B * J * sizeof(float), (hipStream_t)stream, dy, x, B, C, J, dw, db);
+    COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }
 int cosy_stem_im2col_ld(const float* x_nhwc8, int B, int H, int W, int ld, float* cols, cosy_stream_t stream) {

@@ -58,8 +58,8 @@ def bn_apply(x, mean, rstd, gamma, beta, M, C, act, rowscale=None, HW=1, res=Non
     return out
 
 
-def bn_backward(dout, x, mean, rstd, gamma, beta, M, C, act, rowscale=None, HW=1):
-    dgamma = torch.empty(C, device=x.device); dbeta = torch.empty(C, device=x.device)
+def bn_backward(dout, x, mean, rstd, gamma, beta, M, C, act, rowscale=None, HW=1, out=None):
+    dgamma, dbeta = out if out is not None else (torch.empty(C, device=x.device), torch.empty(C, device=x.device))
     dx = torch.empty_like(x); sums = torch.empty(2 * C, device=x.device)
     check(lib().cosy_bn_train_backward(ptr(dout), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), M, C, act, ptr(rowscale), HW,
                                        ptr(dgamma), ptr(dbeta), 0, ptr(dx), ptr(sums), ptr(_workspace(x.device)), stream()))
@@ -124,11 +124,56 @@ def act_backward(x, dy, kind):
 SWISH, SIGMOID = 0, 1
 
 
-def wgrad(dY, X):
-    """dW (N,K) = dY^T X for dY (M,N), X (M,K): the streaming fp32 MFMA kernel (cosy_wgrad), every shape."""
+def se_forward(pooled, w_reduce, b_reduce, w_expand, b_expand):
+    """squeeze-excite FCs of one block, ONE launch: pooled (B,C) -> (h_pre (B,Cse), gate (B,C)); weights in the module's own layout
+    (_se_reduce.weight (Cse,C,1,1), _se_expand.weight (C,Cse,1,1)).  efficientnet.py:85-88."""
+    B, C = pooled.shape
+    cse = b_reduce.numel()
+    h_pre = torch.empty(B, cse, device=pooled.device); gate = torch.empty(B, C, device=pooled.device)
+    check(lib().cosy_se_train_forward(ptr(pooled), ptr(w_reduce), ptr(b_reduce), ptr(w_expand), ptr(b_expand), B, C, cse, ptr(h_pre), ptr(gate), stream()))
+    return h_pre, gate
+
+
+def se_backward(dgate, gate, h_pre, pooled, w_reduce, w_expand, out=None):
+    """gradients of se_forward from dgate (B,C), two launches: -> dpooled (B,C), dw_reduce (Cse,C), db_reduce (Cse), dw_expand (C,Cse),
+    db_expand (C); `out` = the four parameter-gradient tensors to write into (contiguous), else fresh ones."""
+    B, C = pooled.shape
+    cse = h_pre.shape[1]
+    dev = pooled.device
+    dpooled = torch.empty(B, C, device=dev)
+    dw1, db1, dw2, db2 = out if out is not None else (torch.empty(cse, C, device=dev), torch.empty(cse, device=dev),
+                                                       torch.empty(C, cse, device=dev), torch.empty(C, device=dev))
+    check(lib().cosy_se_train_backward(ptr(dgate), ptr(gate), ptr(h_pre), ptr(pooled), ptr(w_reduce), ptr(w_expand), B, C, cse, ptr(dpooled),
+                                       ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(_workspace(dev)), stream()))
+    return dpooled, dw1, db1, dw2, db2
+
+
+def fc_small_forward(x, w, bias):
+    """x (B,C) @ w (J,C)^T + bias for J <= 16 (the pose head), one launch"""
+    B, C = x.shape
+    y = torch.empty(B, w.shape[0], device=x.device)
+    check(lib().cosy_fc_small_forward(ptr(x), ptr(w), ptr(bias), B, C, w.shape[0], ptr(y), stream()))
+    return y
+
+
+def fc_small_backward(dy, x, w, out=None):
+    """-> dx (B,C), dw (J,C), db (J)"""
+    B, C = x.shape
+    J = w.shape[0]
+    dx = torch.empty(B, C, device=x.device)
+    dw, db = out if out is not None else (torch.empty(J, C, device=x.device), torch.empty(J, device=x.device))
+    check(lib().cosy_fc_small_backward(ptr(dy), ptr(x), ptr(w), B, C, J, ptr(dx), ptr(dw), ptr(db), stream()))
+    return dx, dw, db
+
+
+def wgrad(dY, X, out=None):
+    """dW (N,K) = dY^T X for dY (M,N), X (M,K): the streaming fp32 MFMA kernel (cosy_wgrad), every shape.  `out`: a contiguous
+    destination of N*K floats (e.g. a parameter's slice of a flat gradient buffer)."""
     M, N = dY.shape
     K = X.shape[1]
-    out = torch.empty(N, K, device=dY.device)
+    if out is None:
+        out = torch.empty(N, K, device=dY.device)
+    assert out.numel() == N * K and out.is_contiguous()
     check(lib().cosy_wgrad(ptr(dY), ptr(X), M, N, K, ptr(out), ptr(_workspace(dY.device)), stream()))
     return out
 
@@ -179,8 +224,12 @@ def make_drop_connect_scales(B, device, rate=DROP_CONNECT_RATE, generator=None):
 class _Net:
     """Forward (saving what the backward needs) and backward of backbone + pooling + pose_fc."""
 
-    def __init__(self, P, buffers):
+    def __init__(self, P, buffers, stage=None):
         self.P, self.buf = P, buffers
+        self.stage = stage       # name -> destination view of the parameter's gradient (FlatAdam's staging buffer), or None
+
+    def _dst(self, name):
+        return self.stage[name] if self.stage is not None else None
 
     # ---- helpers
     def _bn_f(self, tape, name, raw, M, C, act, rowscale=None, HW=1, res=None):
@@ -191,7 +240,8 @@ class _Net:
 
     def _bn_b(self, tape, grads, name, dout):
         raw, mean, rstd, M, C, act, rowscale, HW = tape[name]
-        dx, dg, db = bn_backward(dout, raw, mean, rstd, self.P[name + '.weight'], self.P[name + '.bias'], M, C, act, rowscale, HW)
+        out = (self._dst(name + '.weight'), self._dst(name + '.bias')) if self.stage is not None else None
+        dx, dg, db = bn_backward(dout, raw, mean, rstd, self.P[name + '.weight'], self.P[name + '.bias'], M, C, act, rowscale, HW, out=out)
         grads[name + '.weight'], grads[name + '.bias'] = dg, db
         return dx
 
@@ -225,23 +275,19 @@ class _Net:
             a1 = self._bn_f(tape, p + '_bn1', raw, Mo, cmid, 1)
             # squeeze-excite
             pooled = rows_mean(a1, B, HWo, cmid)
-            cse = P[p + '_se_reduce.bias'].numel()
-            h_pre = torch.addmm(P[p + '_se_reduce.bias'], pooled, P[p + '_se_reduce.weight'].view(cse, cmid).t())
-            h = act_forward(h_pre, SWISH)
-            g_pre = torch.addmm(P[p + '_se_expand.bias'], h, P[p + '_se_expand.weight'].view(cmid, cse).t())
-            g = act_forward(g_pre, SIGMOID)
+            h_pre, g = se_forward(pooled, P[p + '_se_reduce.weight'], P[p + '_se_reduce.bias'], P[p + '_se_expand.weight'], P[p + '_se_expand.bias'])
             a2 = rows_scale(a1, g, B, HWo, cmid)
             raw = gemm(a2, P[p + '_project_conv.weight'].view(cout, cmid))
             skip = s == 1 and cin == cout
             rowscale = drop.get(i) if (skip and drop) else None
             x = self._bn_f(tape, p + '_bn2', raw, Mo, cout, 0, rowscale, HWo, inp if skip else None)
-            tape[p] = (inp, a0, wt, a1, pooled, h_pre, h, g_pre, g, a2, H, W, Ho, Wo)
+            tape[p] = (inp, a0, wt, a1, pooled, h_pre, g, a2, H, W, Ho, Wo)
             H, W = Ho, Wo
         M = B * H * W
         raw = gemm(x, P['backbone._conv_head.weight'].view(arch.HEAD_C, -1))
         a = self._bn_f(tape, 'backbone._bn1', raw, M, arch.HEAD_C, 1)
         feat = rows_mean(a, B, H * W, arch.HEAD_C)
-        pose = torch.addmm(P['pose_fc.bias'], feat, P['pose_fc.weight'].t())
+        pose = fc_small_forward(feat, P['pose_fc.weight'], P['pose_fc.bias'])
         tape['head'] = (x, feat, B, H, W)
         nbt = [v for k, v in self.buf.items() if k.endswith('num_batches_tracked')]
         if nbt:
@@ -252,68 +298,76 @@ class _Net:
         P = self.P
         grads = {}
         x_head, feat, B, H, W = tape['head']
-        grads['pose_fc.weight'] = dpose.t() @ feat
-        grads['pose_fc.bias'] = dpose.sum(0)
-        dfeat = dpose @ P['pose_fc.weight']
+        D = self._dst
+        staged = self.stage is not None
+        dfeat, grads['pose_fc.weight'], grads['pose_fc.bias'] = fc_small_backward(
+            dpose, feat, P['pose_fc.weight'], out=(D('pose_fc.weight'), D('pose_fc.bias')) if staged else None)
         da = rows_broadcast(dfeat, 1.0 / (H * W), B, H * W, arch.HEAD_C)
         draw = self._bn_b(tape, grads, 'backbone._bn1', da)
         wh = P['backbone._conv_head.weight']
-        grads['backbone._conv_head.weight'] = wgrad(draw, x_head).view_as(wh)
+        grads['backbone._conv_head.weight'] = wgrad(draw, x_head, out=D('backbone._conv_head.weight')).view_as(wh)
         dx = gemm(draw, wh.view(arch.HEAD_C, -1), w_is_kn=True)
         for i in reversed(range(len(arch.B3_BLOCKS))):
             k, s, e, cin, cout = arch.B3_BLOCKS[i]
             p = f'backbone._blocks.{i}.'
-            inp, a0, wt, a1, pooled, h_pre, h, g_pre, g, a2, H, W, Ho, Wo = tape[p]
+            inp, a0, wt, a1, pooled, h_pre, g, a2, H, W, Ho, Wo = tape[p]
             cmid, HWo = cin * e, Ho * Wo
             skip = s == 1 and cin == cout
             dout = dx
             draw = self._bn_b(tape, grads, p + '_bn2', dout)
             wp = P[p + '_project_conv.weight']
-            grads[p + '_project_conv.weight'] = wgrad(draw, a2).view_as(wp)
+            grads[p + '_project_conv.weight'] = wgrad(draw, a2, out=D(p + '_project_conv.weight')).view_as(wp)
             da2 = gemm(draw, wp.view(cout, cmid), w_is_kn=True)
             # squeeze-excite backward
             dg = rows_dot(da2, a1, B, HWo, cmid)
-            dg_pre = act_backward(g_pre, dg, SIGMOID)
             w2, w1 = P[p + '_se_expand.weight'], P[p + '_se_reduce.weight']
-            cse = w1.shape[0]
-            grads[p + '_se_expand.bias'] = dg_pre.sum(0)
-            grads[p + '_se_expand.weight'] = (dg_pre.t() @ h).view_as(w2)
-            dh = dg_pre @ w2.view(cmid, cse)
-            dh_pre = act_backward(h_pre, dh, SWISH)
-            grads[p + '_se_reduce.bias'] = dh_pre.sum(0)
-            grads[p + '_se_reduce.weight'] = (dh_pre.t() @ pooled).view_as(w1)
-            dpooled = dh_pre @ w1.view(cse, cmid)
+            dpooled, dw1, db1, dw2, db2 = se_backward(dg, g, h_pre, pooled, w1, w2, out=(D(p + '_se_reduce.weight'), D(p + '_se_reduce.bias'),
+                                                      D(p + '_se_expand.weight'), D(p + '_se_expand.bias')) if staged else None)
+            grads[p + '_se_reduce.weight'], grads[p + '_se_reduce.bias'] = dw1.view_as(w1), db1
+            grads[p + '_se_expand.weight'], grads[p + '_se_expand.bias'] = dw2.view_as(w2), db2
             da1 = rows_scale(da2, g, B, HWo, cmid, add=dpooled, add_scale=1.0 / HWo)
             draw = self._bn_b(tape, grads, p + '_bn1', da1)
             da0, dwt = dw_backward(a0, draw, wt, B, H, W, cmid, k, s)
-            grads[p + '_depthwise_conv.weight'] = dwt.t().reshape(cmid, 1, k, k)
+            if staged:
+                D(p + '_depthwise_conv.weight').view(cmid, k * k).copy_(dwt.t())
+            else:
+                grads[p + '_depthwise_conv.weight'] = dwt.t().reshape(cmid, 1, k, k)
             if e != 1:
                 draw = self._bn_b(tape, grads, p + '_bn0', da0)
                 we = P[p + '_expand_conv.weight']
-                grads[p + '_expand_conv.weight'] = wgrad(draw, inp).view_as(we)
+                grads[p + '_expand_conv.weight'] = wgrad(draw, inp, out=D(p + '_expand_conv.weight')).view_as(we)
                 # the skip connection's gradient rides on the GEMM (C = dout + draw W) instead of a separate add
                 dx = gemm(draw, we.view(cmid, cin), w_is_kn=True, add=dout if skip else None)
             else:
                 dx = da0 + dout if skip else da0
         draw = self._bn_b(tape, grads, 'backbone._bn0', dx)
         cols = tape['stem']
-        grads['backbone._conv_stem.weight'] = wgrad(draw, cols)[:, :54].reshape(arch.STEM_C, 3, 3, 6).permute(0, 3, 1, 2).contiguous()
+        gstem = wgrad(draw, cols)[:, :54].reshape(arch.STEM_C, 3, 3, 6).permute(0, 3, 1, 2)
+        if staged:
+            D('backbone._conv_stem.weight').copy_(gstem)
+        else:
+            grads['backbone._conv_stem.weight'] = gstem.contiguous()
         return grads
 
 
 class _BackboneTrainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x8, drop, buffers, names, *params):
-        net = _Net({n: p.detach() for n, p in zip(names, params)}, buffers)
+    def forward(ctx, x8, drop, buffers, names, direct, *params):
+        net = _Net({n: p.detach() for n, p in zip(names, params)}, buffers, stage=direct.stage if direct is not None else None)
         pose, tape = net.forward(x8.detach(), drop)
-        ctx.net, ctx.tape, ctx.names = net, tape, names
+        ctx.net, ctx.tape, ctx.names, ctx.direct = net, tape, names, direct
         return pose
 
     @staticmethod
     def backward(ctx, dpose):
         grads = ctx.net.backward(ctx.tape, dpose.contiguous().float())
         ctx.tape = None
-        return (None, None, None, None) + tuple(grads[n] for n in ctx.names)
+        if ctx.direct is not None:
+            # every kernel wrote its parameter gradient straight into FlatAdam's staging buffer: ONE add accumulates all 340 of them
+            # into the flat gradient (instead of 340 AccumulateGrad launches), and autograd gets nothing to accumulate
+            ctx.direct.accumulate_staged()
+            return (None,) * (5 + len(ctx.names))
+        return (None, None, None, None, None) + tuple(grads[n] for n in ctx.names)
 
 
 def backbone_train(model, x8, drop=None):
@@ -330,7 +384,10 @@ def backbone_train(model, x8, drop=None):
         if p_.dtype != torch.float32 or not p_.is_contiguous():
             raise ValueError('training runs on contiguous fp32 parameters')
     buffers = dict(model.named_buffers())
-    return _BackboneTrainFn.apply(x8, drop or {}, buffers, names, *params)
+    direct = getattr(model, '_cosy_flat_adam', None)
+    if direct is not None and not (direct.direct_grads and direct.owns(params)):
+        direct = None
+    return _BackboneTrainFn.apply(x8, drop or {}, buffers, names, direct, *params)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -385,7 +442,7 @@ class FlatAdam:
     ONE flat fp32 buffer.  Construction re-homes the parameters (and their .grad) as views of flat buffers, in
     named_parameters() order; the module keeps working as before."""
 
-    def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_grad_norm=0.5):
+    def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_grad_norm=0.5, direct_grads=True):
         params = [p for p in model.parameters()]
         dev = params[0].device
         require_device(params[0])
@@ -400,10 +457,39 @@ class FlatAdam:
             p.grad = self.grad[off:off + k].view_as(p.data)
             off += k
         self.params = params
+        # direct_grads: the backward of backbone_train writes every parameter gradient into `gstage` (same layout as `grad`) and adds the
+        # whole buffer to `grad` with one launch; autograd's 340 per-parameter AccumulateGrad launches (~1.5 ms per step) disappear.
+        # Semantics are those of .grad accumulation (several backwards before a step add up).  NOT with a DistributedDataParallel
+        # wrapper -- its reducer hangs on the per-parameter hooks that never fire then; average with allreduce_gradients(opt) instead
+        # (or pass direct_grads=False).
+        self.direct_grads = bool(direct_grads)
+        self.gstage = torch.zeros(n, device=dev)
+        self.stage, off = {}, 0
+        for name, p in model.named_parameters():
+            self.stage[name] = self.gstage[off:off + p.numel()].view_as(p.data)
+            off += p.numel()
+        model.__dict__['_cosy_flat_adam'] = self          # found by backbone_train (not a submodule / parameter: invisible to state_dict)
         self.m = torch.zeros(n, device=dev); self.v = torch.zeros(n, device=dev)
         self.norm_coef = torch.ones(2, device=dev)
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, clip_grad_norm
         self.step_count = 0
+
+    def owns(self, params):
+        """the given parameters are exactly this optimizer's, still living in its flat buffer"""
+        if len(params) != len(self.params):
+            return False
+        base, off = self.flat.data_ptr(), 0
+        for p, q in zip(params, self.params):
+            if p is not q or p.data_ptr() != base + 4 * off:
+                return False
+            off += p.numel()
+        return True
+
+    def accumulate_staged(self):
+        """grad += gstage (one launch).  Parameters whose .grad was dropped (zero_grad(set_to_none=True)) restart from zero and ones
+        that were given a foreign .grad tensor are copied in first, exactly as step() treats them."""
+        self._collect_stray_gradients()
+        self.grad.add_(self.gstage)
 
     def zero_grad(self):
         self.grad.zero_()

@@ -234,6 +234,19 @@ int cosy_rows_scale(const float* a, const float* g, const float* add, float add_
                     cosy_stream_t stream);
 int cosy_rows_broadcast(const float* v, float scale, int B, int HW, int C, float* out, cosy_stream_t stream);
 /* elementwise Swish (kind 0) / sigmoid (kind 1) and their gradients */
+/* Squeeze-excite of an MBConv block in the training step (efficientnet.py:85-88 and its autograd), one launch forward, two backward:
+ *   forward : h_pre (B,Cse) = pooled (B,C) w_reduce^T + b_reduce;  gate (B,C) = sigmoid(swish(h_pre) w_expand^T + b_expand)
+ *   backward: from dgate (B,C): dpooled (B,C), dw_reduce (Cse,C), db_reduce (Cse), dw_expand (C,Cse), db_expand (C); sums over the batch in
+ *             sample order (deterministic).  Weight layouts are the module's own (_se_reduce.weight (Cse,C,1,1), _se_expand.weight (C,Cse,1,1)).
+ * cosy_fc_small_*: a Linear layer with J <= 16 outputs (models/pose.py:84: pose_fc, J = 9): y = x w^T + bias and its three gradients.
+ * They replace torch.addmm / matmul + elementwise launches (rocBLAS at 64 rows). */
+int cosy_se_train_forward(const float* pooled, const float* w_reduce, const float* b_reduce, const float* w_expand, const float* b_expand, int B, int C,
+                          int Cse, float* h_pre, float* gate, cosy_stream_t stream);
+int cosy_se_train_backward(const float* dgate, const float* gate, const float* h_pre, const float* pooled, const float* w_reduce, const float* w_expand,
+                           int B, int C, int Cse, float* dpooled, float* dw_reduce, float* db_reduce, float* dw_expand, float* db_expand, void* workspace,
+                           cosy_stream_t stream);
+int cosy_fc_small_forward(const float* x, const float* w, const float* bias, int B, int C, int J, float* y, cosy_stream_t stream);
+int cosy_fc_small_backward(const float* dy, const float* x, const float* w, int B, int C, int J, float* dx, float* dw, float* db, cosy_stream_t stream);
 int cosy_act_forward(const float* x, long n, int kind, float* out, cosy_stream_t stream);
 int cosy_act_backward(const float* x, const float* dy, long n, int kind, float* dx, cosy_stream_t stream);
 /* stem 3x3 stride-2 patches of the NHWC8 input as GEMM rows: cols (B*Ho*Wo, 54), column = (ky*3+kx)*6 + c */

@@ -755,8 +755,11 @@ def test_training_step_vs_reference(oracle, golden_train, golden_sd):
         if k.startswith('tr_after_adam/'):
             n = k[len('tr_after_adam/'):]
             ref = g[k]; got = named[n].detach().cpu().numpy()
-            # Adam's first step moves every weight by ~lr*sign(g): compare the applied update
-            assert np.abs(got - ref).max() < 3e-5, (n, np.abs(got - ref).max())
+            # Adam's first step moves every weight by lr * g / (|g| + 1e-8) ~ lr * sign(g) = 3e-4: compare the applied update.  An element
+            # whose gradient is within a few 1e-8 of zero turns fp32 summation-order noise into a visible fraction of that step (a sign
+            # flip would be 6e-4), so: no element further than a third of a step, and the tensor as a whole two orders below it
+            d = np.abs(got - ref)
+            assert d.max() < 1e-4 and d.mean() < 3e-6, (n, d.max(), d.mean())
     # after the update the model still serves inference (the engine notices the new weights)
     model.eval()
     with torch.no_grad():
