@@ -10,6 +10,10 @@ A "step" = one pass of the hot path over one batch of synthetic input.  --config
      scaling with --split skewed (per-rank shares ~ [512,384,320,256,224,160,128,64]/2048) or balanced (equal counts).
 Everything (frames, intrinsics, detections, mesh table, weights, the synthetic renderer's images) is resident in HBM
 before the timed region.  The refined poses of all ranks are exchanged by ONE RCCL all-gather per step.
+Schedule inside a rank: the candidates are cut into --streams (default 2) equal chunks that each run coarse -> refiner on their own
+HIP stream (CoarseRefinePosePredictor n_streams; results bit-identical to one stream, tests/test_gpu_parity.py): another chunk's
+kernels fill the ramp-up / drain of each of the ~90 dependent launches of a forward.  `config.single_stream` is the same workload as
+ONE stream of full-size launches (the schedule of the earlier rounds' lines), timed in the same process.
 
 Storage type.  BASELINE configs[1] names bf16 AND north_star demands <= 1e-4 relative pose deviation; measured, bf16 storage
 (8 significant bits on every stored activation and weight) cannot meet that bound (3-6e-4 per parameter group) while fp16
@@ -45,7 +49,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s 
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0, 'fp32': 157.3}
 ALGO_MB_PER_POSE_ITER = {('bf16', 256): 10.7, ('fp16', 256): 10.7, ('fp32', 256): 21.3, ('bf16', 240): 12.4, ('fp16', 240): 12.4, ('fp32', 240): 24.9}
 SKEW = [512, 384, 320, 256, 224, 160, 128, 64]
-DEFAULT_STREAMS = 1
+DEFAULT_STREAMS = 2     # chunks of a rank on two HIP streams (CoarseRefinePosePredictor n_streams): +3.5 % at the headline workload, bit-identical results
 NAMED_DTYPE = {1: 'bf16', 2: 'fp16', 3: 'bf16'}     # the storage type BASELINE.json's configs[i] names (3: the docstring's choice)
 
 
@@ -201,7 +205,7 @@ def main():
                     help='crops per forward: default 256 for config 1 (BASELINE configs[1] names batch=256), 512 for configs 2 and 3 '
                          '(their batches are 1024 / 2048 candidates; 512 per forward measured +9 %% over 256, profiles/r02_batch_sweep.txt)')
     ap.add_argument('--streams', type=int, default=None,
-                    help='HIP streams the chunks of a stage run on concurrently (CoarseRefinePosePredictor n_streams); with N > 1 and no '
+                    help='HIP streams the chunks of a stage run on concurrently (CoarseRefinePosePredictor n_streams; default 2); with N > 1 and no '
                          '--bsz-objects the candidates of a rank are cut into N equal chunks')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-dtypes', action='store_true', help='skip the bf16 / fp32 repeats of the timed loop and the deviation pass')
@@ -337,6 +341,20 @@ def main():
         t = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # the same K steps as ONE stream of full-size launches (the schedule of rounds 1-3's lines), reported beside the headline
+    single = None
+    if args.streams > 1 and not args.no_other_dtypes:
+        predictor.n_streams, predictor.bsz_objects = 1, min(max(per_rank), full_bsz)
+        step()
+        k1 = max(2, min(args.steps, 8))
+        sync(); t1 = time.perf_counter()
+        for _ in range(k1):
+            step()
+        sync(); d1 = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([d1], device='cuda', dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); d1 = float(tt.item())
+        single = dict(value=round(iters_total * k1 / d1, 1), ms_per_step=round(1e3 * d1 / k1, 3), steps=k1, bsz_objects=predictor.bsz_objects, streams=1)
+        predictor.n_streams, predictor.bsz_objects = args.streams, args.bsz_objects
     # the collective alone, timed in its own pass (device events around the call; nothing is drained inside the timed region)
     if use_dist and cfg_i == 1:
         local = step(local_only=True)
@@ -506,6 +524,7 @@ def main():
                                     'renders by the on-device HIP rasteriser (6k-triangle meshes) inside the loop'),
                        'pose_iterations_per_step': iters_total, 'candidates_per_rank': per_rank, 'bsz_objects': args.bsz_objects, 'streams': args.streams,
                        'parallelism': f'candidate-sharded x{world}, 1 all-gather of refined poses per step' + (' (RCCL, forced 1-rank group)' if use_dist and world == 1 else ''),
+                       'single_stream': single,
                        'all_gather_us': round(float(np.median(gather_us)), 1) if gather_us else None,
                        'process_group': process_group_info()},
             'roofline': roofline,

@@ -257,7 +257,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
             p += b.cmid;
             b.se_wr = up_f32(wr); b.se_br = up_f32(br); b.se_we = up_f32(we); b.se_be = up_f32(be);
             b.se_batched = i >= n->se_batch_from && se_batched_supported(b.cmid, b.cse);
-            b.se_fused = ((n->se_fuse_mask >> i) & 1) && (size_t)b.cse * b.cmid * 8 <= ((size_t)256 << 10) && b.cse <= 128;
+            b.se_fused = false;      // decided below, once the project GEMM's tile is known
             b.se_wr_p = b.se_br_p = b.se_we_p = nullptr;
             if (b.se_batched) {
                 const int csep = (b.cse + 15) & ~15;
@@ -272,6 +272,11 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
             }
         }
         mk_pw(b.proj, p, b.cmid, b.d.cout, p + (size_t)b.d.cout * b.cmid, b.Ho * b.Wo, true);
+        // squeeze-excite inside the project GEMM's prologue: small FC matrices, and m-tiles that never straddle two samples (a straddling
+        // tile computes two gates: at 240x320 crops -- maps of 1200 / 300 pixels under 128-row tiles -- the project GEMMs of blocks 13-17
+        // went 64 -> 148 us for 13 us of squeeze-excite kernels saved; those sizes keep the kernels)
+        b.se_fused = ((n->se_fuse_mask >> i) & 1) && (size_t)b.cse * b.cmid * 8 <= ((size_t)256 << 10) && b.cse <= 128 &&
+                     (b.Ho * b.Wo) % pw_bm(b.proj.cfg) == 0;
         p += (size_t)b.d.cout * b.cmid + 4 * b.d.cout;
         h = b.Ho; w_ = b.Wo;
     }

@@ -784,27 +784,36 @@ __global__ __launch_bounds__(256) void se_train_bwd_w_kernel(const float* __rest
     for (int t = 0; t < 8; ++t) { a2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; a1[t] = a2[t]; sb1[t] = a2[t]; }
     const int cc = min(c0 + i, C - 1);
     const bool first = c0 == 0;
-    for (int bb = 0; bb < B; bb += 4) {
-        const int b = bb + kq;
-        const bool okb = b < B;
-        const float d = okb ? dg_pre[(size_t)b * C + cc] : 0.f, pv = okb ? pooled[(size_t)b * C + cc] : 0.f;
-        float hv[8], dv[8];
+    // UB = 2 MFMA k-steps (8 samples) per iteration with all their loads in flight first: the loop is a chain of dependent memory latencies
+    constexpr int UB = 2;
+    for (int bb = 0; bb < B; bb += 4 * UB) {
+        float d[UB], pv[UB], hv[UB][8], dv[UB][8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int j = t * 16 + i;
-            const bool ok = okb && t < njt && j < Cse;
-            const float hp = ok ? h_pre[(size_t)b * Cse + j] : 0.f;
-            hv[t] = ok ? hp * sigmoidf_(hp) : 0.f;
-            dv[t] = ok ? dh_pre[(size_t)b * Cse + j] : 0.f;
-        }
-        sb2 = __builtin_amdgcn_mfma_f32_16x16x4f32(d, 1.f, sb2, 0, 0, 0);
+        for (int u = 0; u < UB; ++u) {
+            const int b = bb + 4 * u + kq;
+            const bool okb = b < B;
+            d[u] = okb ? dg_pre[(size_t)b * C + cc] : 0.f;
+            pv[u] = okb ? pooled[(size_t)b * C + cc] : 0.f;
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
-            if (t < njt) {                                 // wave-uniform
-                a2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(d, hv[t], a2[t], 0, 0, 0);          // rows = channels, columns = j
-                a1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[t], pv, a1[t], 0, 0, 0);         // rows = j, columns = channels
-                if (first) sb1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[t], 1.f, sb1[t], 0, 0, 0);
+            for (int t = 0; t < 8; ++t) {
+                const int j = t * 16 + i;
+                const bool ok = okb && t < njt && j < Cse;
+                hv[u][t] = ok ? h_pre[(size_t)b * Cse + j] : 0.f;
+                dv[u][t] = ok ? dh_pre[(size_t)b * Cse + j] : 0.f;
             }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            sb2 = __builtin_amdgcn_mfma_f32_16x16x4f32(d[u], 1.f, sb2, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (t < njt) {                                 // wave-uniform
+                    const float hp = hv[u][t], h = hp * sigmoidf_(hp);       // swish(0) = 0: masked elements stay 0
+                    a2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[u], h, a2[t], 0, 0, 0);              // rows = channels, columns = j
+                    a1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[u][t], pv[u], a1[t], 0, 0, 0);      // rows = j, columns = channels
+                    if (first) sb1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[u][t], 1.f, sb1[t], 0, 0, 0);
+                }
+        }
     }
     // accumulator element q of lane (i, kq) = output[row 4 kq + q][column i]
 #pragma unroll
