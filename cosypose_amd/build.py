@@ -38,7 +38,7 @@ def _stale_sources(force, tune=False):
     out = []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), _obj(s, tune)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+        if force or not os.path.exists(obj) or not os.path.exists(_res_file(s, tune)) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
             out.append(s)
     return out
 
@@ -76,6 +76,14 @@ def build(force=False, verbose=False, tune=False):
             check_wave_isa(verbose=verbose)
         return LIB
 
+    def run(cmd, s):
+        # -Rpass-analysis=kernel-resource-usage makes the compile that produces the object also report every kernel's registers, scratch and
+        # occupancy (remarks on stderr): parsed into lib/<source>.res.json -> kernel_resources() / tests/test_build_isa.py
+        r = subprocess.run(cmd + ['-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed on {s}:\n' + '\n'.join(l for l in r.stderr.split('\n') if 'remark:' not in l)[-6000:])
+        _write_resources(s, r.stderr, tune)
+
     def compile_one(s):
         cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(s, []) + (['-DCOSY_TUNE'] if tune else []) + ['-c', os.path.join(CSRC, s), '-o', _obj(s, tune)]
         if s == 'kernels_wave.hip' and not tune:
@@ -85,7 +93,7 @@ def build(force=False, verbose=False, tune=False):
                 cmd = cmd[:-1] + [os.path.join(tmp, 'kernels_wave.o'), '-save-temps=obj']
                 if verbose:
                     print(' '.join(cmd), flush=True)
-                subprocess.check_call(cmd)
+                run(cmd, s)
                 shutil.move(os.path.join(tmp, 'kernels_wave-hip-amdgcn-amd-amdhsa-gfx950.s'), WAVE_ISA)
                 shutil.move(os.path.join(tmp, 'kernels_wave.o'), _obj(s, tune))
             finally:
@@ -93,7 +101,7 @@ def build(force=False, verbose=False, tune=False):
             return
         if verbose:
             print(' '.join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        run(cmd, s)
 
     with ThreadPoolExecutor(max_workers=min(len(stale), os.cpu_count() or 1) or 1) as ex:
         list(ex.map(compile_one, stale))
@@ -104,6 +112,38 @@ def build(force=False, verbose=False, tune=False):
     if not tune:
         check_wave_isa(verbose=verbose)
     return LIB
+
+
+def _res_file(src, tune=False):
+    return os.path.join(LIBDIR, os.path.splitext(src)[0] + ('.tune' if tune else '') + '.res.json')
+
+
+def _write_resources(src, remarks, tune=False):
+    import json
+    import re
+    out = {}
+    for blk in re.split(r'remark: [^\n]*Function Name: ', remarks)[1:]:
+        name = blk.split('\n')[0].strip().split()[0]
+        g = lambda k: int(re.search(k + r': (\d+)', blk).group(1))
+        out[name] = dict(vgpr=g('VGPRs'), agpr=g('AGPRs'), sgpr=g('SGPRs'), scratch=g(r'ScratchSize \[bytes/lane\]'),
+                         occupancy=g(r'Occupancy \[waves/SIMD\]'), lds=g(r'LDS Size \[bytes/block\]'))
+    json.dump(out, open(_res_file(src, tune), 'w'), indent=0, sort_keys=True)
+
+
+def kernel_resources(demangle=True):
+    """{kernel: {vgpr, agpr, sgpr, scratch (bytes per lane), occupancy (waves per SIMD), lds (static bytes)}} of every kernel of the shipping
+    library, as hipcc reported them while compiling the shipped objects."""
+    import json
+    out = {}
+    for src in SOURCES:
+        if os.path.exists(_res_file(src)):
+            out.update(json.load(open(_res_file(src))))
+    if demangle and out:
+        names = list(out)
+        dm = subprocess.run(['c++filt'], input='\n'.join(names), capture_output=True, text=True).stdout.strip().split('\n')
+        if len(dm) == len(names):
+            out = {d.replace('void ', '', 1).split('(')[0]: out[n] for d, n in zip(dm, names)}
+    return out
 
 
 def _wave_src_sha():

@@ -130,8 +130,15 @@ struct PwKArgs {
 // the MFMA work at 4 waves per SIMD and the loop has half as many barriers.  After the loop group 1 hands its accumulators to group 0
 // through the (now free) ring -- a fixed-order fp32 add, deterministic -- and group 0 runs the epilogue.  No global partials, no combine
 // launch, the activations are still read once per n-tile.
+// Waves per SIMD the register allocation must allow (second __launch_bounds__ argument): what each tile shape reached in rounds 1-3 and
+// what its LDS ring is sized for.  Pinned because several shapes sit one register below a cliff -- <5,2> at 176 + 80 = 256: a single
+// extra register in a prologue halves the occupancy (round 4: blocks 13-17's project GEMMs went 54 -> 91 us that way, unnoticed for a
+// few commits); with the bound the compiler re-allocates (or spills a prologue value) instead.
+constexpr int pw_min_waves(int NI, int MI, int NWV) {
+    return NWV >= 8 ? 4 : MI < 4 ? 1 : NI <= 2 ? 4 : NI == 3 ? 3 : 2;
+}
 template <typename T, int NI, int WN, int NS, bool GATE, int MI, int NWV = 4, int KG = 1>
-__global__ __launch_bounds__(NWV * 64) void pw_gemm_dma_kernel(PwKArgs a) {
+__global__ __launch_bounds__(NWV * 64, pw_min_waves(NI, MI, NWV)) void pw_gemm_dma_kernel(PwKArgs a) {
     using D = DT<T>;
     using raw_t = typename D::raw_t;
     constexpr int EPL = D::EPL, KB = D::KB;
