@@ -276,7 +276,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         // tile computes two gates: at 240x320 crops -- maps of 1200 / 300 pixels under 128-row tiles -- the project GEMMs of blocks 13-17
         // went 64 -> 148 us for 13 us of squeeze-excite kernels saved; those sizes keep the kernels)
         b.se_fused = ((n->se_fuse_mask >> i) & 1) && (size_t)b.cse * b.cmid * 8 <= ((size_t)256 << 10) && b.cse <= 128 &&
-                     (b.Ho * b.Wo) % pw_bm(b.proj.cfg) == 0;
+                     (b.Ho * b.Wo) % pw_bm(b.proj.cfg) == 0 && b.proj.cfg.WV == 4 && b.proj.cfg.NI >= 3 && b.cmid > 2 * pw_kb(n->dtype);   // (the 3-stage 4-wave tiles carry the prologue)
         p += (size_t)b.d.cout * b.cmid + 4 * b.d.cout;
         h = b.Ho; w_ = b.Wo;
     }
@@ -415,7 +415,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         SeArgs se{};
         se.partial = w.partial; se.n_tiles = se_tiles; se.w_red = b.se_wr; se.b_red = b.se_br; se.w_exp = b.se_we; se.b_exp = b.se_be;
         se.gate = w.gate; se.B = Bc; se.C = b.cmid; se.Cse = b.cse; se.HW = b.Ho * b.Wo;
-        // Squeeze-excite: blocks 5-17 (b.se_fused; FC matrices <= 222 KB, project GEMMs of <= 2048 workgroups) have NO launch of their own -- every
+        // Squeeze-excite: blocks 5-13 (b.se_fused; FC matrices <= 222 KB, project GEMMs of <= 2048 workgroups) have NO launch of their own -- every
         // workgroup of the project GEMM computes the gates of its samples in its prologue (kernels_net.hip); the late blocks (0.65 / 1.77 MB
         // of FC weights per gate) keep the batched kernels, where a 16-sample tile shares one read of them.
         if (!b.se_fused) {
@@ -549,13 +549,15 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
         // measured (256 crops): batched from block 19: +1.5 %, from 9: another +1.1 % over one-workgroup-per-sample everywhere; the early
         // blocks (Cmid <= 288, Cse <= 12) stay on se_kernel: two dependent launches cost what its one does
         n->se_batch_from = tune_int("COSY_SE_BATCH_FROM", 9);
-        // round 4: blocks 5-17 compute the gate inside the project GEMM's prologue (no squeeze-excite launch at all).  Measured per block
+        // round 4: blocks 5-13 compute the gate inside the project GEMM's prologue (no squeeze-excite launch at all).  Measured per block
         // at 256 crops (profiles/r04_se_fused_ab.txt): the prologue adds 6-11 us to the GEMM (5-8 dependent L2 round trips under the
-        // DMA streams of the co-resident workgroups) against 8-14 us of squeeze-excite kernel(s): -2.3..-6.5 us per block, 13 launches
+        // DMA streams of the co-resident workgroups) against 8-14 us of squeeze-excite kernel(s): -2..-6 us per block, 9 launches
         // fewer per forward.  NOT for blocks 0-4 (their project GEMMs stream 8,000-16,000 workgroups and every one would redo the
         // gate: block 0 160 -> 458 us, blocks 2-4 +13..22 us), block 18 (+3 us) or blocks 19-25 (0.65 / 1.77 MB of FC weights per gate:
         // the size rule in build_weights keeps them on the batched kernels, where a 16-sample tile shares one read of them).
-        n->se_fuse_mask = (unsigned)tune_int("COSY_SE_FUSE_MASK", 0x3ffe0);
+        // Same-box A/B against the round-3 tree (profiles/r04_vs_r03_layers.txt): blocks 5-13 gain 2-6 us each; blocks 14-17 (Cse = 34,
+        // Cmid = 816: the largest prologue) lose 1.7 us each -> not fused.
+        n->se_fuse_mask = (unsigned)tune_int("COSY_SE_FUSE_MASK", 0x3fe0);
         n->small_mask = (unsigned)tune_int("COSY_SMALL_MASK", 0x3f80000);
         n->tile_mask = (unsigned)tune_int("COSY_TILE_MASK", 0x13c);         // blocks 2-5 and 8 (measured in round 1: it loses on the k=5 stride-1 blocks 6/7)   // blocks 19-25 (8x8 / 7x10 maps): whole-image kernel
         n->wave_mask = (unsigned)tune_int("COSY_WAVE_MASK", 0x3fffc);   // blocks 2-17: maps 16..128 pixels wide, stride per shape table

@@ -130,15 +130,19 @@ struct PwKArgs {
 // the MFMA work at 4 waves per SIMD and the loop has half as many barriers.  After the loop group 1 hands its accumulators to group 0
 // through the (now free) ring -- a fixed-order fp32 add, deterministic -- and group 0 runs the epilogue.  No global partials, no combine
 // launch, the activations are still read once per n-tile.
-// Waves per SIMD the register allocation must allow (second __launch_bounds__ argument): what each tile shape reached in rounds 1-3 and
-// what its LDS ring is sized for.  Pinned because several shapes sit one register below a cliff -- <5,2> at 176 + 80 = 256: a single
-// extra register in a prologue halves the occupancy (round 4: blocks 13-17's project GEMMs went 54 -> 91 us that way, unnoticed for a
-// few commits); with the bound the compiler re-allocates (or spills a prologue value) instead.
+// Waves per SIMD every tile shape has to reach (what its LDS ring is sized for).  Several shapes sit one register below a cliff -- <5,2> at
+// 176 VGPRs + 80 AGPRs = 256: a single extra register in a prologue halves the occupancy (round 4: blocks 13-17's project GEMMs went
+// 54 -> 91 us that way, unnoticed for a few commits).  NOT enforced through the second __launch_bounds__ argument for the 4-wave tiles: with it
+// hipcc gives up the VGPR + AGPR split (accumulators in AGPRs) and the <5,2> tile runs 59 instead of 53 us; the bound is held by
+// tests/test_build_isa.py on the resource table the build writes (cosypose_amd/build.py: kernel_resources).
 constexpr int pw_min_waves(int NI, int MI, int NWV) {
     return NWV >= 8 ? 4 : MI < 4 ? 1 : NI <= 2 ? 4 : NI == 3 ? 3 : 2;
 }
-template <typename T, int NI, int WN, int NS, bool GATE, int MI, int NWV = 4, int KG = 1>
-__global__ __launch_bounds__(NWV * 64, pw_min_waves(NI, MI, NWV)) void pw_gemm_dma_kernel(PwKArgs a) {
+constexpr int pw_bound_waves(int NI, int MI, int NWV) { return NWV >= 8 ? 4 : 1; }
+// SEF: the squeeze-excite prologue is compiled in (PwArgs::se_fused).  A template parameter, not a run-time branch: carried by every gated
+// instantiation it cost the streaming project GEMMs of blocks 0-4, which never use it, 4-10 us per launch in registers and code.
+template <typename T, int NI, int WN, int NS, bool GATE, int MI, int NWV = 4, int KG = 1, bool SEF = false>
+__global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm_dma_kernel(PwKArgs a) {
     using D = DT<T>;
     using raw_t = typename D::raw_t;
     constexpr int EPL = D::EPL, KB = D::KB;
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(NWV * 64, pw_min_waves(NI, MI, NWV)) void pw_gemm_d
     float* gl = (float*)(dummy + 1024);   // GATE: [nsamp][Kpad] gate rows of the samples under this m-tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kgp = wave / GW, wq = wave % GW;      // K-group, wave inside the group
+    const int kgp = KG == 1 ? 0 : wave / GW, wq = KG == 1 ? wave : wave % GW;      // K-group, wave inside the group (constants for the plain tiles)
     const int wm = wq / WN, wn = wq % WN;
     const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
     const int mt = (jj / a.NT) * 8 + xcd, nt = jj % a.NT;
@@ -171,14 +175,14 @@ __global__ __launch_bounds__(NWV * 64, pw_min_waves(NI, MI, NWV)) void pw_gemm_d
     size_t achunk[L];
 #pragma unroll
     for (int i = 0; i < L; ++i) {
-        const int m = min(m0 + ((i * NWV + wave) % NB) * 16 + row, M - 1), bs = m / a.HW;
+        const int m = min(m0 + (KG == 1 ? i * NWV + wave : (i * NWV + wave) % NB) * 16 + row, M - 1), bs = m / a.HW;
         achunk[i] = a.a_chunked ? ((size_t)bs * (K >> 4) * a.HW + (m - bs * a.HW)) * 16 : 0;
     }
     auto issue = [&](int ks) {              // stage ks = the k-blocks ks * KG .. ks * KG + KG - 1
         char* st = lds + (ks % NS) * SB * 1024;
 #pragma unroll
         for (int i = 0; i < L; ++i) {
-            const int sblk = i * NWV + wave, blk = sblk % NB, kb = ks * KG + sblk / NB;
+            const int sblk = i * NWV + wave, blk = KG == 1 ? sblk : sblk % NB, kb = KG == 1 ? ks : ks * KG + sblk / NB;     // (no division in the plain tiles: 5-9 us per launch)
             const void* src = a.zeros;
             char* dst = dummy;
             if (kb < a.nkb_valid && sblk < SB) {
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(NWV * 64, pw_min_waves(NI, MI, NWV)) void pw_gemm_d
     if constexpr (KG == 1) prefetch_residual();     // split-K tiles (128 registers per wave): behind the loop, in the shadow of the hand-over
     if constexpr (GATE) {
         const int b_first = m0 / a.HW;
-        if (KG == 1 && a.se_wr) {     // (the split-K tiles serve blocks 19-25, whose squeeze-excite stays on the batched kernels)
+        if constexpr (SEF) {
             // ---- squeeze-excite in the prologue (efficientnet.py:85-88): no se launch between the front kernel and this GEMM.  Every
             // workgroup computes the gate of each sample under its m-tile: pooled = sum of the squeeze partials / HW -> reduce FC + bias
             // -> swish -> expand FC + bias -> sigmoid, fp32, fixed summation order (deterministic; a sample's gate depends on nothing
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(NWV * 64, pw_min_waves(NI, MI, NWV)) void pw_gemm_d
                 // the next sample's pooled / redv are written behind barriers that every thread reaches after this phase
             }
         } else
-        for (int i = tid; i < a.nsamp * Kpad; i += NWV * 64) {
+        for (int i = tid; i < a.nsamp * Kpad; i += NWV * 64) {       // the gate rows a squeeze-excite kernel wrote
             const int sidx = i / Kpad, k = i - sidx * Kpad;
             const long mrow = (long)(b_first + sidx) * a.HW;
             const float g = (k < K && mrow < M) ? a.gate[(size_t)(b_first + sidx) * K + k] : 0.f;
@@ -464,8 +468,9 @@ __global__ __launch_bounds__(NWV * 64, pw_min_waves(NI, MI, NWV)) void pw_gemm_d
     }
 }
 
-template <typename T, int NI, int WN, bool GATE, int NS, int MI, int NWV = 4, int KG = 1>
+template <typename T, int NI, int WN, bool GATE, int NS, int MI, int NWV = 4, int KG = 1, bool SEF = false>
 static int launch_pw_dma_mi(PwKArgs k, hipStream_t s) {
+    if constexpr (!SEF) COSY_REQUIRE(!k.se_wr, "pw_gemm_dma: this tile shape has no squeeze-excite prologue (NI=%d WN=%d)", NI, WN);
     constexpr int WM = NWV / KG / WN, NB = KG * (MI * WM + NI * WN);
     k.MT = cdiv(k.M, 16 * MI * WM);
     const int grid = cdiv(k.MT, 8) * 8 * k.NT;
@@ -476,10 +481,10 @@ static int launch_pw_dma_mi(PwKArgs k, hipStream_t s) {
     COSY_REQUIRE(lds <= 160 * 1024, "pw_gemm_dma: the gate rows of %d samples x K=%d do not fit the LDS (map of %d pixels too small)", k.nsamp, k.K, k.HW);
     // once per instantiation and process, race-free: function-local statics are initialised exactly once (C++11), also when two
     // nets launch from two threads at the same time (the header promises thread-safety across distinct nets / streams)
-    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)pw_gemm_dma_kernel<T, NI, WN, NS, GATE, MI, NWV, KG>,
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)pw_gemm_dma_kernel<T, NI, WN, NS, GATE, MI, NWV, KG, SEF>,
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     COSY_CHECK_HIP(attr_rc);
-    hipLaunchKernelGGL((pw_gemm_dma_kernel<T, NI, WN, NS, GATE, MI, NWV, KG>), dim3(grid), dim3(NWV * 64), lds, s, k);
+    hipLaunchKernelGGL((pw_gemm_dma_kernel<T, NI, WN, NS, GATE, MI, NWV, KG, SEF>), dim3(grid), dim3(NWV * 64), lds, s, k);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }
@@ -494,6 +499,9 @@ static int launch_pw_dma_ns(const PwKArgs& k, int grid, hipStream_t s) {
     if (pw_mi(k) == 2) {
         if constexpr (!GATE) return launch_pw_dma_mi<T, NI, WN, GATE, NS, 2>(k, s);
         else if (k.HW % 32 == 0 && k.HW >= 64) return launch_pw_dma_mi<T, NI, WN, GATE, NS, 2>(k, s);
+    }
+    if constexpr (GATE && NS == 3 && NI >= 3) {       // the fused blocks' project GEMMs: >= 3 k-blocks (Cmid >= 96), tiles of >= 48 columns
+        if (k.se_wr) return launch_pw_dma_mi<T, NI, WN, GATE, NS, 4, 4, 1, true>(k, s);
     }
     return launch_pw_dma_mi<T, NI, WN, GATE, NS, 4>(k, s);
 }
