@@ -10,7 +10,9 @@ TAG=${1:-run}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-other-dtypes $*"
+# --streams 1: the per-kernel numbers (rocprofv3 averages, PMC traffic per launch) are for ONE stream of full-size launches, like the HIP-event
+# pass that bench.py's `roofline` comes from (under concurrency a kernel's counters and duration include its neighbours')
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-other-dtypes --streams 1 $*"
 rocprofv3 -M --kernel-trace --stats -f csv -d $OUT/stats -o t -- python bench.py $ARGS > $OUT/bench_stats.json 2> $OUT/stats.err
 pass() { # name counters...
   local name=$1; shift

@@ -5,20 +5,21 @@
 # the rocprofv3 stats + PMC summaries (profiles/collect.sh) and the batch sweep with matrix-core utilisation.
 # Copy what is to be judged into profiles/ afterwards (profiles/publish.sh <tag>).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/all_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 # 2. per-layer HIP-event table
-python bench.py --steps 4 --warmup 2 --no-cpu-baseline --layers > $OUT/bench_layers.json 2> $OUT/layers_events.txt
+python bench.py --steps 4 --warmup 2 --no-cpu-baseline --streams 1 --layers > $OUT/bench_layers.json 2> $OUT/layers_events.txt
 # 3. other configurations on one GPU
 python bench.py --config 2 --no-cpu-baseline > $OUT/bench_config2.json 2> /dev/null
 python bench.py --config 3 --no-cpu-baseline > $OUT/bench_config3_skewed.json 2> /dev/null
 python bench.py --config 3 --split balanced --no-cpu-baseline > $OUT/bench_config3_balanced.json 2> /dev/null
 python bench.py --crop 240x320 --no-cpu-baseline > $OUT/bench_240x320.json 2> /dev/null
 python bench.py --renderer hip --no-cpu-baseline > $OUT/bench_renderer_hip.json 2> /dev/null
-# 3b. chunks on concurrent HIP streams (CoarseRefinePosePredictor n_streams): opt-in, measured beside the single-stream default
-python bench.py --streams 2 --no-cpu-baseline --no-other-dtypes --no-profile > $OUT/bench_streams2.json 2> /dev/null
+# 3b. the default is two HIP streams per rank (CoarseRefinePosePredictor n_streams); the single-stream schedule and three streams on config 3 beside it
+python bench.py --streams 1 --no-cpu-baseline --no-other-dtypes --no-profile > $OUT/bench_streams1.json 2> /dev/null
+python bench.py --crop 240x320 --streams 1 --no-cpu-baseline --no-other-dtypes --no-profile > $OUT/bench_240x320_streams1.json 2> /dev/null
 python bench.py --config 3 --split balanced --streams 3 --bsz-objects 128 --no-cpu-baseline --no-other-dtypes --no-profile > $OUT/bench_config3_balanced_streams3.json 2> /dev/null
 python bench_train.py --kernels > $OUT/bench_train.json 2> $OUT/bench_train_kernels.txt
 # 4. rocprofv3 stats + PMC passes of the headline command
@@ -31,9 +32,9 @@ cp $OUT/pmc_traffic.json profiles/${TAG%[a-z]}_pmc_traffic.json 2>/dev/null
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 # 5. batch sweep: throughput and matrix-core utilisation of the GEMM kernels at 256..2048 crops per forward
 for B in 256 512 1024 2048; do
-  python bench.py --steps 4 --warmup 2 --detections $B --bsz-objects $B --no-cpu-baseline --no-profile --no-other-dtypes > $OUT/sweep_B$B.json 2> /dev/null
+  python bench.py --steps 4 --warmup 2 --detections $B --bsz-objects $B --streams 1 --no-cpu-baseline --no-profile --no-other-dtypes > $OUT/sweep_B$B.json 2> /dev/null
   rocprofv3 -M --kernel-trace --pmc MfmaUtil SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_BUSY_CU_CYCLES -f csv -d $OUT/sweep_pmc_B$B -o t -- \
-      python bench.py --steps 1 --warmup 1 --detections $B --bsz-objects $B --no-cpu-baseline --no-profile --no-other-dtypes > /dev/null 2> $OUT/sweep_pmc_B$B.err
+      python bench.py --steps 1 --warmup 1 --detections $B --bsz-objects $B --streams 1 --no-cpu-baseline --no-profile --no-other-dtypes > /dev/null 2> $OUT/sweep_pmc_B$B.err
 done
 python profiles/sweep_table.py $OUT > $OUT/batch_sweep.txt 2>&1
 rm -rf $OUT/sweep_pmc_B*/  # raw counter dumps are large; the table is what is kept

@@ -535,6 +535,42 @@ def test_headline_config_vs_oracle(model, oracle, golden_sd, mesh_table, labels2
 # ---------------------------------------------------------------------------------------------
 # full-size (BASELINE configs[1]: 256 crops in flight) size-independent properties
 # ---------------------------------------------------------------------------------------------
+def test_headline_launch_size_vs_oracle(model, oracle, golden_sd, mesh_table, labels21):
+    """The benched launch size against the oracle DIRECTLY: 256 detections of the bench's generator in ONE 256-crop launch of every kernel
+    (bsz_objects = 256, one stream: the schedule bench.py's per-kernel pass times), one coarse iteration, fp32 and the headline fp16,
+    per parameter group <= 1e-4 against the torch-CPU oracle on the same inputs.  (test_headline_config_vs_oracle runs the 5-iteration
+    loop at 32 detections; test_full_batch_properties ties 256-crop launches to small ones bit for bit; this closes the triangle with
+    an oracle comparison at the launch size itself.  One iteration: the oracle's 256 crops take ~20 s of host time.)"""
+    import pandas as pd
+    from conftest import pose_errors, rows_rel_err
+    from cosypose_amd import tensor_collection as tc
+    from cosypose_amd.pose_predictor import CoarseRefinePosePredictor
+    D, n_frames, h, w = 256, 16, 512, 512
+    obj, im, boxes = syn.make_detections(11, D, n_frames, 21, h, w)
+    frames, K = syn.make_frames(1, n_frames, h, w), syn.make_K(n_frames, h, w)
+    rend = syn.make_renders(9000, D, 256, 256)
+    oracle.set_threads(min(os.cpu_count() or 1, 16)); torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    TCO = oracle.tco_init_from_boxes(boxes, K[im])
+    want = oracle.pose_predictor_forward(frames[im], K[im], obj, TCO, mesh_table, None, lambda n, t, k: rend, 1, (256, 256),
+                                         backbone=oracle.TorchRef(golden_sd).net_forward)['iteration=1']
+    det = tc.PandasTensorCollection(infos=pd.DataFrame(dict(label=labels21[obj], batch_im_id=im, score=1.0)), bboxes=dev(boxes))
+    model.render_size = (256, 256)
+    model.cfg.init_method = 'v0'
+    try:
+        for dtype in ('fp32', 'fp16'):
+            model.compute_dtype = dtype
+            model.renderer = FakeRenderer(9000)          # the same renders as the oracle's, for every dtype
+            pred = CoarseRefinePosePredictor(coarse_model=model, refiner_model=model, bsz_objects=256, n_streams=1)
+            final, allp = pred.get_predictions(dev(frames), dev(K), detections=det, n_coarse_iterations=1, n_refiner_iterations=0)
+            got = allp['coarse/iteration=1']
+            r, t = pose_errors(got.poses.cpu().numpy(), want['TCO_output'])
+            kc = rows_rel_err(got.K_crop.cpu().numpy(), want['K_crop'])
+            print(f'256 crops in one launch, {dtype} vs fp32 oracle: R {r:.2e} t {t:.2e} K_crop {kc:.2e}')
+            assert r < NET_TOL and t < NET_TOL and kc < NET_TOL, (dtype, r, t, kc)
+    finally:
+        model.compute_dtype = 'fp32'; model.render_size = (240, 320)
+
+
 @pytest.mark.parametrize('dtype', ['fp16', 'bf16', 'fp32'])
 def test_full_batch_properties(model, labels21, dtype):
     """At B=256, 256x256 crops: (1) bitwise run-to-run determinism (fixed-order reductions everywhere),
