@@ -217,3 +217,31 @@ def test_sharded_scenes_mixed_frame_sizes_simulated_ranks():
             poses, plan = get_predictions_sharded_scenes(pred, scenes, 1, 2, rank=r, world_size=world,
                                                          gather_rows=lambda l, c: torch.cat(local_rows), **kw)
             assert torch.equal(poses, ref) and sum(len(p) for p in plan) == 27
+
+
+def test_self_launch_spawns_its_ranks():
+    """`python script.py --gpus N` without a launcher (the driver's command shape for bench.py): self_launch re-executes the script as N
+    ranks under torch.distributed.run on 127.0.0.1, stdout carries rank 0's single JSON line, the exit code is the launcher's; with
+    WORLD_SIZE already set (an external launcher) or N = 1 it launches nothing.  gloo on CPU; the GPU suite runs bench.py itself this way."""
+    import json
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'selflaunch_worker.py')
+    env = dict(os.environ, COSY_DIST_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'):
+        env.pop(k, None)
+    for n in (1, 2, 3):
+        r = subprocess.run([sys.executable, worker, '--gpus', str(n)], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+        lines = [l for l in r.stdout.split('\n') if l.startswith('{')]
+        assert len(lines) == 1, r.stdout
+        rec = json.loads(lines[0])
+        assert rec['n_gpus'] == n and rec['launched'] == (n > 1)
+        assert rec['rows'] == [float(q) for q in range(n) for _ in range(q + 1)]          # rank order = row order, ragged shares
+        assert rec['process_group']['world_size'] == n and rec['process_group']['backend'] == ('gloo' if n > 1 else None)
+    # nccl with fewer GPUs than ranks: a message, not a hang
+    env_nccl = {k: v for k, v in env.items() if k != 'COSY_DIST_BACKEND'}
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, worker, '--gpus', '2'], capture_output=True, text=True, timeout=120, env=env_nccl)
+        assert r.returncode != 0 and 'RCCL refuses several ranks on one device' in r.stderr
