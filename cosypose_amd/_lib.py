@@ -51,6 +51,7 @@ _SIGNATURES = {
     'cosy_bn_train_stats': ([_P, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P], _I),
     'cosy_bn_train_apply': ([_P, _P, _P, _P, _P, _L, _I, _I, _P, _I, _P, _P, _P], _I),
     'cosy_bn_train_backward': ([_P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P], _I),
+    'cosy_bn_train_backward_gated': ([_P, _P, _P, _F, _P, _P, _P, _P, _P, _L, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P], _I),
     'cosy_dw_train_forward': ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _P], _I),
     'cosy_dw_train_backward_data': ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _P], _I),
     'cosy_dw_train_backward_weight': ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P], _I),

@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, long M,
                                                             int C, int act, const float* __restrict__ rowscale, int HW,
-                                                            int rows_per_slab, double* __restrict__ partial) {
+                                                            int rows_per_slab, double* __restrict__ partial, const float* __restrict__ cgate,
+                                                            const float* __restrict__ cadd, float cadd_scale) {
     __shared__ double lds[16 * 16 * 4 * 2];
     const int tid = threadIdx.x, cq = tid & 15, rs = tid >> 4;
     const int cbase = blockIdx.x * 64, c0 = cbase + cq * 4, slab = blockIdx.y;
@@ -159,6 +160,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                 xv[u] = ok ? *(const f32x4*)(x + rr * C + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
                 dv[u] = ok ? *(const f32x4*)(dout + rr * C + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
                 sc[u] = !ok ? 0.f : (rowscale ? rowscale[rr / HW] : 1.f);
+                if (cgate && ok) {        // incoming gradient = dout * gate[sample][c] + add[sample][c] * scale, formed on the fly (squeeze-excite backward)
+                    const size_t bo = (size_t)((unsigned)rr / (unsigned)HW) * C + c0;
+                    const f32x4 gq = *(const f32x4*)(cgate + bo), aq = *(const f32x4*)(cadd + bo);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dv[u][k] = dv[u][k] * gq[k] + aq[k] * cadd_scale;
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -178,7 +185,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ sum_dy, const float* __restrict__ sum_dyx, long n4,
                                                            int C4, float inv_M, int act, const float* __restrict__ rowscale, int HW,
-                                                           float* __restrict__ dx) {
+                                                           float* __restrict__ dx, const float* __restrict__ cgate, const float* __restrict__ cadd,
+                                                           float cadd_scale) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const int c4 = (int)(i % C4);
@@ -186,11 +194,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const f32x4 v = __builtin_nontemporal_load((const f32x4*)x + i), d0 = __builtin_nontemporal_load((const f32x4*)dout + i), m = ((const f32x4*)mean)[c4], r = ((const f32x4*)rstd)[c4];
     const f32x4 g = ((const f32x4*)gamma)[c4], b = ((const f32x4*)beta)[c4], s1 = ((const f32x4*)sum_dy)[c4], s2 = ((const f32x4*)sum_dyx)[c4];
     const float rs = rowscale ? rowscale[row / HW] : 1.f;
+    f32x4 dq = d0;
+    if (cgate) {
+        const size_t bo = (size_t)((unsigned)row / (unsigned)HW) * C4 + c4;
+        const f32x4 gq = ((const f32x4*)cgate)[bo], aq = ((const f32x4*)cadd)[bo];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dq[k] = d0[k] * gq[k] + aq[k] * cadd_scale;
+    }
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float xhat = (v[k] - m[k]) * r[k];
-        const float d = bn_dy(d0[k], xhat, g[k], b[k], act, rs);
+        const float d = bn_dy(dq[k], xhat, g[k], b[k], act, rs);
         o[k] = g[k] * r[k] * (d - s1[k] * inv_M - xhat * s2[k] * inv_M);
     }
     ((f32x4*)dx)[i] = o;
@@ -1158,19 +1173,27 @@ int cosy_bn_train_apply(const float* x, const float* mean, const float* rstd, co
 int cosy_bn_train_backward(const float* dout, const float* x, const float* mean, const float* rstd, const float* gamma,
                            const float* beta, long M, int C, int act, const float* rowscale, int HW, float* dgamma, float* dbeta,
                            int accumulate, float* dx, float* sums /*2*C scratch*/, void* workspace, cosy_stream_t stream) {
+    return cosy_bn_train_backward_gated(dout, nullptr, nullptr, 0.f, x, mean, rstd, gamma, beta, M, C, act, rowscale, HW, dgamma, dbeta, accumulate, dx,
+                                        sums, workspace, stream);
+}
+int cosy_bn_train_backward_gated(const float* dout, const float* cgate, const float* cadd, float cadd_scale, const float* x, const float* mean,
+                                 const float* rstd, const float* gamma, const float* beta, long M, int C, int act, const float* rowscale, int HW,
+                                 float* dgamma, float* dbeta, int accumulate, float* dx, float* sums /*2*C scratch*/, void* workspace,
+                                 cosy_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
+    COSY_REQUIRE(!cgate || (cadd && M % HW == 0 && M < (1l << 31)), "bn_train_backward: the per-sample gate / add rows need M=%ld = samples x HW=%d", M, HW);
     COSY_REQUIRE(dout && x && mean && rstd && gamma && beta && dgamma && dbeta && dx && sums && workspace && C % 4 == 0 && M > 0 && HW > 0,
                  "bn_train_backward: bad argument");
     const RedGeom g = red_geom(M, C);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.cgroups, g.nslab), dim3(256), 0, s, dout, x, mean, rstd, gamma, beta, M, C, act, rowscale,
-                       HW, g.rows_per_slab, (double*)workspace);
+                       HW, g.rows_per_slab, (double*)workspace, cgate, cadd, cadd_scale);
     COSY_CHECK_HIP(hipGetLastError());
     // this call's sums (needed by dx) into `sums`; the parameter gradients accumulate on request
     hipLaunchKernelGGL(bn_bwd_combine_final_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, (const double*)workspace, g.nslab, C, sums, dgamma, dbeta,
                        accumulate);
     COSY_CHECK_HIP(hipGetLastError());
     LAUNCH1D(bn_bwd_apply_kernel, M * (C / 4), s, dout, x, mean, rstd, gamma, beta, sums, sums + C, M * (C / 4), C / 4, 1.f / (float)M, act,
-             rowscale, HW, dx);
+             rowscale, HW, dx, cgate, cadd, cadd_scale);
     return COSY_OK;
 }
 

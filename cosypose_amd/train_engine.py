@@ -58,11 +58,12 @@ def bn_apply(x, mean, rstd, gamma, beta, M, C, act, rowscale=None, HW=1, res=Non
     return out
 
 
-def bn_backward(dout, x, mean, rstd, gamma, beta, M, C, act, rowscale=None, HW=1, out=None):
+def bn_backward(dout, x, mean, rstd, gamma, beta, M, C, act, rowscale=None, HW=1, out=None, cgate=None, cadd=None, cadd_scale=0.0):
+    """cgate / cadd (B,C): the incoming gradient is dout * cgate[sample] + cadd[sample] * cadd_scale, formed inside the kernels (HW rows per sample)"""
     dgamma, dbeta = out if out is not None else (torch.empty(C, device=x.device), torch.empty(C, device=x.device))
     dx = torch.empty_like(x); sums = torch.empty(2 * C, device=x.device)
-    check(lib().cosy_bn_train_backward(ptr(dout), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), M, C, act, ptr(rowscale), HW,
-                                       ptr(dgamma), ptr(dbeta), 0, ptr(dx), ptr(sums), ptr(_workspace(x.device)), stream()))
+    check(lib().cosy_bn_train_backward_gated(ptr(dout), ptr(cgate), ptr(cadd), cadd_scale, ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), M, C, act,
+                                             ptr(rowscale), HW, ptr(dgamma), ptr(dbeta), 0, ptr(dx), ptr(sums), ptr(_workspace(x.device)), stream()))
     return dx, dgamma, dbeta
 
 
@@ -238,10 +239,14 @@ class _Net:
         tape[name] = (raw, mean, rstd, M, C, act, rowscale, HW)
         return bn_apply(raw, mean, rstd, self.P[name + '.weight'], self.P[name + '.bias'], M, C, act, rowscale, HW, res)
 
-    def _bn_b(self, tape, grads, name, dout):
+    def _bn_b(self, tape, grads, name, dout, cgate=None, cadd=None, cadd_scale=0.0, HWg=None):
         raw, mean, rstd, M, C, act, rowscale, HW = tape[name]
         out = (self._dst(name + '.weight'), self._dst(name + '.bias')) if self.stage is not None else None
-        dx, dg, db = bn_backward(dout, raw, mean, rstd, self.P[name + '.weight'], self.P[name + '.bias'], M, C, act, rowscale, HW, out=out)
+        if cgate is not None:
+            assert rowscale is None
+            HW = HWg
+        dx, dg, db = bn_backward(dout, raw, mean, rstd, self.P[name + '.weight'], self.P[name + '.bias'], M, C, act, rowscale, HW, out=out,
+                                 cgate=cgate, cadd=cadd, cadd_scale=cadd_scale)
         grads[name + '.weight'], grads[name + '.bias'] = dg, db
         return dx
 
@@ -325,8 +330,8 @@ class _Net:
                                                       D(p + '_se_expand.weight'), D(p + '_se_expand.bias')) if staged else None)
             grads[p + '_se_reduce.weight'], grads[p + '_se_reduce.bias'] = dw1.view_as(w1), db1
             grads[p + '_se_expand.weight'], grads[p + '_se_expand.bias'] = dw2.view_as(w2), db2
-            da1 = rows_scale(da2, g, B, HWo, cmid, add=dpooled, add_scale=1.0 / HWo)
-            draw = self._bn_b(tape, grads, p + '_bn1', da1)
+            # da1 = da2 * g + dpooled / HW (gradient through the gate multiply and the pooled mean) is formed inside BatchNorm 1's backward kernels
+            draw = self._bn_b(tape, grads, p + '_bn1', da2, cgate=g, cadd=dpooled, cadd_scale=1.0 / HWo, HWg=HWo)
             da0, dwt = dw_backward(a0, draw, wt, B, H, W, cmid, k, s)
             if staged:
                 D(p + '_depthwise_conv.weight').view(cmid, k * k).copy_(dwt.t())

@@ -207,6 +207,12 @@ int cosy_bn_train_apply(const float* x, const float* mean, const float* rstd, co
 int cosy_bn_train_backward(const float* dout, const float* x, const float* mean, const float* rstd, const float* gamma,
                            const float* beta, long M, int C, int act, const float* rowscale, int HW, float* dgamma, float* dbeta,
                            int accumulate, float* dx, float* sums, void* workspace, cosy_stream_t stream);
+/* the same with the incoming gradient formed on the fly as dout * cgate[sample][c] + cadd[sample][c] * cadd_scale (sample = row / HW; cgate,
+ * cadd (B,C)): the squeeze-excite backward of an MBConv block (gradient through the gate multiply + the pooled mean) feeds BatchNorm 1's
+ * backward without the sum being stored */
+int cosy_bn_train_backward_gated(const float* dout, const float* cgate, const float* cadd, float cadd_scale, const float* x, const float* mean,
+                                 const float* rstd, const float* gamma, const float* beta, long M, int C, int act, const float* rowscale, int HW,
+                                 float* dgamma, float* dbeta, int accumulate, float* dx, float* sums, void* workspace, cosy_stream_t stream);
 /* depthwise convolution with the reference's static "same" padding; weights transposed to (k*k, C) */
 int cosy_dw_train_forward(const float* x, const float* wt, int B, int H, int W, int C, int k, int stride, float* out,
                           cosy_stream_t stream);
