@@ -61,6 +61,9 @@ _SIGNATURES = {
     'cosy_train_gemm': ([_P, _P, _I, _L, _I, _I, _P, _P, _P, _P], _I),
     'cosy_stem_im2col_ld': ([_P, _I, _I, _I, _I, _P, _P], _I),
     'cosy_rows_mean': ([_P, _I, _I, _I, _P, _P, _P], _I),
+    'cosy_rows_mean_bn': ([_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P], _I),
+    'cosy_rows_dot_bn': ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P], _I),
+    'cosy_bn_train_apply_gated': ([_P, _P, _P, _P, _P, _L, _I, _I, _P, _I, _P, _P], _I),
     'cosy_rows_dot': ([_P, _P, _I, _I, _I, _P, _P, _P], _I),
     'cosy_rows_scale': ([_P, _P, _P, _F, _I, _I, _I, _P, _P], _I),
     'cosy_rows_broadcast': ([_P, _F, _I, _I, _I, _P, _P], _I),

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, long n4, int C4, int act,
                                                        const float* __restrict__ rowscale, int HW, const float* __restrict__ res,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, const float* __restrict__ cgate) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const int c4 = (int)(i % C4);
@@ -122,6 +122,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         float y = (v[k] - m[k]) * r[k] * g[k] + b[k];
         if (act == 1) y = y * sigmoidf_(y);
         o[k] = y * rs;
+    }
+    if (cgate) {        // squeeze-excite: out = act(bn(x)) * gate[sample][c] -- the unscaled activation is never stored
+        const f32x4 gq = ((const f32x4*)cgate)[(size_t)((unsigned)row / (unsigned)HW) * C4 + c4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] *= gq[k];
     }
     if (res) {
         const f32x4 q = ((const f32x4*)res)[i];
@@ -513,15 +518,23 @@ __global__ __launch_bounds__(1024) void bn_bwd_combine_final_kernel(const double
 // ------------------------------------------------------------------------------------------
 // partial[(b*nchunk + chunk)][c] = sum over the chunk's pixels of f(a[b][p][c] (, a2[b][p][c]));  MODE 0: a;  MODE 1: a * a2.
 // One workgroup per (64 channels, sample, chunk of pixels); rows_reduce_final sums the chunks and scales.
-template <int MODE>
+// BN: the activation operand (MODE 0: a; MODE 1: a2) is given as the BatchNorm INPUT and swish(bn(.)) is recomputed per element (same
+// arithmetic as bn_apply_kernel), so that the activated tensor need not exist in memory
+struct BnParams { const float *mean, *rstd, *gamma, *beta; };
+template <int MODE, bool BN = false>
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ a, const float* __restrict__ a2, int HW, int C,
-                                                          int rows_per_chunk, double* __restrict__ partial) {
+                                                          int rows_per_chunk, double* __restrict__ partial, BnParams bn = BnParams{}) {
     // 16 channel quads x 16 row lanes per workgroup, 16-byte loads, four independent rows in flight per lane (see bn_stats_kernel)
     __shared__ double lds[16 * 16 * 4];
     const int tid = threadIdx.x, cq = tid & 15, rs = tid >> 4;
     const int cbase = blockIdx.x * 64, c0 = cbase + cq * 4, b = blockIdx.y, chunk = blockIdx.z, nchunk = gridDim.z;
     const int p0 = chunk * rows_per_chunk, p1 = min(HW, p0 + rows_per_chunk);
     double acc[4] = {0., 0., 0., 0.};
+    f32x4 bm = {0.f, 0.f, 0.f, 0.f}, br = bm, bg = bm, bb = bm;
+    if constexpr (BN) {
+        if (c0 < C) { bm = *(const f32x4*)(bn.mean + c0); br = *(const f32x4*)(bn.rstd + c0); bg = *(const f32x4*)(bn.gamma + c0); bb = *(const f32x4*)(bn.beta + c0); }
+    }
+    auto actv = [&](float x, int k) { float y = (x - bm[k]) * br[k] * bg[k] + bb[k]; return y * sigmoidf_(y); };
     if (c0 < C)
         for (int p = p0 + rs; p < p1; p += 64) {
             f32x4 v[4], w[4];
@@ -535,7 +548,13 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restric
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc[k] += MODE == 0 ? (double)v[u][k] : (double)v[u][k] * w[u][k];
+                for (int k = 0; k < 4; ++k) {
+                    if constexpr (BN) {
+                        if (p + 16 * u < p1) acc[k] += MODE == 0 ? (double)actv(v[u][k], k) : (double)v[u][k] * actv(w[u][k], k);
+                    } else {
+                        acc[k] += MODE == 0 ? (double)v[u][k] : (double)v[u][k] * w[u][k];
+                    }
+                }
         }
 #pragma unroll
     for (int k = 0; k < 4; ++k) lds[(rs * 16 + cq) * 4 + k] = acc[k];
@@ -1166,7 +1185,17 @@ int cosy_bn_train_apply(const float* x, const float* mean, const float* rstd, co
     hipStream_t s = (hipStream_t)stream;
     COSY_REQUIRE(x && mean && rstd && gamma && beta && out && C % 4 == 0 && HW > 0, "bn_train_apply: bad argument (C=%d)", C);
     if (M == 0) return COSY_OK;
-    LAUNCH1D(bn_apply_kernel, M * (C / 4), s, x, mean, rstd, gamma, beta, M * (C / 4), C / 4, act, rowscale, HW, res, out);
+    LAUNCH1D(bn_apply_kernel, M * (C / 4), s, x, mean, rstd, gamma, beta, M * (C / 4), C / 4, act, rowscale, HW, res, out, (const float*)nullptr);
+    return COSY_OK;
+}
+int cosy_bn_train_apply_gated(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, long M, int C,
+                              int act, const float* cgate, int HW, float* out, cosy_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    COSY_REQUIRE(x && mean && rstd && gamma && beta && out && cgate && C % 4 == 0 && HW > 0 && M % HW == 0 && M < (1l << 31),
+                 "bn_train_apply_gated: bad argument (C=%d, M=%ld, HW=%d)", C, M, HW);
+    if (M == 0) return COSY_OK;
+    LAUNCH1D(bn_apply_kernel, M * (C / 4), s, x, mean, rstd, gamma, beta, M * (C / 4), C / 4, act, (const float*)nullptr, HW, (const float*)nullptr, out,
+             cgate);
     return COSY_OK;
 }
 
@@ -1344,6 +1373,32 @@ int cosy_rows_dot(const float* a, const float* a2, int B, int HW, int C, float* 
     const int nchunk = rows_chunks(B, HW, C, &rpc);
     hipLaunchKernelGGL(rows_reduce_kernel<1>, dim3(cdiv(C, 64), B, nchunk), dim3(256), 0, (hipStream_t)stream, a, a2, HW, C, rpc,
                        (double*)workspace);
+    COSY_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rows_reduce_final_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, nchunk, C,
+                       1.f, out);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+int cosy_rows_mean_bn(const float* raw, const float* mean, const float* rstd, const float* gamma, const float* beta, int B, int HW, int C, float* out,
+                      void* workspace, cosy_stream_t stream) {
+    COSY_REQUIRE(raw && mean && rstd && gamma && beta && out && workspace && B > 0 && HW > 0 && C > 0 && C % 4 == 0, "rows_mean_bn: bad argument");
+    int rpc;
+    const int nchunk = rows_chunks(B, HW, C, &rpc);
+    hipLaunchKernelGGL((rows_reduce_kernel<0, true>), dim3(cdiv(C, 64), B, nchunk), dim3(256), 0, (hipStream_t)stream, raw, (const float*)nullptr, HW, C,
+                       rpc, (double*)workspace, BnParams{mean, rstd, gamma, beta});
+    COSY_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rows_reduce_final_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, nchunk, C,
+                       1.f / (float)HW, out);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+int cosy_rows_dot_bn(const float* a, const float* raw, const float* mean, const float* rstd, const float* gamma, const float* beta, int B, int HW, int C,
+                     float* out, void* workspace, cosy_stream_t stream) {
+    COSY_REQUIRE(a && raw && mean && rstd && gamma && beta && out && workspace && B > 0 && HW > 0 && C > 0 && C % 4 == 0, "rows_dot_bn: bad argument");
+    int rpc;
+    const int nchunk = rows_chunks(B, HW, C, &rpc);
+    hipLaunchKernelGGL((rows_reduce_kernel<1, true>), dim3(cdiv(C, 64), B, nchunk), dim3(256), 0, (hipStream_t)stream, a, raw, HW, C, rpc,
+                       (double*)workspace, BnParams{mean, rstd, gamma, beta});
     COSY_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(rows_reduce_final_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, nchunk, C,
                        1.f, out);

@@ -92,6 +92,27 @@ def rows_mean(a, B, HW, C):
     return out
 
 
+def rows_mean_bn(raw, mean, rstd, gamma, beta, B, HW, C):
+    """per-sample mean over the pixels of swish(bn(raw)), the activation recomputed on the fly (never stored)"""
+    out = torch.empty(B, C, device=raw.device)
+    check(lib().cosy_rows_mean_bn(ptr(raw), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), B, HW, C, ptr(out), ptr(_workspace(raw.device)), stream()))
+    return out
+
+
+def rows_dot_bn(a, raw, mean, rstd, gamma, beta, B, HW, C):
+    """per-sample sum over the pixels of a * swish(bn(raw))"""
+    out = torch.empty(B, C, device=a.device)
+    check(lib().cosy_rows_dot_bn(ptr(a), ptr(raw), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), B, HW, C, ptr(out), ptr(_workspace(a.device)), stream()))
+    return out
+
+
+def bn_apply_gated(x, mean, rstd, gamma, beta, M, C, act, cgate, HW):
+    """act(bn(x)) * cgate[sample][c] (cgate (B,C), HW rows per sample)"""
+    out = torch.empty_like(x)
+    check(lib().cosy_bn_train_apply_gated(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), M, C, act, ptr(cgate), HW, ptr(out), stream()))
+    return out
+
+
 def rows_dot(a, a2, B, HW, C):
     out = torch.empty(B, C, device=a.device)
     check(lib().cosy_rows_dot(ptr(a), ptr(a2), B, HW, C, ptr(out), ptr(_workspace(a.device)), stream()))
@@ -277,16 +298,20 @@ class _Net:
             raw = dw_forward(a0, wt, B, H, W, cmid, k, s)
             Ho, Wo = _dw_out(H, W, k, s)
             Mo, HWo = B * Ho * Wo, Ho * Wo
-            a1 = self._bn_f(tape, p + '_bn1', raw, Mo, cmid, 1)
-            # squeeze-excite
-            pooled = rows_mean(a1, B, HWo, cmid)
+            # BatchNorm 1 + Swish + squeeze-excite without the unscaled activation a1 in memory: statistics, then the per-sample means of
+            # swish(bn(raw)) recomputed on the fly, the gate, and ONE pass that writes swish(bn(raw)) * gate (the project conv's input)
+            n1 = p + '_bn1'
+            mean1, rstd1 = bn_stats(raw, Mo, cmid, self.buf.get(n1 + '.running_mean'), self.buf.get(n1 + '.running_var'))
+            tape[n1] = (raw, mean1, rstd1, Mo, cmid, 1, None, 1)
+            g1, b1 = P[n1 + '.weight'], P[n1 + '.bias']
+            pooled = rows_mean_bn(raw, mean1, rstd1, g1, b1, B, HWo, cmid)
             h_pre, g = se_forward(pooled, P[p + '_se_reduce.weight'], P[p + '_se_reduce.bias'], P[p + '_se_expand.weight'], P[p + '_se_expand.bias'])
-            a2 = rows_scale(a1, g, B, HWo, cmid)
+            a2 = bn_apply_gated(raw, mean1, rstd1, g1, b1, Mo, cmid, 1, g, HWo)
             raw = gemm(a2, P[p + '_project_conv.weight'].view(cout, cmid))
             skip = s == 1 and cin == cout
             rowscale = drop.get(i) if (skip and drop) else None
             x = self._bn_f(tape, p + '_bn2', raw, Mo, cout, 0, rowscale, HWo, inp if skip else None)
-            tape[p] = (inp, a0, wt, a1, pooled, h_pre, g, a2, H, W, Ho, Wo)
+            tape[p] = (inp, a0, wt, pooled, h_pre, g, a2, H, W, Ho, Wo)
             H, W = Ho, Wo
         M = B * H * W
         raw = gemm(x, P['backbone._conv_head.weight'].view(arch.HEAD_C, -1))
@@ -315,7 +340,7 @@ class _Net:
         for i in reversed(range(len(arch.B3_BLOCKS))):
             k, s, e, cin, cout = arch.B3_BLOCKS[i]
             p = f'backbone._blocks.{i}.'
-            inp, a0, wt, a1, pooled, h_pre, g, a2, H, W, Ho, Wo = tape[p]
+            inp, a0, wt, pooled, h_pre, g, a2, H, W, Ho, Wo = tape[p]
             cmid, HWo = cin * e, Ho * Wo
             skip = s == 1 and cin == cout
             dout = dx
@@ -324,7 +349,8 @@ class _Net:
             grads[p + '_project_conv.weight'] = wgrad(draw, a2, out=D(p + '_project_conv.weight')).view_as(wp)
             da2 = gemm(draw, wp.view(cout, cmid), w_is_kn=True)
             # squeeze-excite backward
-            dg = rows_dot(da2, a1, B, HWo, cmid)
+            raw1, mean1, rstd1 = tape[p + '_bn1'][:3]
+            dg = rows_dot_bn(da2, raw1, mean1, rstd1, P[p + '_bn1.weight'], P[p + '_bn1.bias'], B, HWo, cmid)      # sum_hw da2 * a1, a1 recomputed
             w2, w1 = P[p + '_se_expand.weight'], P[p + '_se_reduce.weight']
             dpooled, dw1, db1, dw2, db2 = se_backward(dg, g, h_pre, pooled, w1, w2, out=(D(p + '_se_reduce.weight'), D(p + '_se_reduce.bias'),
                                                       D(p + '_se_expand.weight'), D(p + '_se_expand.bias')) if staged else None)

@@ -235,6 +235,15 @@ int cosy_wgrad_tall(const float* dY, const float* X, long M, int N, int K, float
 /* per-sample reductions / broadcasts over the HW pixels of a (B,HW,C) activation: mean (adaptive_avg_pool2d),
  * sum of a*a2 (gradient of the squeeze-excite gate), a*g[b,c] (+ add[b,c]*add_scale), v[b,c]*scale broadcast */
 int cosy_rows_mean(const float* a, int B, int HW, int C, float* out, void* workspace, cosy_stream_t stream);
+/* Squeeze-excite without the unscaled activation in memory (efficientnet.py:84-90 in train mode): the per-sample means / dot products take the
+ * BatchNorm INPUT `raw` and recompute swish(bn(raw)) per element (the arithmetic of cosy_bn_train_apply), and cosy_bn_train_apply_gated writes
+ * swish(bn(raw)) * cgate[sample][c] -- the project conv's input -- directly. */
+int cosy_rows_mean_bn(const float* raw, const float* mean, const float* rstd, const float* gamma, const float* beta, int B, int HW, int C, float* out,
+                      void* workspace, cosy_stream_t stream);
+int cosy_rows_dot_bn(const float* a, const float* raw, const float* mean, const float* rstd, const float* gamma, const float* beta, int B, int HW, int C,
+                     float* out, void* workspace, cosy_stream_t stream);
+int cosy_bn_train_apply_gated(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, long M, int C, int act,
+                              const float* cgate, int HW, float* out, cosy_stream_t stream);
 int cosy_rows_dot(const float* a, const float* a2, int B, int HW, int C, float* out, void* workspace, cosy_stream_t stream);
 int cosy_rows_scale(const float* a, const float* g, const float* add, float add_scale, int B, int HW, int C, float* out,
                     cosy_stream_t stream);
