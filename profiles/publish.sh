@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy the judged artefacts of a profiles/collect_all.sh run from gpurun_out/ (scratch) into profiles/ (tracked):
 #   profiles/publish.sh <tag> [round-prefix]      e.g. profiles/publish.sh r02c r02
-TAG=${1:?tag}; R=${2:-r03}
+TAG=${1:?tag}; R=${2:-r04}
 S=gpurun_out/all_$TAG
 cp $S/bench.json profiles/${R}_bench.json
 cp $S/layers_events.txt profiles/${R}_layers_events.txt
@@ -9,6 +9,7 @@ cp $S/summary.txt profiles/${R}_pmc_summary.txt
 cp $S/pmc_traffic.json profiles/${R}_pmc_traffic.json
 cp $S/kernel_stats.csv profiles/${R}_rocprofv3_kernel_stats.csv
 cp $S/batch_sweep.txt profiles/${R}_batch_sweep.txt
+cp $S/stream_overlap.txt profiles/${R}_stream_overlap.txt 2>/dev/null
 cp $S/rccl_kernels.csv profiles/${R}_rccl_1rank_log.txt
 cp $S/bench_train.json profiles/${R}_bench_train.json
 grep -E "time by family|  gemm " $S/bench_train_kernels.txt > profiles/${R}_bench_train_families.txt
