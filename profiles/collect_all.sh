@@ -22,12 +22,6 @@ python bench.py --streams 1 --no-cpu-baseline --no-other-dtypes --no-profile > $
 python bench.py --crop 240x320 --streams 1 --no-cpu-baseline --no-other-dtypes --no-profile > $OUT/bench_240x320_streams1.json 2> /dev/null
 python bench.py --config 3 --split balanced --streams 3 --bsz-objects 128 --no-cpu-baseline --no-other-dtypes --no-profile > $OUT/bench_config3_balanced_streams3.json 2> /dev/null
 python bench_train.py --kernels > $OUT/bench_train.json 2> $OUT/bench_train_kernels.txt
-# 3c. kernel concurrency of the default (two-stream) schedule against one stream: rocprofv3 kernel traces -> profiles/overlap.py
-for ST in 2 1; do
-  rocprofv3 -M --kernel-trace -f csv -d $OUT/trace_s$ST -o t -- python bench.py --steps 3 --warmup 2 --streams $ST --no-cpu-baseline --no-profile --no-other-dtypes > /dev/null 2> $OUT/trace_s$ST.err
-  python profiles/overlap.py $OUT/trace_s$ST "streams=$ST" >> $OUT/stream_overlap.txt 2>&1
-  rm -rf $OUT/trace_s$ST
-done
 # 4. rocprofv3 stats + PMC passes of the headline command
 bash profiles/collect.sh $TAG > $OUT/collect.log 2>&1
 cp -r gpurun_out/prof_$TAG/summary.txt gpurun_out/prof_$TAG/pmc_traffic.json gpurun_out/prof_$TAG/rccl_kernels.csv $OUT/ 2>/dev/null

@@ -9,7 +9,6 @@ cp $S/summary.txt profiles/${R}_pmc_summary.txt
 cp $S/pmc_traffic.json profiles/${R}_pmc_traffic.json
 cp $S/kernel_stats.csv profiles/${R}_rocprofv3_kernel_stats.csv
 cp $S/batch_sweep.txt profiles/${R}_batch_sweep.txt
-cp $S/stream_overlap.txt profiles/${R}_stream_overlap.txt 2>/dev/null
 cp $S/rccl_kernels.csv profiles/${R}_rccl_1rank_log.txt
 cp $S/bench_train.json profiles/${R}_bench_train.json
 grep -E "time by family|  gemm " $S/bench_train_kernels.txt > profiles/${R}_bench_train_families.txt
