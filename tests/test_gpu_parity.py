@@ -1279,6 +1279,55 @@ def test_train_gemm_and_wgrad_vs_torch_fp64(M, K, N):
     assert torch.equal(dW, te.wgrad(dY, A))                                                           # fixed-order combine: deterministic
 
 
+@pytest.mark.parametrize('B,C,Cse', [(64, 40, 10), (3, 24, 6), (70, 144, 6), (64, 816, 34), (17, 1392, 58), (64, 2304, 96)])
+def test_se_train_kernels_vs_torch_fp64(B, C, Cse):
+    """The fused squeeze-excite kernels of the training step (cosy_se_train_forward / _backward: batched fp32-MFMA FCs, efficientnet.py:85-88
+    and its autograd) and the small Linear kernels (cosy_fc_small_*: models/pose.py:84) against float64 autograd on the same operands: every
+    MBConv shape class of EfficientNet-B3 incl. channel counts that are not multiples of 16, squeeze widths that are not multiples of 4 and
+    batches that are not multiples of the 16-sample tile; plus the on-the-fly forms (means / dots over swish(bn(raw)), gated BatchNorm apply,
+    BatchNorm backward with the incoming gradient formed inside)."""
+    from cosypose_amd import train_engine as te
+    g = torch.Generator(device='cuda').manual_seed(B * 1000 + C + Cse)
+    rn = lambda *sh: torch.randn(*sh, device='cuda', generator=g)
+    pooled, w1, b1, w2, b2, dgate = rn(B, C), rn(Cse, C, 1, 1) / C ** 0.5, rn(Cse), rn(C, Cse, 1, 1) / Cse ** 0.5, rn(C), rn(B, C)
+    h_pre, gate = te.se_forward(pooled, w1, b1, w2, b2)
+    P = [t.double().requires_grad_(True) for t in (pooled, w1, b1, w2, b2)]
+    hp = P[0] @ P[1].view(Cse, C).t() + P[2]
+    gt = torch.sigmoid((hp * torch.sigmoid(hp)) @ P[3].view(C, Cse).t() + P[4])
+    rel = lambda got, want: float((got.double() - want).abs().max() / max(float(want.abs().max()), 1e-30))
+    assert rel(h_pre, hp.detach()) < 2e-6 and rel(gate, gt.detach()) < 2e-6
+    gt.backward(dgate.double())
+    dpooled, dw1, db1, dw2, db2 = te.se_backward(dgate, gate, h_pre, pooled, w1, w2)
+    for name, got, want in (('dpooled', dpooled, P[0].grad), ('dw_reduce', dw1.view_as(w1), P[1].grad), ('db_reduce', db1, P[2].grad),
+                            ('dw_expand', dw2.view_as(w2), P[3].grad), ('db_expand', db2, P[4].grad)):
+        assert rel(got, want) < 5e-6, (name, rel(got, want))
+    assert all(torch.equal(a, b) for a, b in zip(te.se_backward(dgate, gate, h_pre, pooled, w1, w2), (dpooled, dw1, db1, dw2, db2)))   # deterministic
+    # Linear with few outputs (the pose head)
+    J = 9
+    x, w, bias, dy = rn(B, C), rn(J, C) / C ** 0.5, rn(J), rn(B, J)
+    y = te.fc_small_forward(x, w, bias)
+    assert rel(y, x.double() @ w.double().t() + bias.double()) < 2e-6
+    dx, dw, db = te.fc_small_backward(dy, x, w)
+    assert rel(dx, dy.double() @ w.double()) < 2e-6 and rel(dw, dy.double().t() @ x.double()) < 5e-6 and rel(db, dy.double().sum(0)) < 5e-6
+    # the on-the-fly squeeze-excite forms around BatchNorm 1 (HW pixels per sample)
+    HW = 12
+    raw, da2 = rn(B * HW, C), rn(B * HW, C)
+    mean, rstd, gamma, beta = rn(C) * 0.1, rn(C).abs() + 0.5, rn(C), rn(C) * 0.1
+    bn = lambda t: (t.double() - mean.double()) * rstd.double() * gamma.double() + beta.double()
+    a1 = bn(raw) * torch.sigmoid(bn(raw))
+    assert rel(te.rows_mean_bn(raw, mean, rstd, gamma, beta, B, HW, C), a1.view(B, HW, C).mean(1)) < 5e-6
+    assert rel(te.rows_dot_bn(da2, raw, mean, rstd, gamma, beta, B, HW, C), (da2.double() * a1).view(B, HW, C).sum(1)) < 5e-6
+    gate32 = torch.sigmoid(rn(B, C))
+    assert rel(te.bn_apply_gated(raw, mean, rstd, gamma, beta, B * HW, C, 1, gate32, HW), a1 * gate32.double().repeat_interleave(HW, 0)) < 5e-6
+    # BatchNorm backward with dout = da2 * gate + add / HW formed inside == the same call on the materialised tensor
+    add = rn(B, C)
+    da1 = te.rows_scale(da2, gate32, B, HW, C, add=add, add_scale=1.0 / HW)
+    ref = te.bn_backward(da1, raw, mean, rstd, gamma, beta, B * HW, C, 1)
+    got = te.bn_backward(da2, raw, mean, rstd, gamma, beta, B * HW, C, 1, HW=HW, cgate=gate32, cadd=add, cadd_scale=1.0 / HW)
+    for a, b in zip(got, ref):
+        assert rel(a, b.double()) < 2e-6
+
+
 def test_training_loop_checkpoint_and_resume(tmp_path, golden_sd):
     """the loop around the step (cosypose/training/train_pose.py:282-343): warm-up ramp + step decay applied to
     the optimizer, one reference-format checkpoint per epoch ({'state_dict', 'epoch'}, loadable strict=True into the
