@@ -357,7 +357,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    out = None
     for _ in range(args.warmup):
+        out = step()
+    if out is None:             # --warmup 0: the checks (and the engines' first-call set-up) still happen once, untimed
         out = step()
     assert torch.isfinite(out).all(), 'non-finite refined poses'
     assert out.shape == (total, 4, 4)
