@@ -27,8 +27,17 @@ def _i32(t, device):
     return ints_to_device(t, device)
 
 
-def crop_geometry(point_table, obj_ids, K, TCO, im_size, render_size, im_ids=None, lamb=1.4, z_min=0.1):
-    """-> boxes_rend (B,4), boxes_crop (B,4), K_crop (B,3,3).  K is (B,3,3), or (N,3,3) with im_ids (B,)."""
+def _dst(out, shape, dev):
+    """a caller-provided destination (contiguous fp32 tensor of `shape` on `dev`, e.g. the rows of a result tensor) or a fresh one"""
+    if out is None:
+        return torch.empty(*shape, device=dev)
+    assert tuple(out.shape) == tuple(shape) and out.dtype == torch.float32 and out.is_contiguous() and out.device == dev, (out.shape, shape)
+    return out
+
+
+def crop_geometry(point_table, obj_ids, K, TCO, im_size, render_size, im_ids=None, lamb=1.4, z_min=0.1, out=None):
+    """-> boxes_rend (B,4), boxes_crop (B,4), K_crop (B,3,3).  K is (B,3,3), or (N,3,3) with im_ids (B,).
+    out = (boxes_rend, boxes_crop, K_crop) destinations to write into (each may be None)."""
     require_device(point_table, K, TCO)
     TCO, K, point_table = _f32(TCO), _f32(K), _f32(point_table)
     dev = TCO.device
@@ -36,8 +45,8 @@ def crop_geometry(point_table, obj_ids, K, TCO, im_size, render_size, im_ids=Non
     B = TCO.shape[0]
     assert TCO.shape == (B, 4, 4) and obj_ids.shape == (B,)
     assert K.shape == ((im_ids is None and B or K.shape[0]), 3, 3)
-    boxes_rend = torch.empty(B, 4, device=dev); boxes_crop = torch.empty(B, 4, device=dev)
-    K_crop = torch.empty(B, 3, 3, device=dev)
+    o = out if out is not None else (None, None, None)
+    boxes_rend, boxes_crop, K_crop = _dst(o[0], (B, 4), dev), _dst(o[1], (B, 4), dev), _dst(o[2], (B, 3, 3), dev)
     check(lib().cosy_crop_geometry(ptr(point_table), ptr(obj_ids), ptr(K), ptr(im_ids), ptr(TCO), B, point_table.shape[1],
                                    z_min, int(im_size[0]), int(im_size[1]), int(render_size[0]), int(render_size[1]),
                                    lamb, ptr(boxes_rend), ptr(boxes_crop), ptr(K_crop), stream()))
@@ -60,11 +69,11 @@ def roi_align(images, boxes, output_size, sampling_ratio=4, im_ids=None):
     return out
 
 
-def update_pose(TCO, K_crop, pose_outputs):
+def update_pose(TCO, K_crop, pose_outputs, out=None):
     require_device(TCO, K_crop, pose_outputs)
     TCO, K_crop, pose_outputs = _f32(TCO), _f32(K_crop), _f32(pose_outputs)
     assert pose_outputs.shape[-1] == 9
-    out = torch.empty_like(TCO)
+    out = _dst(out, TCO.shape, TCO.device)
     check(lib().cosy_pose_update(ptr(TCO), ptr(K_crop), ptr(pose_outputs), TCO.shape[0], ptr(out), stream()))
     return out
 

@@ -45,14 +45,14 @@ class PosePredictor(nn.Module):
         self.debug = False
 
     # ---- pieces of the loop, reference signatures -------------------------------------------
-    def _geometry(self, K, TCO, labels, im_size, im_ids=None):
+    def _geometry(self, K, TCO, labels, im_size, im_ids=None, out=None):
         if self.pose_dim != 9:
             raise ValueError(f'pose_dim={self.pose_dim} not supported')
         table = self.mesh_db.point_table(2000)
         if table.device != TCO.device:
             raise CosyHipError(f'mesh_db lives on {table.device} but poses on {TCO.device}; call mesh_db.cuda()')
         obj_ids = labels if torch.is_tensor(labels) else self.mesh_db.object_ids(labels, TCO.device)
-        return lib3d.crop_geometry(table, obj_ids, K, TCO, im_size, self.render_size, im_ids=im_ids, lamb=1.4)
+        return lib3d.crop_geometry(table, obj_ids, K, TCO, im_size, self.render_size, im_ids=im_ids, lamb=1.4, out=out)
 
     def crop_inputs(self, images, K, TCO, labels):
         bsz, nchannels, h, w = images.shape
@@ -91,7 +91,10 @@ class PosePredictor(nn.Module):
         return outputs
 
     # ---- the loop ----------------------------------------------------------------------------
-    def forward(self, images, K, labels, TCO, n_iterations=1, im_ids=None):
+    def forward(self, images, K, labels, TCO, n_iterations=1, im_ids=None, out=None):
+        """(reference: models/pose.py:89-132.)  `out` (an extension, inference only): {iteration number: {'TCO_output' | 'K_crop' | 'boxes_rend' |
+        'boxes_crop': destination tensor}} -- the geometry and pose-update kernels then write those outputs straight into the given
+        (contiguous fp32) tensors, e.g. this chunk's rows of a batch-wide result, instead of fresh ones that have to be copied."""
         require_device(images, K, TCO)
         if self.pose_dim != 9:
             raise ValueError(f'pose_dim={self.pose_dim} not supported')
@@ -119,7 +122,9 @@ class PosePredictor(nn.Module):
         TCO_input = TCO
         for n in range(n_iterations):
             TCO_input = TCO_input.detach().float().contiguous()
-            boxes_rend, boxes_crop, K_crop = self._geometry(K, TCO_input, obj_ids, (h, w), im_ids=im_ids)
+            dst = (out or {}).get(n + 1, {})
+            boxes_rend, boxes_crop, K_crop = self._geometry(K, TCO_input, obj_ids, (h, w), im_ids=im_ids,
+                                                            out=(dst.get('boxes_rend'), dst.get('boxes_crop'), dst.get('K_crop')))
             # a renderer of this library renders straight into the network input (cosy_render_crop_pack): no (B,3,H,W) fp32
             # render tensor exists; any other renderer keeps the reference's interface (renderer.render -> images)
             fused = hasattr(self.renderer, 'render_crop_pack') and not self.debug
@@ -150,7 +155,7 @@ class PosePredictor(nn.Module):
                 pose = torch.empty(bsz, self.pose_dim, device=dev)
                 check(lib().cosy_effnet_b3_forward(net, bsz, None, ptr(pose), None, stream()))
             model_outputs = dict(pose=pose)
-            TCO_output = lib3d.update_pose(TCO_input, K_crop, pose.detach())
+            TCO_output = lib3d.update_pose(TCO_input, K_crop, pose.detach(), out=dst.get('TCO_output'))
 
             outputs[f'iteration={n+1}'] = {
                 'TCO_input': TCO_input,

@@ -79,7 +79,16 @@ class CoarseRefinePosePredictor(torch.nn.Module):
         lanes = self._lane_streams(device, min(int(self.n_streams), len(firsts)))
         main = torch.cuda.current_stream(device)
         keys = [f'{name}/{_iteration_key(n)}' for name, _, n_it in stages for n in range(1, n_it + 1)]
-        full = {key: {name: torch.empty((n_objects,) + shape, device=device) for name, shape in _ITERATION_SHAPES} for key in keys}
+        # Every chunk's kernels write their outputs STRAIGHT into the chunk's rows of the batch-wide result tensors (PosePredictor.forward
+        # `out=`): no per-field copy launches on the lanes (5 fields x 5 iterations x 2 chunks of ~4 us each broke up every chunk's kernel
+        # chain).  An iteration's input poses ARE the previous iteration's outputs (or the initial poses): `poses_input` shares that tensor,
+        # as the sequential path's collections do.
+        made = {key: {name: torch.empty((n_objects,) + shape, device=device) for name, shape in _ITERATION_SHAPES if name != 'poses_input'}
+                for key in keys}
+        full, prev = {}, start.poses
+        for key in keys:
+            full[key] = dict(made[key], poses_input=prev)
+            prev = made[key]['poses']
         # the chunks are cut on `main` BEFORE the lanes wait for it, and must be views: a gather enqueued on `main` behind the wait
         # would be read by a lane unsynchronised
         chunks = [start[np.arange(first, min(first + self.bsz_objects, n_objects))] for first in firsts]
@@ -87,17 +96,17 @@ class CoarseRefinePosePredictor(torch.nn.Module):
         assert all(c.poses.untyped_storage().data_ptr() == base for c in chunks), 'chunks of consecutive rows must be tensor views'
         for lane in lanes:
             lane.wait_stream(main)             # frames, K, the initial poses and the result buffers are ready on `main`
+        _OUT = (('TCO_output', 'poses'), ('K_crop', 'K_crop'), ('boxes_rend', 'boxes_rend'), ('boxes_crop', 'boxes_crop'))
         for i, (first, chunk) in enumerate(zip(firsts, chunks)):
             last = min(first + self.bsz_objects, n_objects)
             labels, im_ids = chunk.infos['label'].values, chunk.infos['batch_im_id'].values
             with torch.cuda.stream(lanes[i % len(lanes)]):
                 poses = chunk.poses
                 for name, model, n_it in stages:
-                    outputs = model(images=images, K=K, TCO=poses, n_iterations=n_it, labels=labels, im_ids=im_ids)
-                    for n in range(1, n_it + 1):
-                        out_n, rows = outputs[_iteration_key(n)], full[f'{name}/{_iteration_key(n)}']
-                        for field, source in _ITERATION_FIELDS:
-                            rows[field][first:last].copy_(out_n[source])
+                    dst = {n: {src: full[f'{name}/{_iteration_key(n)}'][field][first:last] for src, field in _OUT} for n in range(1, n_it + 1)}
+                    outputs = model(images=images, K=K, TCO=poses, n_iterations=n_it, labels=labels, im_ids=im_ids, out=dst)
+                    for n in range(1, n_it + 1):       # the model wrote into the rows it was given
+                        assert outputs[_iteration_key(n)]['TCO_output'].data_ptr() == dst[n]['TCO_output'].data_ptr()
                     poses = outputs[_iteration_key(n_it)]['TCO_output']
         for lane in lanes:
             main.wait_stream(lane)
