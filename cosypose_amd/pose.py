@@ -91,10 +91,22 @@ class PosePredictor(nn.Module):
         return outputs
 
     # ---- the loop ----------------------------------------------------------------------------
-    def forward(self, images, K, labels, TCO, n_iterations=1, im_ids=None, out=None):
+    @staticmethod
+    def frames_to_nhwc4(images):
+        """(N,3,h,w) float frames -> the interleaved (N,h,w,4) fp32 copy the crop kernels read (one 16-byte load per pixel).  forward() makes
+        it per call; a driver that calls several models / chunks on the same frames makes it once and hands it over (`frames_nhwc4=`)."""
+        require_device(images)
+        images = images.detach().float().contiguous()
+        n_im, _, h, w = images.shape
+        frames4 = torch.empty(n_im, h, w, 4, device=images.device, dtype=torch.float32)
+        check(lib().cosy_frames_to_nhwc4(ptr(images), ptr(frames4), n_im, h, w, stream()))
+        return frames4
+
+    def forward(self, images, K, labels, TCO, n_iterations=1, im_ids=None, out=None, frames_nhwc4=None):
         """(reference: models/pose.py:89-132.)  `out` (an extension, inference only): {iteration number: {'TCO_output' | 'K_crop' | 'boxes_rend' |
         'boxes_crop': destination tensor}} -- the geometry and pose-update kernels then write those outputs straight into the given
-        (contiguous fp32) tensors, e.g. this chunk's rows of a batch-wide result, instead of fresh ones that have to be copied."""
+        (contiguous fp32) tensors, e.g. this chunk's rows of a batch-wide result, instead of fresh ones that have to be copied;
+        `frames_nhwc4`: the result of frames_to_nhwc4(images) when the caller already has it."""
         require_device(images, K, TCO)
         if self.pose_dim != 9:
             raise ValueError(f'pose_dim={self.pose_dim} not supported')
@@ -111,8 +123,11 @@ class PosePredictor(nn.Module):
         K = K.detach().float().contiguous()
         dev = TCO.device
         # frames -> interleaved (N,h,w,4) once per call: the crop kernel then fetches a pixel's RGB with one 16-byte load
-        frames4 = torch.empty(n_im, h, w, 4, device=dev, dtype=torch.float32)
-        check(lib().cosy_frames_to_nhwc4(ptr(images), ptr(frames4), n_im, h, w, stream()))
+        if frames_nhwc4 is None:
+            frames4 = self.frames_to_nhwc4(images)
+        else:
+            frames4 = frames_nhwc4
+            assert frames4.shape == (n_im, h, w, 4) and frames4.dtype == torch.float32 and frames4.is_contiguous() and frames4.device == dev
         obj_ids = self.mesh_db.object_ids(labels, dev)
         train = self.training and torch.is_grad_enabled()
         net = None if train else self._net(bsz, dev)

@@ -53,15 +53,26 @@ class CoarseRefinePosePredictor(torch.nn.Module):
             lanes.append(torch.cuda.Stream(device=device))
         return lanes[:n]
 
+    @staticmethod
+    def _frames4(model, images):
+        """the frames' interleaved copy, made ONCE per call for every model / chunk that crops from them (models without the hook: None)"""
+        make = getattr(model, 'frames_to_nhwc4', None)
+        return make(images) if make is not None and images.is_cuda else None
+
     @torch.no_grad()
-    def batched_model_predictions(self, model, images, K, obj_data, n_iterations=1):
+    def batched_model_predictions(self, model, images, K, obj_data, n_iterations=1, frames_nhwc4=None):
         """Run `model` over obj_data (infos[label, batch_im_id], poses) chunk by chunk -> {'iteration=k': collection}."""
         per_iteration = {_iteration_key(n): [] for n in range(1, n_iterations + 1)}
         n_objects = len(obj_data)
+        extra = {}
+        if n_objects > self.bsz_objects or frames_nhwc4 is not None:      # several chunks share one conversion of the frames
+            f4 = frames_nhwc4 if frames_nhwc4 is not None else self._frames4(model, images)
+            if f4 is not None:
+                extra = dict(frames_nhwc4=f4)
         for first in range(0, n_objects, self.bsz_objects):
             chunk = obj_data[np.arange(first, min(first + self.bsz_objects, n_objects))]
             outputs = model(images=images, K=K, TCO=chunk.poses, n_iterations=n_iterations,
-                            labels=chunk.infos['label'].values, im_ids=chunk.infos['batch_im_id'].values)
+                            labels=chunk.infos['label'].values, im_ids=chunk.infos['batch_im_id'].values, **extra)
             for key, collected in per_iteration.items():
                 collected.append(_iteration_collection(chunk.infos, outputs[key]))
         return {key: tc.concatenate(parts) for key, parts in per_iteration.items()}
@@ -94,6 +105,8 @@ class CoarseRefinePosePredictor(torch.nn.Module):
         chunks = [start[np.arange(first, min(first + self.bsz_objects, n_objects))] for first in firsts]
         base = start.poses.untyped_storage().data_ptr()
         assert all(c.poses.untyped_storage().data_ptr() == base for c in chunks), 'chunks of consecutive rows must be tensor views'
+        frames4 = self._frames4(stages[0][1], images) if stages else None      # on `main`, once for every chunk and both models
+        extra = dict(frames_nhwc4=frames4) if frames4 is not None else {}
         for lane in lanes:
             lane.wait_stream(main)             # frames, K, the initial poses and the result buffers are ready on `main`
         _OUT = (('TCO_output', 'poses'), ('K_crop', 'K_crop'), ('boxes_rend', 'boxes_rend'), ('boxes_crop', 'boxes_crop'))
@@ -104,7 +117,7 @@ class CoarseRefinePosePredictor(torch.nn.Module):
                 poses = chunk.poses
                 for name, model, n_it in stages:
                     dst = {n: {src: full[f'{name}/{_iteration_key(n)}'][field][first:last] for src, field in _OUT} for n in range(1, n_it + 1)}
-                    outputs = model(images=images, K=K, TCO=poses, n_iterations=n_it, labels=labels, im_ids=im_ids, out=dst)
+                    outputs = model(images=images, K=K, TCO=poses, n_iterations=n_it, labels=labels, im_ids=im_ids, out=dst, **extra)
                     for n in range(1, n_it + 1):       # the model wrote into the rows it was given
                         assert outputs[_iteration_key(n)]['TCO_output'].data_ptr() == dst[n]['TCO_output'].data_ptr()
                     poses = outputs[_iteration_key(n_it)]['TCO_output']
@@ -144,8 +157,12 @@ class CoarseRefinePosePredictor(torch.nn.Module):
             preds.update(self._concurrent_predictions(images, K, start, stages))
             return (preds[f'{stages[-1][0]}/{_iteration_key(stages[-1][2])}'] if stages else start), preds
 
+        shared = {}
+
         def run_stage(stage, model, start, n_iterations):
-            out = self.batched_model_predictions(model, images, K, start, n_iterations=n_iterations)
+            if 'f4' not in shared:                 # one conversion of the frames for the coarse and the refiner model and all their chunks
+                shared['f4'] = self._frames4(model, images)
+            out = self.batched_model_predictions(model, images, K, start, n_iterations=n_iterations, frames_nhwc4=shared['f4'])
             for n in range(1, n_iterations + 1):
                 preds[f'{stage}/{_iteration_key(n)}'] = out[_iteration_key(n)]
             return out[_iteration_key(n_iterations)]
