@@ -28,6 +28,7 @@ _SIGNATURES = {
     'cosy_effnet_b3_set_profiling': ([_P, _I], _I),
     'cosy_effnet_b3_profile_read': ([_P, _P, _I, _c.POINTER(_I)], _I),
     'cosy_frames_to_nhwc4': ([_P, _P, _I, _I, _I, _P], _I),
+    'cosy_frames_u8_to_nhwc4': ([_P, _P, _I, _I, _I, _P], _I),
     'cosy_crop_pack': ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     'cosy_effnet_b3_forward': ([_P, _I, _P, _P, _P, _P], _I),
     'cosy_crop_geometry': ([_P, _P, _P, _P, _P, _I, _I, _F, _I, _I, _I, _I, _F, _P, _P, _P, _P], _I),
@@ -54,6 +55,7 @@ _SIGNATURES = {
     'cosy_bn_train_backward_gated': ([_P, _P, _P, _F, _P, _P, _P, _P, _P, _L, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P], _I),
     'cosy_dw_train_forward': ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _P], _I),
     'cosy_dw_train_backward_data': ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _P], _I),
+    'cosy_dw_train_backward_data_add': ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P], _I),
     'cosy_dw_train_backward_weight': ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P], _I),
     'cosy_wgrad_tall_supported': ([_L, _I, _I], _I),
     'cosy_wgrad_tall': ([_P, _P, _L, _I, _I, _P, _P, _P], _I),

@@ -77,6 +77,7 @@ int launch_tco_init_zup(const float* boxes, const float* pts_table, const int* o
 int launch_scatter_argmin(const float* dists, const int* ids, int M, int n_seg, int* out, hipStream_t s);
 // crop + render pack into the NHWC8 network input (T = float or bf16_t), see kernels_geom.hip
 int launch_frames_to_nhwc4(const float* images, float* out, int N, int h, int w, hipStream_t s);
+int launch_frames_u8_to_nhwc4(const unsigned char* images, float* out, int N, int h, int w, hipStream_t s);
 int launch_crop_pack(void* x_nhwc8, int dtype, const float* frames_nhwc4, const int* im_id, const float* boxes,
                      const float* renders, int B, int N, int h, int w, int H, int W, void* taps_ws, hipStream_t s);
 size_t crop_taps_bytes(int B, int H, int W);    // scratch of the per-crop roi_align tap tables (taps_ws above; may be null)

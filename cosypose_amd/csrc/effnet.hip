@@ -677,6 +677,10 @@ int cosy_effnet_b3_set_input_nchw(cosy_net_t* n, const float* x, int B, cosy_str
     return launch_pack_nchw(n->X, n->dtype, x, B, n->H, n->W, (hipStream_t)stream);
 }
 
+int cosy_frames_u8_to_nhwc4(const unsigned char* images, float* out, int N, int h, int w, cosy_stream_t stream) {
+    COSY_REQUIRE(images && out, "frames_u8_to_nhwc4: null argument");
+    return launch_frames_u8_to_nhwc4(images, out, N, h, w, (hipStream_t)stream);
+}
 int cosy_frames_to_nhwc4(const float* images, float* out, int N, int h, int w, cosy_stream_t stream) {
     COSY_REQUIRE(images && out, "frames_to_nhwc4: null argument");
     return launch_frames_to_nhwc4(images, out, N, h, w, (hipStream_t)stream);

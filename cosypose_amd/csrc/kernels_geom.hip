@@ -202,6 +202,20 @@ __global__ __launch_bounds__(256) void frames_to_nhwc4_kernel(const float* __res
     const float* s = src + (size_t)n * 3 * hw + i;
     ((f32x4*)dst)[(size_t)n * hw + i] = f32x4{s[0], s[hw], s[2 * (size_t)hw], 0.f};
 }
+// the same from uint8 frames (what the datasets deliver): value / 255.f, the arithmetic of the reference's `images.float() / 255.`
+// (training/pose_forward_loss.py:24) without the two fp32 passes over the frames
+__global__ __launch_bounds__(256) void frames_u8_to_nhwc4_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, int hw) {
+    const int n = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= hw) return;
+    const unsigned char* s = src + (size_t)n * 3 * hw + i;
+    ((f32x4*)dst)[(size_t)n * hw + i] = f32x4{(float)s[0] / 255.f, (float)s[hw] / 255.f, (float)s[2 * (size_t)hw] / 255.f, 0.f};
+}
+int launch_frames_u8_to_nhwc4(const unsigned char* images, float* out, int N, int h, int w, hipStream_t s) {
+    if (N == 0) return COSY_OK;
+    hipLaunchKernelGGL(frames_u8_to_nhwc4_kernel, dim3(cdiv(h * w, 256), N), dim3(256), 0, s, images, out, h * w);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
 int launch_frames_to_nhwc4(const float* images, float* out, int N, int h, int w, hipStream_t s) {
     if (N == 0) return COSY_OK;
     hipLaunchKernelGGL(frames_to_nhwc4_kernel, dim3(cdiv(h * w, 256), N), dim3(256), 0, s, images, out, h * w);

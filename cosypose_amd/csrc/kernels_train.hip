@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // stride 1 that is lo again).  Sums run in a fixed order (kx outer, rows inner): deterministic.
 template <int K, int S, bool FLIP>
 __global__ __launch_bounds__(256) void dw_rows_kernel(const float* __restrict__ x, const float* __restrict__ wt, int H, int W, int Ho, int Wo, int C4,
-                                                      long n, float* __restrict__ out) {
+                                                      long n, float* __restrict__ out, const float* __restrict__ add = nullptr) {
     static_assert(!FLIP || S == 1, "the data-gradient form is stride 1 only");
     constexpr int R = 4, LO = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -265,7 +265,11 @@ __global__ __launch_bounds__(256) void dw_rows_kernel(const float* __restrict__ 
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        if (oy0 + r < Ho) ((f32x4*)out)[(((size_t)b * Ho + oy0 + r) * Wo + ox) * C4 + c4] = acc[r];
+        if (oy0 + r < Ho) {
+            const size_t o = (((size_t)b * Ho + oy0 + r) * Wo + ox) * C4 + c4;
+            // add: the skip connection's gradient of a block without expansion (dx = conv-transpose(dy) + dout) rides on the store
+            ((f32x4*)out)[o] = add ? acc[r] + ((const f32x4*)add)[o] : acc[r];
+        }
 }
 __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ wt, int H, int W, int C4,
                                                           int Ho, int Wo, int k, int s, int lo, long n4, float* __restrict__ dx) {
@@ -1245,16 +1249,21 @@ int cosy_dw_train_forward(const float* x, const float* wt, int B, int H, int W, 
 
 int cosy_dw_train_backward_data(const float* dy, const float* wt, int B, int H, int W, int C, int k, int stride, float* dx,
                                 cosy_stream_t stream) {
+    return cosy_dw_train_backward_data_add(dy, wt, nullptr, B, H, W, C, k, stride, dx, stream);
+}
+int cosy_dw_train_backward_data_add(const float* dy, const float* wt, const float* add, int B, int H, int W, int C, int k, int stride, float* dx,
+                                    cosy_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     COSY_REQUIRE(dy && wt && dx && C % 4 == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2), "dw_train_backward_data: bad argument");
+    COSY_REQUIRE(!add || stride == 1, "dw_train_backward_data: the fused skip gradient exists for stride 1 (blocks with a skip connection)%s", "");
     const int lo = stride == 1 ? (k - 1) / 2 : (k - 2) / 2;
     const int Ho = stride == 1 ? H : (H + (k - 2) - k) / 2 + 1, Wo = stride == 1 ? W : (W + (k - 2) - k) / 2 + 1;
     const long n4 = (long)B * H * W * (C / 4);
     if (n4 == 0) return COSY_OK;
     if (stride == 1) {
         const long n = (long)B * cdiv(H, 4) * W * (C / 4);
-        if (k == 3) LAUNCH1D((dw_rows_kernel<3, 1, true>), n, s, dy, wt, H, W, H, W, C / 4, n, dx);
-        else LAUNCH1D((dw_rows_kernel<5, 1, true>), n, s, dy, wt, H, W, H, W, C / 4, n, dx);
+        if (k == 3) LAUNCH1D((dw_rows_kernel<3, 1, true>), n, s, dy, wt, H, W, H, W, C / 4, n, dx, add);
+        else LAUNCH1D((dw_rows_kernel<5, 1, true>), n, s, dy, wt, H, W, H, W, C / 4, n, dx, add);
         return COSY_OK;
     }
     LAUNCH1D(dw_bwd_data_kernel, n4, s, dy, wt, H, W, C / 4, Ho, Wo, k, stride, lo, n4, dx);

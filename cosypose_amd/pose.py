@@ -96,10 +96,14 @@ class PosePredictor(nn.Module):
         """(N,3,h,w) float frames -> the interleaved (N,h,w,4) fp32 copy the crop kernels read (one 16-byte load per pixel).  forward() makes
         it per call; a driver that calls several models / chunks on the same frames makes it once and hands it over (`frames_nhwc4=`)."""
         require_device(images)
-        images = images.detach().float().contiguous()
         n_im, _, h, w = images.shape
         frames4 = torch.empty(n_im, h, w, 4, device=images.device, dtype=torch.float32)
-        check(lib().cosy_frames_to_nhwc4(ptr(images), ptr(frames4), n_im, h, w, stream()))
+        if images.dtype == torch.uint8:          # the datasets' frames: value / 255.f inside the kernel (== images.float() / 255.)
+            images = images.detach().contiguous()
+            check(lib().cosy_frames_u8_to_nhwc4(ptr(images), ptr(frames4), n_im, h, w, stream()))
+        else:
+            images = images.detach().float().contiguous()
+            check(lib().cosy_frames_to_nhwc4(ptr(images), ptr(frames4), n_im, h, w, stream()))
         return frames4
 
     def forward(self, images, K, labels, TCO, n_iterations=1, im_ids=None, out=None, frames_nhwc4=None):
@@ -119,7 +123,8 @@ class PosePredictor(nn.Module):
         else:
             assert K.shape == (n_im, 3, 3) and len(im_ids) == bsz
             im_ids = ints_to_device(im_ids, TCO.device)
-        images = images.detach().float().contiguous()
+        if images.dtype != torch.uint8:          # uint8 frames (an extension: the training batches) are scaled by 1/255 inside the frame conversion
+            images = images.detach().float().contiguous()
         K = K.detach().float().contiguous()
         dev = TCO.device
         # frames -> interleaved (N,h,w,4) once per call: the crop kernel then fetches a pixel's RGB with one 16-byte load
@@ -184,6 +189,7 @@ class PosePredictor(nn.Module):
 
             if self.debug:
                 self.tmp_debug.update(outputs[f'iteration={n+1}'])
-                self.tmp_debug.update(images=images, renders=renders,
-                                      images_crop=lib3d.roi_align(images, boxes_crop, self.render_size, 4, im_ids=im_ids))
+                images_f = images.float() / 255. if images.dtype == torch.uint8 else images
+                self.tmp_debug.update(images=images_f, renders=renders,
+                                      images_crop=lib3d.roi_align(images_f, boxes_crop, self.render_size, 4, im_ids=im_ids))
         return outputs

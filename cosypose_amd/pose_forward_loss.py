@@ -55,7 +55,11 @@ def h_pose(model, mesh_db, data, meters, cfg, n_iterations=1, input_generator='f
     if not (cfg.loss_disentangled and cfg.n_pose_dims == 9):
         raise ValueError('only the disentangled loss on 9-d pose outputs is built (cfg.loss_disentangled, n_pose_dims=9)')
     # batch -> device (uint8 frames to [0,1] floats as in the reference)
-    images = cast(data.images).float() / 255.
+    # the reference: images = cast(data.images).float() / 255. (pose_forward_loss.py:24).  uint8 frames go to the model as they are: its frame
+    # conversion kernel computes value / 255.f itself (the same arithmetic, without two fp32 passes over 59 MB of frames)
+    images = cast(data.images)
+    if images.dtype != torch.uint8:
+        images = images.float() / 255.
     K, TCO_gt, bboxes = cast(data.K).float(), cast(data.TCO).float(), cast(data.bboxes).float()
     labels = np.array([obj['name'] for obj in data.objects])
 

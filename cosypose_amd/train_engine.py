@@ -78,9 +78,10 @@ def dw_forward(x, wt, B, H, W, C, k, s):
     return out
 
 
-def dw_backward(x, dy, wt, B, H, W, C, k, s):
+def dw_backward(x, dy, wt, B, H, W, C, k, s, add=None):
+    """-> (dx (+ add: the skip connection's gradient of a block without expansion, fused into the store), dwt (k*k, C))"""
     dx = torch.empty(B * H * W, C, device=x.device)
-    check(lib().cosy_dw_train_backward_data(ptr(dy), ptr(wt), B, H, W, C, k, s, ptr(dx), stream()))
+    check(lib().cosy_dw_train_backward_data_add(ptr(dy), ptr(wt), ptr(add), B, H, W, C, k, s, ptr(dx), stream()))
     dwt = torch.empty(k * k, C, device=x.device)
     check(lib().cosy_dw_train_backward_weight(ptr(x), ptr(dy), B, H, W, C, k, s, ptr(dwt), ptr(_workspace(x.device)), stream()))
     return dx, dwt
@@ -358,7 +359,7 @@ class _Net:
             grads[p + '_se_expand.weight'], grads[p + '_se_expand.bias'] = dw2.view_as(w2), db2
             # da1 = da2 * g + dpooled / HW (gradient through the gate multiply and the pooled mean) is formed inside BatchNorm 1's backward kernels
             draw = self._bn_b(tape, grads, p + '_bn1', da2, cgate=g, cadd=dpooled, cadd_scale=1.0 / HWo, HWg=HWo)
-            da0, dwt = dw_backward(a0, draw, wt, B, H, W, cmid, k, s)
+            da0, dwt = dw_backward(a0, draw, wt, B, H, W, cmid, k, s, add=dout if (e == 1 and skip) else None)
             if staged:
                 D(p + '_depthwise_conv.weight').view(cmid, k * k).copy_(dwt.t())
             else:
@@ -370,7 +371,7 @@ class _Net:
                 # the skip connection's gradient rides on the GEMM (C = dout + draw W) instead of a separate add
                 dx = gemm(draw, we.view(cmid, cin), w_is_kn=True, add=dout if skip else None)
             else:
-                dx = da0 + dout if skip else da0
+                dx = da0             # (+ dout for a skip block: already added inside dw_backward)
         draw = self._bn_b(tape, grads, 'backbone._bn0', dx)
         cols = tape['stem']
         gstem = wgrad(draw, cols)[:, :54].reshape(arch.STEM_C, 3, 3, 6).permute(0, 3, 1, 2)

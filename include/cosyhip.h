@@ -68,6 +68,8 @@ int cosy_effnet_b3_set_input_nchw(cosy_net_t* net, const float* x, int B, cosy_s
 /* Frames (N,3,h,w) fp32 planar -> (N,h,w,4) fp32 interleaved (RGB + pad), the layout cosy_crop_pack samples from.
  * Done once per PosePredictor.forward call (the frames do not change across iterations); out holds N*h*w*4 floats. */
 int cosy_frames_to_nhwc4(const float* images, float* out, int N, int h, int w, cosy_stream_t stream);
+/* the same from uint8 frames (N,3,h,w) as the datasets deliver them: out = value / 255.f (training/pose_forward_loss.py:24: images.float() / 255.) */
+int cosy_frames_u8_to_nhwc4(const unsigned char* images, float* out, int N, int h, int w, cosy_stream_t stream);
 
 /* Fused replacement of deepim_crops_robust's roi_align (cosypose/lib3d/cropping.py:73-74,
  * torchvision 0.4.2 semantics, sampling_ratio=4) + torch.cat with the renders (pose.py:104):
@@ -218,6 +220,9 @@ int cosy_dw_train_forward(const float* x, const float* wt, int B, int H, int W, 
                           cosy_stream_t stream);
 int cosy_dw_train_backward_data(const float* dy, const float* wt, int B, int H, int W, int C, int k, int stride, float* dx,
                                 cosy_stream_t stream);
+/* ... + add (B,H,W,C): dx = conv-transpose(dy) + add in one pass (stride 1): the skip connection's gradient of an MBConv block without expansion */
+int cosy_dw_train_backward_data_add(const float* dy, const float* wt, const float* add, int B, int H, int W, int C, int k, int stride, float* dx,
+                                    cosy_stream_t stream);
 int cosy_dw_train_backward_weight(const float* x, const float* dy, int B, int H, int W, int C, int k, int stride, float* dwt,
                                   void* workspace, cosy_stream_t stream);
 /* 1x1 convolutions of the training step on the library's own fp32 MFMA GEMMs (no rocBLAS on the path):
