@@ -57,6 +57,7 @@ _SIGNATURES = {
     'cosy_dw_train_backward_data': ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _P], _I),
     'cosy_dw_train_backward_data_add': ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P], _I),
     'cosy_dw_train_backward_weight': ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P], _I),
+    'cosy_dw_train_backward_weight_ex': ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P], _I),
     'cosy_wgrad_tall_supported': ([_L, _I, _I], _I),
     'cosy_wgrad_tall': ([_P, _P, _L, _I, _I, _P, _P, _P], _I),
     'cosy_wgrad': ([_P, _P, _L, _I, _I, _P, _P, _P], _I),

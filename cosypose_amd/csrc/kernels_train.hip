@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void wgrad_tall_kernel(const float* __restrict
 // out[j] = sum over slabs of partial[slab*n + j]; lanes = 64 consecutive j, 16 waves stride over the slabs
 template <typename PT>
 __global__ __launch_bounds__(1024) void combine_partials_kernel(const PT* __restrict__ partial, int nslab, long n, double* __restrict__ out_d,
-                                                                float* __restrict__ out_f) {
+                                                                float* __restrict__ out_f, int tC = 0) {
     __shared__ double lds[16 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long j = (long)blockIdx.x * 64 + lane;
@@ -458,7 +458,9 @@ __global__ __launch_bounds__(1024) void combine_partials_kernel(const PT* __rest
 #pragma unroll
         for (int w = 0; w < 16; ++w) t += lds[w * 64 + lane];
         if (out_d) out_d[j] = t;
-        if (out_f) out_f[j] = (float)t;
+        // tC > 0: the n values are a (n / tC, tC) matrix that is written transposed, (tC, n / tC) -- the depthwise weight gradient [tap][channel] straight
+        // into the module's (C, 1, k, k) layout
+        if (out_f) out_f[tC > 0 ? (j % tC) * (n / tC) + j / tC : j] = (float)t;
     }
 }
 // BatchNorm: the combine of the per-slab partials and the per-channel finish in ONE launch (they were two: a tiny dependent
@@ -1272,7 +1274,12 @@ int cosy_dw_train_backward_data_add(const float* dy, const float* wt, const floa
 
 int cosy_dw_train_backward_weight(const float* x, const float* dy, int B, int H, int W, int C, int k, int stride, float* dwt,
                                   void* workspace, cosy_stream_t stream) {
+    return cosy_dw_train_backward_weight_ex(x, dy, B, H, W, C, k, stride, dwt, 0, workspace, stream);
+}
+int cosy_dw_train_backward_weight_ex(const float* x, const float* dy, int B, int H, int W, int C, int k, int stride, float* dw, int module_layout,
+                                     void* workspace, cosy_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
+    float* dwt = dw;
     COSY_REQUIRE(x && dy && dwt && workspace && (k == 3 || k == 5) && (stride == 1 || stride == 2), "dw_train_backward_weight: bad argument");
     const int lo = stride == 1 ? (k - 1) / 2 : (k - 2) / 2;
     const int Ho = stride == 1 ? H : (H + (k - 2) - k) / 2 + 1, Wo = stride == 1 ? W : (W + (k - 2) - k) / 2 + 1;
@@ -1290,7 +1297,7 @@ int cosy_dw_train_backward_weight(const float* x, const float* dy, int B, int H,
 #undef DW_BW
     COSY_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(combine_partials_kernel<double>, dim3(cdiv((long)k * k * C, 64)), dim3(1024), 0, s, (const double*)workspace, g.nslab,
-                       (long)k * k * C, (double*)nullptr, dwt);
+                       (long)k * k * C, (double*)nullptr, dwt, module_layout ? C : 0);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }

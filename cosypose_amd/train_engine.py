@@ -78,13 +78,15 @@ def dw_forward(x, wt, B, H, W, C, k, s):
     return out
 
 
-def dw_backward(x, dy, wt, B, H, W, C, k, s, add=None):
-    """-> (dx (+ add: the skip connection's gradient of a block without expansion, fused into the store), dwt (k*k, C))"""
+def dw_backward(x, dy, wt, B, H, W, C, k, s, add=None, out=None):
+    """-> (dx (+ add: the skip connection's gradient of a block without expansion, fused into the store), dw (C,1,k,k))"""
     dx = torch.empty(B * H * W, C, device=x.device)
     check(lib().cosy_dw_train_backward_data_add(ptr(dy), ptr(wt), ptr(add), B, H, W, C, k, s, ptr(dx), stream()))
-    dwt = torch.empty(k * k, C, device=x.device)
-    check(lib().cosy_dw_train_backward_weight(ptr(x), ptr(dy), B, H, W, C, k, s, ptr(dwt), ptr(_workspace(x.device)), stream()))
-    return dx, dwt
+    # the weight gradient lands in the module's (C, 1, k, k) layout -- in `out` (e.g. the parameter's slice of a flat gradient buffer) when given
+    dw = out if out is not None else torch.empty(C, 1, k, k, device=x.device)
+    assert dw.numel() == C * k * k and dw.is_contiguous()
+    check(lib().cosy_dw_train_backward_weight_ex(ptr(x), ptr(dy), B, H, W, C, k, s, ptr(dw), 1, ptr(_workspace(x.device)), stream()))
+    return dx, dw
 
 
 def rows_mean(a, B, HW, C):
@@ -359,11 +361,8 @@ class _Net:
             grads[p + '_se_expand.weight'], grads[p + '_se_expand.bias'] = dw2.view_as(w2), db2
             # da1 = da2 * g + dpooled / HW (gradient through the gate multiply and the pooled mean) is formed inside BatchNorm 1's backward kernels
             draw = self._bn_b(tape, grads, p + '_bn1', da2, cgate=g, cadd=dpooled, cadd_scale=1.0 / HWo, HWg=HWo)
-            da0, dwt = dw_backward(a0, draw, wt, B, H, W, cmid, k, s, add=dout if (e == 1 and skip) else None)
-            if staged:
-                D(p + '_depthwise_conv.weight').view(cmid, k * k).copy_(dwt.t())
-            else:
-                grads[p + '_depthwise_conv.weight'] = dwt.t().reshape(cmid, 1, k, k)
+            da0, grads[p + '_depthwise_conv.weight'] = dw_backward(a0, draw, wt, B, H, W, cmid, k, s, add=dout if (e == 1 and skip) else None,
+                                                                   out=D(p + '_depthwise_conv.weight'))
             if e != 1:
                 draw = self._bn_b(tape, grads, p + '_bn0', da0)
                 we = P[p + '_expand_conv.weight']

@@ -225,6 +225,9 @@ int cosy_dw_train_backward_data_add(const float* dy, const float* wt, const floa
                                     cosy_stream_t stream);
 int cosy_dw_train_backward_weight(const float* x, const float* dy, int B, int H, int W, int C, int k, int stride, float* dwt,
                                   void* workspace, cosy_stream_t stream);
+/* module_layout = 1: the gradient is written as (C, k*k) = the module's _depthwise_conv.weight (C,1,k,k) instead of [tap][channel] */
+int cosy_dw_train_backward_weight_ex(const float* x, const float* dy, int B, int H, int W, int C, int k, int stride, float* dw, int module_layout,
+                                     void* workspace, cosy_stream_t stream);
 /* 1x1 convolutions of the training step on the library's own fp32 MFMA GEMMs (no rocBLAS on the path):
  *   cosy_train_gemm: out (M,N) = A (M,K) . op(W) (+ add (M,N)); op(W) = W^T for W stored (N,K) [w_is_kn = 0: the forward of
  *                    F.conv2d with a 1x1 kernel, efficientnet.py:81,90,188], W for W stored (K,N) [w_is_kn = 1: the data
