@@ -80,10 +80,14 @@ def h_pose(model, mesh_db, data, meters, cfg, n_iterations=1, input_generator='f
         loss_n = train_engine.loss_refiner_CO_disentangled(TCO_possible_gt=TCO_possible_gt, TCO_input=it['TCO_input'],
                                                            refiner_outputs=it['model_outputs']['pose'], K_crop=it['K_crop'],
                                                            points=points)
-        meters[f'loss_TCO-iter={n}'].add(loss_n.mean().item())
         per_iteration.append(loss_n)
 
     loss = torch.cat(per_iteration).mean()
-    meters['loss_TCO'].add(loss.item())
-    meters['loss_total'].add(loss.item())
+    # the meters take the same numbers as in the reference (pose_forward_loss.py:74-83: .item() per iteration, then twice on the total), read back
+    # with ONE device synchronisation instead of n_iterations + 2
+    values = torch.stack([l.mean() for l in per_iteration] + [loss.detach()]).tolist()
+    for n, v in enumerate(values[:-1], 1):
+        meters[f'loss_TCO-iter={n}'].add(v)
+    meters['loss_TCO'].add(values[-1])
+    meters['loss_total'].add(values[-1])
     return loss
