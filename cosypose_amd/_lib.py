@@ -189,9 +189,16 @@ def ints_to_device(values, device):
         hit = _id_cache.get(key)
         if hit is not None:
             _id_cache.move_to_end(key)
-            return hit
+            dev_t, ready = hit
+            # the upload was enqueued on the stream that first asked for this content: another stream (a concurrent chunk with the same
+            # ids) must not read it before it has landed
+            if not ready.query():
+                torch.cuda.current_stream(device).wait_event(ready)
+            return dev_t
         dev_t = host.pin_memory().to(device, non_blocking=True)
-        _id_cache[key] = dev_t
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(device))
+        _id_cache[key] = (dev_t, ready)
         while len(_id_cache) > _ID_CACHE_ENTRIES:
             _id_cache.popitem(last=False)
         return dev_t
