@@ -1,3 +1,5 @@
+# Same-box A/B against the round-3 tree.  Prepare once: git worktree add .r03tree 4741c64 && (cd .r03tree && python -m cosypose_amd.build)
+# (.r03tree is git-ignored and travels to the GPU box with the snapshot).
 mkdir -p gpurun_out/r04m
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "storage_emulation or headline_config or full_batch_properties" > gpurun_out/r04m/tests.log 2>&1; echo "rc=$?" >> gpurun_out/r04m/tests.log; tail -3 gpurun_out/r04m/tests.log
 A="--no-cpu-baseline --no-other-dtypes --steps 10 --warmup 3"

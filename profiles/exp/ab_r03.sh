@@ -1,3 +1,5 @@
+# Same-box A/B against the round-3 tree.  Prepare once: git worktree add .r03tree 4741c64 && (cd .r03tree && python -m cosypose_amd.build)
+# (.r03tree is git-ignored and travels to the GPU box with the snapshot).
 mkdir -p gpurun_out/r04k
 A="--no-cpu-baseline --no-other-dtypes --no-profile --steps 12 --warmup 3"
 for i in 1 2 3; do
