@@ -33,12 +33,17 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--kernels', action='store_true', help='per-kernel table from torch.profiler to stderr')
+    ap.add_argument('--upload', choices=('prefetch', 'in_step'), default='prefetch',
+                    help="prefetch: batch i+1 is uploaded on a copy stream while step i runs (training.DevicePrefetcher, what train_loop does); "
+                         "in_step: h_pose's .cuda() uploads the batch at the top of its own step (the reference's order)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from bench import SyntheticRenderer, build_model
+    import itertools
     from cosypose_amd import synthetic as syn, train_engine, pose_forward_loss as pfl
+    from cosypose_amd.training import DevicePrefetcher
     from cosypose_amd.mesh_db import BatchedMeshes
     from cosypose_amd.distributed import init_distributed_mode, local_device_index, self_launch, process_group_info
 
@@ -67,8 +72,9 @@ def main():
     uv = (Kc.unsqueeze(1) @ cam.unsqueeze(-1)).squeeze(-1)
     uv = uv[..., :2] / uv[..., 2:]
     bboxes = torch.cat([uv.min(1)[0], uv.max(1)[0]], 1)
-    # the batch arrives as the reference's DataLoader delivers it (train_pose.py:242: pin_memory=True): page-locked host tensors,
-    # uploaded inside the step by h_pose's non-blocking .cuda()
+    # the batch arrives as the reference's DataLoader delivers it (train_pose.py:242: pin_memory=True): page-locked host tensors.  EVERY step
+    # uploads one batch (59 MB of frames): with --upload prefetch (default, what training.train_loop does) the upload of step i+1's batch runs on a
+    # copy stream beside step i's kernels; with --upload in_step h_pose's non-blocking .cuda() uploads it at the top of its own step
     pin = lambda t: t.contiguous().pin_memory()
     data = types.SimpleNamespace(images=pin(torch.from_numpy(frames)), K=pin(torch.from_numpy(K)), TCO=pin(torch.from_numpy(TCO)),
                                  objects=[dict(name=l) for l in labels[obj]], bboxes=pin(bboxes.cpu()))
@@ -78,11 +84,15 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)
     split = defaultdict(float)
 
+    feeds = {'in_step': itertools.repeat(data), 'prefetch': iter(DevicePrefetcher(itertools.repeat(data)))}
+    mode = [args.upload]
+
     def step(timed):
         e = [ev() for _ in range(5)]
         opt.zero_grad()
+        batch = next(feeds[mode[0]])
         e[0].record()
-        loss = pfl.h_pose(model=model, mesh_db=mesh_db, data=data, meters=meters, cfg=cfg, n_iterations=1, input_generator='fixed')
+        loss = pfl.h_pose(model=model, mesh_db=mesh_db, data=batch, meters=meters, cfg=cfg, n_iterations=1, input_generator='fixed')
         e[1].record()
         loss.backward()
         e[2].record()
@@ -114,6 +124,16 @@ def main():
         t = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    other = {'prefetch': 'in_step', 'in_step': 'prefetch'}[args.upload]      # the other upload order, timed beside the headline
+    mode[0] = other
+    step(False); sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(False)
+    sync()
+    dt_other = time.perf_counter() - t0
+    mode[0] = args.upload
+    step(False)
     for _ in range(min(args.steps, 3)):
         step(True)
     nsp = min(args.steps, 3)
@@ -145,6 +165,8 @@ def main():
             'crops_per_s': round(world * B * args.steps / dt, 1),
             'config': {'workload': f'BASELINE configs[4]: {B} crops/GPU from {h}x{w} uint8 frames, {H}x{W} crops, h_pose forward + disentangled '
                                    f'loss + backward + gradient all-reduce ({opt.grad.numel() * 4 / 1e6:.1f} MB fp32) + clip 0.5 + Adam',
+                       'upload': {'mode': args.upload, 'bytes_per_step': int(data.images.numel()),
+                                  f'ms_per_step_{other}': round(1e3 * dt_other / args.steps, 2)},
                        'n_points_loss': 2600, 'drop_connect_rate': model.drop_connect_rate, 'process_group': process_group_info()},
             'split_ms': {k: round(v / nsp, 2) for k, v in split.items()},
             'peak_memory_gb': round(torch.cuda.max_memory_allocated() / 1e9, 2),

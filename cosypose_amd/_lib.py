@@ -62,6 +62,9 @@ _SIGNATURES = {
     'cosy_wgrad_tall': ([_P, _P, _L, _I, _I, _P, _P, _P], _I),
     'cosy_wgrad': ([_P, _P, _L, _I, _I, _P, _P, _P], _I),
     'cosy_train_gemm': ([_P, _P, _I, _L, _I, _I, _P, _P, _P, _P], _I),
+    'cosy_train_pack_plan': ([_I, _P, _P, _P, _P, _P, _P, _P], _I),
+    'cosy_train_pack_all': ([_P, _I, _c.c_longlong, _P, _P], _I),
+    'cosy_train_gemm_packed': ([_P, _P, _c.c_longlong, _L, _I, _I, _P, _P, _P], _I),
     'cosy_stem_im2col_ld': ([_P, _I, _I, _I, _I, _P, _P], _I),
     'cosy_rows_mean': ([_P, _I, _I, _I, _P, _P, _P], _I),
     'cosy_rows_mean_bn': ([_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P], _I),

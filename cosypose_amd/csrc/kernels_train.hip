@@ -1133,6 +1133,17 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // weights change every step, so they are re-packed into the kernel's fragment order on the device (a few microseconds:
 // the largest matrix is 2304 x 384), together with the identity epilogue (scale 1, bias 0) the inference kernel expects.
 // ------------------------------------------------------------------------------------------
+// element idx of the packed form of one weight: lane-major fragment blocks of 4 k-values (see pw_pack_weights, the host-side packer of the inference path)
+__device__ __forceinline__ float pw_pack_f32_elem(const float* __restrict__ w, int K, int N, int w_is_kn, int NI, int WN, int nkb, long idx) {
+    const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+    long r = idx >> 8;
+    const int kbi = (int)(r % nkb); r /= nkb;
+    const int NW = NI * WN, nb = (int)(r % NW), nt = (int)(r / NW);
+    const int i = lane & 15, kg = lane >> 4, wn = nb / NI, ni = nb % NI;
+    const int n = nt * 16 * NW + wn * 16 * NI + (i >> 2) * 4 * NI + ni * 4 + (i & 3);
+    const int k = kbi * 16 + kg * 4 + e;
+    return (n < N && k < K) ? (w_is_kn ? w[(size_t)k * N + n] : w[(size_t)n * K + k]) : 0.f;
+}
 __global__ __launch_bounds__(256) void pw_pack_f32_kernel(const float* __restrict__ w, int K, int N, int w_is_kn, int NI, int WN, int nkb,
                                                           long total, int n_pad, float* __restrict__ dst, float* __restrict__ ones,
                                                           float* __restrict__ zeros) {
@@ -1142,14 +1153,32 @@ __global__ __launch_bounds__(256) void pw_pack_f32_kernel(const float* __restric
         zeros[idx] = 0.f;                     // n_pad zeros for the bias + 16 zero bytes for the DMA's padding source
     }
     if (idx >= total) return;
-    const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
-    long r = idx >> 8;
-    const int kbi = (int)(r % nkb); r /= nkb;
-    const int NW = NI * WN, nb = (int)(r % NW), nt = (int)(r / NW);
-    const int i = lane & 15, kg = lane >> 4, wn = nb / NI, ni = nb % NI;
-    const int n = nt * 16 * NW + wn * 16 * NI + (i >> 2) * 4 * NI + ni * 4 + (i & 3);
-    const int k = kbi * 16 + kg * 4 + e;
-    dst[idx] = (n < N && k < K) ? (w_is_kn ? w[(size_t)k * N + n] : w[(size_t)n * K + k]) : 0.f;
+    dst[idx] = pw_pack_f32_elem(w, K, N, w_is_kn, NI, WN, nkb, idx);
+}
+// Every 1x1-convolution weight of the network (both orientations: forward and data gradient) in ONE launch at the top of a step instead of a
+// ~4.6 us launch in front of each of the ~100 GEMMs.  plan[e] = {source pointer, destination offset in the pool (floats), K, N,
+// w_is_kn | NI << 8 | WN << 16, k-blocks, packed elements, first workgroup}; the pool starts with the identity epilogue the GEMM wants
+// (PACK_HEAD_N ones, then PACK_HEAD_N + 16 zeros: scale, bias and the DMA's padding source).
+constexpr int PACK_HEAD_N = 4096;
+constexpr int PACK_HEAD_FLOATS = 2 * PACK_HEAD_N + 16;
+constexpr int PACK_HEAD_BLOCKS = (PACK_HEAD_FLOATS + 255) / 256;
+__global__ __launch_bounds__(256) void pw_pack_all_kernel(const long long* __restrict__ plan, int n, float* __restrict__ pool) {
+    const long blk = blockIdx.x;
+    if (blk < PACK_HEAD_BLOCKS) {
+        const int idx = (int)blk * 256 + threadIdx.x;
+        if (idx < PACK_HEAD_FLOATS) pool[idx] = idx < PACK_HEAD_N ? 1.f : 0.f;
+        return;
+    }
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {                         // the last entry whose first workgroup is <= blk (uniform over the workgroup)
+        const int mid = (lo + hi + 1) >> 1;
+        if (plan[(size_t)mid * 8 + 7] <= blk) lo = mid; else hi = mid - 1;
+    }
+    const long long* e = plan + (size_t)lo * 8;
+    const long idx = (blk - e[7]) * 256 + threadIdx.x;
+    if (idx >= e[6]) return;
+    const int flags = (int)e[4];
+    pool[e[1] + idx] = pw_pack_f32_elem((const float*)e[0], (int)e[2], (int)e[3], flags & 1, (flags >> 8) & 255, (flags >> 16) & 255, (int)e[5], idx);
 }
 }  // namespace
 }  // namespace cosy
@@ -1361,6 +1390,44 @@ int cosy_train_gemm(const float* A, const float* W, int w_is_kn, long M, int K, 
     a.A = A; a.Wp = wp; a.out = out; a.scale = ones; a.bias = zeros; a.res = add; a.gate = nullptr;
     a.M = (int)M; a.K = K; a.N = N; a.HW = (int)M; a.silu = 0; a.zeros = zeros;
     return launch_pw_gemm(a, cfg, COSY_F32, s);
+}
+
+// ---- the same GEMM on weights packed ahead of time, all of them in one launch (cosy_train_pack_all) ----
+int cosy_train_pack_plan(int n, const float* const* W, const int* K, const int* N, const int* w_is_kn, long long* plan, long long* pool_floats,
+                         long long* n_blocks) {
+    COSY_REQUIRE(n > 0 && W && K && N && w_is_kn && plan && pool_floats && n_blocks, "train_pack_plan: null argument");
+    long long off = PACK_HEAD_FLOATS, blk = PACK_HEAD_BLOCKS;
+    for (int e = 0; e < n; ++e) {
+        COSY_REQUIRE(W[e] && K[e] > 0 && N[e] > 0 && K[e] % 4 == 0 && N[e] % 4 == 0, "train_pack_plan: entry %d: K=%d N=%d", e, K[e], N[e]);
+        const PwCfg cfg = pw_choose_cfg(N[e]);
+        const size_t packed = pw_packed_elems(K[e], N[e], cfg, COSY_F32);
+        COSY_REQUIRE(cdiv(N[e], pw_bn(cfg)) * pw_bn(cfg) <= PACK_HEAD_N, "train_pack_plan: N=%d exceeds the shared epilogue arrays", N[e]);
+        long long* p = plan + (size_t)e * 8;
+        p[0] = (long long)(uintptr_t)W[e]; p[1] = off; p[2] = K[e]; p[3] = N[e];
+        p[4] = (w_is_kn[e] ? 1 : 0) | (cfg.NI << 8) | (cfg.WN << 16);
+        p[5] = (long long)(packed / ((size_t)cdiv(N[e], pw_bn(cfg)) * cfg.NI * cfg.WN * 256));
+        p[6] = (long long)packed; p[7] = blk;
+        off += (long long)((packed + 63) / 64 * 64);                  // 256-byte aligned starts
+        blk += (long long)cdiv((long)packed, 256l);
+    }
+    *pool_floats = off; *n_blocks = blk;
+    return COSY_OK;
+}
+int cosy_train_pack_all(const long long* plan_dev, int n, long long n_blocks, float* pool, cosy_stream_t stream) {
+    COSY_REQUIRE(plan_dev && pool && n > 0 && n_blocks > PACK_HEAD_BLOCKS && n_blocks < (1ll << 31), "train_pack_all: bad argument");
+    hipLaunchKernelGGL(pw_pack_all_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, plan_dev, n, pool);
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+int cosy_train_gemm_packed(const float* A, const float* pool, long long packed_offset, long M, int K, int N, const float* add, float* out,
+                           cosy_stream_t stream) {
+    COSY_REQUIRE(A && pool && out && packed_offset >= PACK_HEAD_FLOATS && M > 0 && K > 0 && N > 0, "train_gemm_packed: bad argument M=%ld K=%d N=%d", M, K, N);
+    COSY_REQUIRE(K % 4 == 0 && N % 4 == 0 && M < (1l << 31), "train_gemm_packed: K=%d and N=%d must be multiples of 4", K, N);
+    const PwCfg cfg = pw_choose_cfg(N);
+    PwArgs a{};
+    a.A = A; a.Wp = pool + packed_offset; a.out = out; a.scale = pool; a.bias = pool + PACK_HEAD_N; a.res = add; a.gate = nullptr;
+    a.M = (int)M; a.K = K; a.N = N; a.HW = (int)M; a.silu = 0; a.zeros = pool + PACK_HEAD_N;
+    return launch_pw_gemm(a, cfg, COSY_F32, (hipStream_t)stream);
 }
 
 static int rows_chunks(int B, int HW, int C, int* rows_per_chunk) {

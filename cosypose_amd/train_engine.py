@@ -203,15 +203,61 @@ def wgrad(dY, X, out=None):
     return out
 
 
-def gemm(A, W, w_is_kn=False, add=None):
+def gemm(A, W, w_is_kn=False, add=None, packed=None):
     """A (M,K) @ W^T for W (N,K)  [w_is_kn=False: a 1x1 convolution's forward]  or  A (M,K) @ W for W (K,N)  [w_is_kn=True: its
-    data gradient], plus `add` (M,N): the library's own fp32 MFMA GEMM (cosy_train_gemm), no rocBLAS."""
+    data gradient], plus `add` (M,N): the library's own fp32 MFMA GEMM (cosy_train_gemm), no rocBLAS.  packed: a PackedWeights holding
+    W in this orientation (packed at the top of the step with every other weight) -- without it the weight is packed by a launch of its own."""
     M, K = A.shape
     N = W.shape[1] if w_is_kn else W.shape[0]
     assert W.shape == ((K, N) if w_is_kn else (N, K)) and A.is_contiguous() and W.is_contiguous()
     out = torch.empty(M, N, device=A.device)
-    check(lib().cosy_train_gemm(ptr(A), ptr(W), int(w_is_kn), M, K, N, ptr(add), ptr(out), ptr(_workspace(A.device)), stream()))
+    if packed is not None:
+        check(lib().cosy_train_gemm_packed(ptr(A), ptr(packed.pool), packed.offset(W, w_is_kn), M, K, N, ptr(add), ptr(out), stream()))
+    else:
+        check(lib().cosy_train_gemm(ptr(A), ptr(W), int(w_is_kn), M, K, N, ptr(add), ptr(out), ptr(_workspace(A.device)), stream()))
     return out
+
+
+class PackedWeights:
+    """The fragment-order copies of a set of 1x1-convolution weights, each in both orientations (forward: (N,K); data gradient: the same
+    storage read as (K,N)), refreshed by ONE launch (cosy_train_pack_all) -- the weights change once per step, in Adam, not between the
+    ~100 GEMMs that read them.  The plan (where each weight lives) is rebuilt only when the set of tensors changes."""
+    _cache = {}            # (device, stream, weight set) -> instance; a handful at most (one per model trained in this process)
+    MAX_SETS = 4
+
+    @classmethod
+    def current(cls, weights):
+        """the instance of (device, stream, this set of 2-D fp32 tensors), planned on first sight, packed now.  Every weight set owns its pool:
+        a backward never finds its forward's packed weights overwritten by another model's forward."""
+        key = (weights[0].device.index, stream()) + tuple((w.data_ptr(), w.shape[0], w.shape[1]) for w in weights)
+        me = cls._cache.pop(key, None)
+        if me is None:
+            me = cls(weights)
+            while len(cls._cache) >= cls.MAX_SETS:
+                cls._cache.pop(next(iter(cls._cache)))         # least recently used
+        cls._cache[key] = me
+        check(lib().cosy_train_pack_all(ptr(me.plan), me.plan.shape[0], me.n_blocks, ptr(me.pool), stream()))
+        return me
+
+    def __init__(self, weights):
+        import ctypes as c
+        n = 2 * len(weights)
+        W = (c.c_void_p * n)(*[w.data_ptr() for w in weights for _ in (0, 1)])
+        # forward: W (N,K) as it is stored; data gradient dX = dY . W: the same storage as a (K', N') = (N, K) matrix, w_is_kn
+        K = (c.c_int * n)(*[v for w in weights for v in (w.shape[1], w.shape[0])])
+        N = (c.c_int * n)(*[v for w in weights for v in (w.shape[0], w.shape[1])])
+        kn = (c.c_int * n)(*[v for _ in weights for v in (0, 1)])
+        plan = torch.empty(n, 8, dtype=torch.int64)
+        floats, blocks = c.c_longlong(), c.c_longlong()
+        check(lib().cosy_train_pack_plan(n, W, K, N, kn, plan.data_ptr(), c.byref(floats), c.byref(blocks)))
+        dev = weights[0].device
+        self.plan = plan.to(dev)
+        self.pool = torch.empty(floats.value, device=dev)
+        self.offsets = {(int(plan[e, 0]), bool(e & 1)): int(plan[e, 1]) for e in range(n)}
+        self.n_blocks = blocks.value
+
+    def offset(self, W, w_is_kn):
+        return self.offsets[(W.data_ptr(), bool(w_is_kn))]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -274,11 +320,23 @@ class _Net:
         grads[name + '.weight'], grads[name + '.bias'] = dg, db
         return dx
 
+    def _conv_weights(self):
+        """the 1x1-convolution weights as 2-D matrices, in network order"""
+        P, out = self.P, []
+        for i, (k, s, e, cin, cout) in enumerate(arch.B3_BLOCKS):
+            p = f'backbone._blocks.{i}.'
+            if e != 1:
+                out.append(P[p + '_expand_conv.weight'].view(cin * e, cin))
+            out.append(P[p + '_project_conv.weight'].view(cout, cin * e))
+        out.append(P['backbone._conv_head.weight'].view(arch.HEAD_C, -1))
+        return out
+
     def forward(self, x8, drop):
         P = self.P
         tape = {}
         B, H, W, _ = x8.shape
         dev = x8.device
+        pk = self.packed = PackedWeights.current(self._conv_weights())      # one launch: every weight, both orientations
         # stem: im2col + GEMM, BN, Swish
         Ho, Wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
         cols = torch.empty(B * Ho * Wo, 56, device=dev)                 # 54 patch values + 2 zero columns: 16-byte aligned rows
@@ -293,7 +351,7 @@ class _Net:
             M, cmid = B * H * W, cin * e
             inp = x
             if e != 1:
-                raw = gemm(inp, P[p + '_expand_conv.weight'].view(cmid, cin))
+                raw = gemm(inp, P[p + '_expand_conv.weight'].view(cmid, cin), packed=pk)
                 a0 = self._bn_f(tape, p + '_bn0', raw, M, cmid, 1)
             else:
                 a0 = inp
@@ -310,14 +368,14 @@ class _Net:
             pooled = rows_mean_bn(raw, mean1, rstd1, g1, b1, B, HWo, cmid)
             h_pre, g = se_forward(pooled, P[p + '_se_reduce.weight'], P[p + '_se_reduce.bias'], P[p + '_se_expand.weight'], P[p + '_se_expand.bias'])
             a2 = bn_apply_gated(raw, mean1, rstd1, g1, b1, Mo, cmid, 1, g, HWo)
-            raw = gemm(a2, P[p + '_project_conv.weight'].view(cout, cmid))
+            raw = gemm(a2, P[p + '_project_conv.weight'].view(cout, cmid), packed=pk)
             skip = s == 1 and cin == cout
             rowscale = drop.get(i) if (skip and drop) else None
             x = self._bn_f(tape, p + '_bn2', raw, Mo, cout, 0, rowscale, HWo, inp if skip else None)
             tape[p] = (inp, a0, wt, pooled, h_pre, g, a2, H, W, Ho, Wo)
             H, W = Ho, Wo
         M = B * H * W
-        raw = gemm(x, P['backbone._conv_head.weight'].view(arch.HEAD_C, -1))
+        raw = gemm(x, P['backbone._conv_head.weight'].view(arch.HEAD_C, -1), packed=pk)
         a = self._bn_f(tape, 'backbone._bn1', raw, M, arch.HEAD_C, 1)
         feat = rows_mean(a, B, H * W, arch.HEAD_C)
         pose = fc_small_forward(feat, P['pose_fc.weight'], P['pose_fc.bias'])
@@ -333,13 +391,14 @@ class _Net:
         x_head, feat, B, H, W = tape['head']
         D = self._dst
         staged = self.stage is not None
+        pk = self.packed            # packed by this step's forward; the weights do not change between a forward and its backward
         dfeat, grads['pose_fc.weight'], grads['pose_fc.bias'] = fc_small_backward(
             dpose, feat, P['pose_fc.weight'], out=(D('pose_fc.weight'), D('pose_fc.bias')) if staged else None)
         da = rows_broadcast(dfeat, 1.0 / (H * W), B, H * W, arch.HEAD_C)
         draw = self._bn_b(tape, grads, 'backbone._bn1', da)
         wh = P['backbone._conv_head.weight']
         grads['backbone._conv_head.weight'] = wgrad(draw, x_head, out=D('backbone._conv_head.weight')).view_as(wh)
-        dx = gemm(draw, wh.view(arch.HEAD_C, -1), w_is_kn=True)
+        dx = gemm(draw, wh.view(arch.HEAD_C, -1), w_is_kn=True, packed=pk)
         for i in reversed(range(len(arch.B3_BLOCKS))):
             k, s, e, cin, cout = arch.B3_BLOCKS[i]
             p = f'backbone._blocks.{i}.'
@@ -350,7 +409,7 @@ class _Net:
             draw = self._bn_b(tape, grads, p + '_bn2', dout)
             wp = P[p + '_project_conv.weight']
             grads[p + '_project_conv.weight'] = wgrad(draw, a2, out=D(p + '_project_conv.weight')).view_as(wp)
-            da2 = gemm(draw, wp.view(cout, cmid), w_is_kn=True)
+            da2 = gemm(draw, wp.view(cout, cmid), w_is_kn=True, packed=pk)
             # squeeze-excite backward
             raw1, mean1, rstd1 = tape[p + '_bn1'][:3]
             dg = rows_dot_bn(da2, raw1, mean1, rstd1, P[p + '_bn1.weight'], P[p + '_bn1.bias'], B, HWo, cmid)      # sum_hw da2 * a1, a1 recomputed
@@ -368,7 +427,7 @@ class _Net:
                 we = P[p + '_expand_conv.weight']
                 grads[p + '_expand_conv.weight'] = wgrad(draw, inp, out=D(p + '_expand_conv.weight')).view_as(we)
                 # the skip connection's gradient rides on the GEMM (C = dout + draw W) instead of a separate add
-                dx = gemm(draw, we.view(cmid, cin), w_is_kn=True, add=dout if skip else None)
+                dx = gemm(draw, we.view(cmid, cin), w_is_kn=True, add=dout if skip else None, packed=pk)
             else:
                 dx = da0             # (+ dout for a skip block: already added inside dw_backward)
         draw = self._bn_b(tape, grads, 'backbone._bn0', dx)

@@ -12,8 +12,13 @@ Contract (cosypose/training/train_pose.py):
   * step (:317-331): zero_grad -> h_pose -> backward -> clip_grad_norm_(clip_grad_norm) -> Adam.step, then the warm-up
     scheduler; with `FlatAdam` clip + Adam are two fused launches on the flat buffers and the gradient all-reduce of a
     multi-rank run is one RCCL call (or pass a DistributedDataParallel model and let DDP do it).
+  * upload (:242 pin_memory=True + pose_forward_loss.py:24-27 .cuda() inside the step): the reference uploads a batch at the
+    top of the step that consumes it -- 59 MB of uint8 frames for 64 x 480x640, ~1 ms of PCIe in front of the first kernel.
+    `DevicePrefetcher` uploads batch i+1 on a copy stream (SDMA, no compute units) WHILE step i computes; h_pose's .cuda() is
+    then the identity.  Same batches, same order, same values.
 Datasets, samplers and evaluation are out of scope: `train_loop` takes any iterable of batches.
 """
+import copy
 import pathlib
 from collections import defaultdict
 
@@ -82,6 +87,58 @@ class LRSchedule:
         return v
 
 
+class DevicePrefetcher:
+    """Iterates `batches` and hands every batch out with its tensor fields already in HBM.  One batch ahead: when batch i is handed
+    out, the upload of batch i+1 has just been enqueued on a dedicated copy stream, so it overlaps with step i's kernels; the
+    consumer's stream waits for the upload's event (not the host).  Batches are shallow copies: the caller's objects keep their
+    host tensors.  Host tensors should be page-locked (DataLoader(pin_memory=True)) -- pageable ones are uploaded synchronously
+    by the runtime and only the ordering benefit remains."""
+    FIELDS = ('images', 'K', 'TCO', 'bboxes')
+
+    def __init__(self, batches, device=None, fields=FIELDS):
+        if not torch.cuda.is_available():
+            raise RuntimeError('DevicePrefetcher uploads to an MI355X: no GPU visible')
+        self.batches, self.fields = batches, tuple(fields)
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def __len__(self):
+        return len(self.batches)
+
+    def _upload(self, batch):
+        ready = torch.cuda.Event()
+        with torch.cuda.stream(self.stream):
+            moved = {name: t.to(self.device, non_blocking=True) for name in self.fields
+                     for t in [getattr(batch, name, None)] if torch.is_tensor(t) and not t.is_cuda}
+            ready.record(self.stream)
+        if hasattr(batch, '_replace'):                 # a namedtuple batch
+            return batch._replace(**moved), ready
+        out = copy.copy(batch)
+        for name, t in moved.items():
+            setattr(out, name, t)
+        return out, ready
+
+    def __iter__(self):
+        source = iter(self.batches)
+        try:
+            ahead = self._upload(next(source))
+        except StopIteration:
+            return
+        while ahead is not None:
+            (batch, ready), ahead = ahead, None
+            try:
+                ahead = self._upload(next(source))     # enqueued BEFORE the consumer enqueues its step: runs beside it
+            except StopIteration:
+                pass
+            consumer = torch.cuda.current_stream(self.device)
+            consumer.wait_event(ready)
+            for name in self.fields:                   # allocated on the copy stream, used on the consumer's: the caching allocator must
+                t = getattr(batch, name, None)         # not hand the block to the next upload while the step still reads it
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(consumer)
+            yield batch
+
+
 def checkpoint_path(save_dir):
     return pathlib.Path(save_dir) / 'checkpoint.pth.tar'
 
@@ -108,10 +165,11 @@ def load_checkpoint(path_or_dir, model, strict=True):
 
 
 def train_loop(model, mesh_db, cfg, batches, n_epochs, save_dir=None, start_epoch=0, optimizer=None, on_epoch_end=None,
-               input_generator='fixed', faithful_schedule=True):
+               input_generator='fixed', faithful_schedule=True, prefetch=True):
     """Runs epochs [start_epoch, n_epochs) of the reference's training loop on `batches` (a callable epoch -> iterable of
     batch objects with images / K / TCO / objects / bboxes, or a re-iterable).  cfg: lr, weight_decay, n_epochs_warmup,
-    lr_epoch_decay, clip_grad_norm, n_iterations (+ what h_pose needs).  Returns {epoch: mean loss}."""
+    lr_epoch_decay, clip_grad_norm, n_iterations (+ what h_pose needs).  prefetch: upload batch i+1 while step i runs
+    (DevicePrefetcher).  Returns {epoch: mean loss}."""
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     is_ddp = hasattr(model, 'module')
@@ -139,7 +197,8 @@ def train_loop(model, mesh_db, cfg, batches, n_epochs, save_dir=None, start_epoc
             schedule = LRSchedule(cfg.lr, cfg.n_epochs_warmup, bpe or len(items), cfg.lr_epoch_decay, start_epoch=start_epoch, faithful=faithful_schedule)
         model.train()
         meters = defaultdict(_Mean)
-        for b, sample in enumerate(items):
+        feed = DevicePrefetcher(items) if prefetch and torch.cuda.is_available() else items
+        for b, sample in enumerate(feed):
             schedule.apply(optimizer, epoch, b)
             optimizer.zero_grad()
             loss = h_pose(model=model, mesh_db=mesh_db, data=sample, meters=meters, cfg=cfg, n_iterations=getattr(cfg, 'n_iterations', 1),

@@ -190,7 +190,7 @@ int cosy_dists_add(const float* TXO_pred, const float* TXO_gt, const float* pts_
 /* ---- training step of the refiner network, fp32, activations NHWC = rows x channels --------------
  * Every piece of cosypose/training/train_pose.py:317-331's step: the 1x1 convolutions and their gradients on the library's own
  * fp32 MFMA GEMMs (cosy_train_gemm / cosy_wgrad below), BatchNorm, depthwise, squeeze-excite scaling, loss gradient, clip +
- * Adam; only the 64-row squeeze-excite / pose FCs are left to the host side (torch.addmm, 1.3 ms of a 43 ms step).  `workspace` is a device buffer
+ * Adam, the squeeze-excite and pose FCs (cosy_se_train_*, cosy_fc_small_*): no rocBLAS on the step.  `workspace` is a device buffer
  * of cosy_train_workspace_bytes() bytes shared by the reductions (deterministic two-stage sums, no atomics). */
 size_t cosy_train_workspace_bytes(void);
 /* crop + render pack (as cosy_crop_pack) into a caller-owned NHWC8 buffer of element type `dtype` */
@@ -238,6 +238,16 @@ int cosy_dw_train_backward_weight_ex(const float* x, const float* dy, int B, int
 int cosy_train_gemm(const float* A, const float* W, int w_is_kn, long M, int K, int N, const float* add, float* out, void* workspace,
                     cosy_stream_t stream);
 int cosy_wgrad(const float* dY, const float* X, long M, int N, int K, float* dW, void* workspace, cosy_stream_t stream);
+/* The weights of EVERY 1x1 convolution packed in one launch per step (they change once per step, in Adam): cosy_train_pack_plan fills `plan`
+ * (host, 8 x int64 per entry: see kernels_train.hip) for n weights given as in cosy_train_gemm and returns the pool size in floats and the grid;
+ * the caller uploads the plan, cosy_train_pack_all packs into `pool` (pool_floats floats), cosy_train_gemm_packed is cosy_train_gemm on entry e's
+ * packed form at pool + plan[e][1]. */
+int cosy_train_pack_plan(int n, const float* const* W, const int* K, const int* N, const int* w_is_kn, long long* plan, long long* pool_floats,
+                         long long* n_blocks);
+int cosy_train_pack_all(const long long* plan_dev, int n, long long n_blocks, float* pool, cosy_stream_t stream);
+int cosy_train_gemm_packed(const float* A, const float* pool, long long packed_offset, long M, int K, int N, const float* add, float* out,
+                           cosy_stream_t stream);
+
 int cosy_wgrad_tall_supported(long M, int N, int K);
 int cosy_wgrad_tall(const float* dY, const float* X, long M, int N, int K, float* dW, void* workspace, cosy_stream_t stream);
 /* per-sample reductions / broadcasts over the HW pixels of a (B,HW,C) activation: mean (adaptive_avg_pool2d),

@@ -1279,6 +1279,33 @@ def test_train_gemm_and_wgrad_vs_torch_fp64(M, K, N):
     assert torch.equal(dW, te.wgrad(dY, A))                                                           # fixed-order combine: deterministic
 
 
+def test_packed_weights_one_launch_matches_per_call_packing():
+    """train_engine.PackedWeights (cosy_train_pack_all: every 1x1-convolution weight, both orientations, in ONE launch per step) feeds
+    cosy_train_gemm_packed the same fragments cosy_train_gemm packs per call: outputs bit-identical, for every shape class of the network
+    (all four tile shapes of pw_choose_cfg, ragged N, K not a multiple of 16); a changed weight is seen after the next refresh; a second
+    weight set gets its own pool (the first one's packed weights survive)."""
+    from cosypose_amd import train_engine as te
+    g = torch.Generator(device='cuda').manual_seed(5)
+    shapes = [(144, 24), (24, 144), (816, 136), (232, 1392), (1536, 384), (40, 56), (96, 48), (48, 288), (2304, 384), (384, 2304)]
+    Ws = [torch.randn(n, k, device='cuda', generator=g) / k ** 0.5 for n, k in shapes]
+    pk = te.PackedWeights.current(Ws)
+    for W in Ws:
+        n, k = W.shape
+        A, dY = torch.randn(777, k, device='cuda', generator=g), torch.randn(777, n, device='cuda', generator=g)
+        add = torch.randn(777, k, device='cuda', generator=g)
+        assert torch.equal(te.gemm(A, W, packed=pk), te.gemm(A, W))
+        assert torch.equal(te.gemm(dY, W, w_is_kn=True, add=add, packed=pk), te.gemm(dY, W, w_is_kn=True, add=add))
+    A = torch.randn(300, 24, device='cuda', generator=g)
+    before = te.gemm(A, Ws[0], packed=pk)
+    Ws[0].mul_(2.0)
+    other = [torch.randn(64, 32, device='cuda', generator=g)]
+    pk2 = te.PackedWeights.current(other)                       # another model's weights: its own pool
+    assert pk2 is not pk and pk2.pool.data_ptr() != pk.pool.data_ptr()
+    assert torch.equal(te.gemm(A, Ws[0], packed=pk), before)    # not refreshed yet: still the packed copy of the old values
+    assert te.PackedWeights.current(Ws) is pk                   # same tensors -> same plan, packed again
+    assert torch.equal(te.gemm(A, Ws[0], packed=pk), te.gemm(A, Ws[0])) and torch.equal(te.gemm(A, Ws[0], packed=pk), before * 2)
+
+
 @pytest.mark.parametrize('B,C,Cse', [(64, 40, 10), (3, 24, 6), (70, 144, 6), (64, 816, 34), (17, 1392, 58), (64, 2304, 96)])
 def test_se_train_kernels_vs_torch_fp64(B, C, Cse):
     """The fused squeeze-excite kernels of the training step (cosy_se_train_forward / _backward: batched fp32-MFMA FCs, efficientnet.py:85-88
