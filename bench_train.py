@@ -21,11 +21,6 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 
-class Meter:
-    def add(self, v):
-        pass
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -43,7 +38,7 @@ def main():
     from bench import SyntheticRenderer, build_model
     import itertools
     from cosypose_amd import synthetic as syn, train_engine, pose_forward_loss as pfl
-    from cosypose_amd.training import DevicePrefetcher
+    from cosypose_amd.training import DevicePrefetcher, LazyMeters
     from cosypose_amd.mesh_db import BatchedMeshes
     from cosypose_amd.distributed import init_distributed_mode, local_device_index, self_launch, process_group_info
 
@@ -80,7 +75,7 @@ def main():
                                  objects=[dict(name=l) for l in labels[obj]], bboxes=pin(bboxes.cpu()))
     cfg = argparse.Namespace(n_points_loss=2600, loss_disentangled=True, n_pose_dims=9, init_method='v0')
     opt = train_engine.FlatAdam(model, lr=3e-4, clip_grad_norm=0.5)
-    meters = defaultdict(Meter)
+    meters = LazyMeters()          # as train_loop: the loss values are read back without stopping the host (no .item() in the middle of the step)
     ev = lambda: torch.cuda.Event(enable_timing=True)
     split = defaultdict(float)
 
@@ -124,16 +119,8 @@ def main():
         t = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    other = {'prefetch': 'in_step', 'in_step': 'prefetch'}[args.upload]      # the other upload order, timed beside the headline
-    mode[0] = other
-    step(False); sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(False)
-    sync()
-    dt_other = time.perf_counter() - t0
-    mode[0] = args.upload
-    step(False)
+    meters.flush()
+    assert meters['loss_total'].n == args.warmup + args.steps
     for _ in range(min(args.steps, 3)):
         step(True)
     nsp = min(args.steps, 3)
@@ -165,8 +152,8 @@ def main():
             'crops_per_s': round(world * B * args.steps / dt, 1),
             'config': {'workload': f'BASELINE configs[4]: {B} crops/GPU from {h}x{w} uint8 frames, {H}x{W} crops, h_pose forward + disentangled '
                                    f'loss + backward + gradient all-reduce ({opt.grad.numel() * 4 / 1e6:.1f} MB fp32) + clip 0.5 + Adam',
-                       'upload': {'mode': args.upload, 'bytes_per_step': int(data.images.numel()),
-                                  f'ms_per_step_{other}': round(1e3 * dt_other / args.steps, 2)},
+                       'upload': {'mode': args.upload, 'bytes_per_step': int(data.images.numel())},
+                       'host_syncs_per_step': 0,
                        'n_points_loss': 2600, 'drop_connect_rate': model.drop_connect_rate, 'process_group': process_group_info()},
             'split_ms': {k: round(v / nsp, 2) for k, v in split.items()},
             'peak_memory_gb': round(torch.cuda.max_memory_allocated() / 1e9, 2),

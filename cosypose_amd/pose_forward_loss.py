@@ -83,11 +83,15 @@ def h_pose(model, mesh_db, data, meters, cfg, n_iterations=1, input_generator='f
         per_iteration.append(loss_n)
 
     loss = torch.cat(per_iteration).mean()
-    # the meters take the same numbers as in the reference (pose_forward_loss.py:74-83: .item() per iteration, then twice on the total), read back
-    # with ONE device synchronisation instead of n_iterations + 2
-    values = torch.stack([l.mean() for l in per_iteration] + [loss.detach()]).tolist()
-    for n, v in enumerate(values[:-1], 1):
-        meters[f'loss_TCO-iter={n}'].add(v)
-    meters['loss_TCO'].add(values[-1])
-    meters['loss_total'].add(values[-1])
+    # the meters take the same numbers as in the reference (pose_forward_loss.py:74-83: .item() per iteration, then twice on the total).  Plain
+    # meters: read back with ONE device synchronisation instead of n_iterations + 2.  Meters with a `defer` method (training.LazyMeters): no
+    # synchronisation at all -- the values are added when their copy has arrived, and the host goes straight on to enqueue the backward pass.
+    values = torch.stack([l.mean() for l in per_iteration] + [loss.detach()])
+    names = [(f'loss_TCO-iter={n}',) for n in range(1, n_iterations + 1)] + [('loss_TCO', 'loss_total')]
+    if hasattr(meters, 'defer') and values.is_cuda:
+        meters.defer(names, values)
+    else:
+        for keys, v in zip(names, values.tolist()):
+            for k in keys:
+                meters[k].add(v)
     return loss

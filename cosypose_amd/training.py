@@ -88,11 +88,14 @@ class LRSchedule:
 
 
 class DevicePrefetcher:
-    """Iterates `batches` and hands every batch out with its tensor fields already in HBM.  One batch ahead: when batch i is handed
-    out, the upload of batch i+1 has just been enqueued on a dedicated copy stream, so it overlaps with step i's kernels; the
-    consumer's stream waits for the upload's event (not the host).  Batches are shallow copies: the caller's objects keep their
-    host tensors.  Host tensors should be page-locked (DataLoader(pin_memory=True)) -- pageable ones are uploaded synchronously
-    by the runtime and only the ordering benefit remains."""
+    """Iterates `batches` and hands every batch out with its tensor fields already in HBM.  One batch ahead: when batch j is handed
+    out, the upload of batch j+1 has just been enqueued on a dedicated copy stream, so it runs beside step j's kernels; the
+    consumer's stream waits for the upload's event (the host does not).  The device tensors live in TWO persistent slots (no
+    allocator traffic, no frees that wait for another stream): batch j+1 goes into the slot batch j-1 used, after an event recorded
+    on the consumer's stream when batch j is requested -- by then all of step j-1 has been enqueued.  So a batch's device tensors
+    are valid until the batch after next is requested; a consumer that keeps them longer must clone them.  Batches are shallow
+    copies: the caller's objects keep their host tensors.  Host tensors should be page-locked (DataLoader(pin_memory=True)) --
+    pageable ones are uploaded synchronously by the runtime and only the ordering benefit remains."""
     FIELDS = ('images', 'K', 'TCO', 'bboxes')
 
     def __init__(self, batches, device=None, fields=FIELDS):
@@ -101,15 +104,28 @@ class DevicePrefetcher:
         self.batches, self.fields = batches, tuple(fields)
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device)
+        self._slots, self._free = [{}, {}], [None, None]
 
     def __len__(self):
         return len(self.batches)
 
-    def _upload(self, batch):
-        ready = torch.cuda.Event()
+    def _upload(self, batch, slot):
+        held, moved = self._slots[slot], {}
         with torch.cuda.stream(self.stream):
-            moved = {name: t.to(self.device, non_blocking=True) for name in self.fields
-                     for t in [getattr(batch, name, None)] if torch.is_tensor(t) and not t.is_cuda}
+            if self._free[slot] is not None:
+                self.stream.wait_event(self._free[slot])            # the step that read this slot's previous batch is through
+            for name in self.fields:
+                t = getattr(batch, name, None)
+                if not torch.is_tensor(t) or t.is_cuda:
+                    continue
+                buf = held.get(name)
+                if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+                    if buf is not None:
+                        buf.record_stream(torch.cuda.current_stream(self.device))
+                    buf = held[name] = torch.empty(t.shape, dtype=t.dtype, device=self.device)
+                buf.copy_(t, non_blocking=True)
+                moved[name] = buf
+            ready = torch.cuda.Event()
             ready.record(self.stream)
         if hasattr(batch, '_replace'):                 # a namedtuple batch
             return batch._replace(**moved), ready
@@ -121,22 +137,57 @@ class DevicePrefetcher:
     def __iter__(self):
         source = iter(self.batches)
         try:
-            ahead = self._upload(next(source))
+            ahead = self._upload(next(source), 0)
         except StopIteration:
             return
+        j = 0
         while ahead is not None:
             (batch, ready), ahead = ahead, None
+            consumer = torch.cuda.current_stream(self.device)
+            done = torch.cuda.Event()
+            done.record(consumer)                      # everything enqueued so far = every step up to j-1
+            self._free[(j + 1) % 2] = done
             try:
-                ahead = self._upload(next(source))     # enqueued BEFORE the consumer enqueues its step: runs beside it
+                ahead = self._upload(next(source), (j + 1) % 2)     # enqueued BEFORE the consumer enqueues step j: runs beside it
             except StopIteration:
                 pass
-            consumer = torch.cuda.current_stream(self.device)
             consumer.wait_event(ready)
-            for name in self.fields:                   # allocated on the copy stream, used on the consumer's: the caching allocator must
-                t = getattr(batch, name, None)         # not hand the block to the next upload while the step still reads it
-                if torch.is_tensor(t) and t.is_cuda:
-                    t.record_stream(consumer)
             yield batch
+            j += 1
+
+
+class LazyMeters(defaultdict):
+    """Meters (name -> object with .add(float)) that take values living on the device WITHOUT stopping the host: `defer` starts a
+    non-blocking copy into page-locked memory and the numbers are added, in order, once their copy has finished (checked at every
+    later `defer`, forced by `flush`).  h_pose uses `defer` when its `meters` has one: the reference's .item() calls in the middle of
+    the step (pose_forward_loss.py:74-83) make the host wait for the forward pass and the GPU then idle while the backward's first
+    kernels are being enqueued (~1 ms of a 33 ms step)."""
+
+    def __init__(self, factory=None, max_pending=64):
+        super().__init__(factory if factory is not None else _Mean)
+        self._pending, self.max_pending = [], max_pending
+
+    def defer(self, names, values):
+        """values: 1-D device tensor; names[i]: the meter names that receive values[i]"""
+        host = torch.empty(values.shape, dtype=values.dtype, pin_memory=True)
+        host.copy_(values.detach(), non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(values.device))
+        self._pending.append((names, host, done))
+        self._drain(force=len(self._pending) - self.max_pending)
+
+    def _drain(self, force=0):
+        while self._pending and (force > 0 or self._pending[0][2].query()):
+            names, host, done = self._pending.pop(0)
+            done.synchronize()
+            for keys, v in zip(names, host.tolist()):
+                for k in keys:
+                    self[k].add(v)
+            force -= 1
+
+    def flush(self):
+        self._drain(force=len(self._pending))
+        return self
 
 
 def checkpoint_path(save_dir):
@@ -165,11 +216,11 @@ def load_checkpoint(path_or_dir, model, strict=True):
 
 
 def train_loop(model, mesh_db, cfg, batches, n_epochs, save_dir=None, start_epoch=0, optimizer=None, on_epoch_end=None,
-               input_generator='fixed', faithful_schedule=True, prefetch=True):
+               input_generator='fixed', faithful_schedule=True, prefetch=True, lazy_meters=True):
     """Runs epochs [start_epoch, n_epochs) of the reference's training loop on `batches` (a callable epoch -> iterable of
     batch objects with images / K / TCO / objects / bboxes, or a re-iterable).  cfg: lr, weight_decay, n_epochs_warmup,
     lr_epoch_decay, clip_grad_norm, n_iterations (+ what h_pose needs).  prefetch: upload batch i+1 while step i runs
-    (DevicePrefetcher).  Returns {epoch: mean loss}."""
+    (DevicePrefetcher); lazy_meters: read the loss / gradient-norm values back without stopping the host (LazyMeters).  Returns {epoch: mean loss}."""
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     is_ddp = hasattr(model, 'module')
@@ -196,7 +247,7 @@ def train_loop(model, mesh_db, cfg, batches, n_epochs, save_dir=None, start_epoc
         if schedule is None:
             schedule = LRSchedule(cfg.lr, cfg.n_epochs_warmup, bpe or len(items), cfg.lr_epoch_decay, start_epoch=start_epoch, faithful=faithful_schedule)
         model.train()
-        meters = defaultdict(_Mean)
+        meters = LazyMeters(_Mean) if lazy_meters and torch.cuda.is_available() else defaultdict(_Mean)
         feed = DevicePrefetcher(items) if prefetch and torch.cuda.is_available() else items
         for b, sample in enumerate(feed):
             schedule.apply(optimizer, epoch, b)
@@ -207,13 +258,19 @@ def train_loop(model, mesh_db, cfg, batches, n_epochs, save_dir=None, start_epoc
             if flat:
                 if world > 1 and not is_ddp:
                     train_engine.allreduce_gradients(optimizer)      # collects detached .grad tensors first
-                meters['grad_norm'].add(float(optimizer.step()))
+                norm = optimizer.step()
+                if hasattr(meters, 'defer') and torch.is_tensor(norm) and norm.is_cuda:
+                    meters.defer([('grad_norm',)], norm.reshape(1))         # read back when it is there: the host goes on to the next step
+                else:
+                    meters['grad_norm'].add(float(norm))
             else:
                 params = (model.module if is_ddp else model).parameters()
                 meters['grad_norm'].add(float(torch.nn.utils.clip_grad_norm_(params, max_norm=cfg.clip_grad_norm, norm_type=2)))
                 optimizer.step()
             schedule.after_batch(epoch)
         schedule.after_epoch(epoch)
+        if hasattr(meters, 'flush'):
+            meters.flush()
         history[epoch] = meters['loss_total'].mean
         if save_dir is not None and (not dist.is_initialized() or dist.get_rank() == 0):
             save_checkpoint(model, epoch, save_dir)

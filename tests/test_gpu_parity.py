@@ -1355,6 +1355,56 @@ def test_se_train_kernels_vs_torch_fp64(B, C, Cse):
         assert rel(a, b.double()) < 2e-6
 
 
+def test_prefetcher_and_lazy_meters_change_nothing(golden_sd):
+    """training.DevicePrefetcher (batch j+1 uploaded on a copy stream into one of two persistent slots while step j runs) and
+    training.LazyMeters (loss values read back without stopping the host) are scheduling only: the batches arrive complete, in order and
+    intact although the host runs ahead of the device, and train_loop with both gives the same loss history and the same weights, bit for
+    bit, as with the reference's order (upload at the top of the step, .item() in the middle)."""
+    import argparse, types
+    from cosypose_amd import training, train_engine
+    # 1. the prefetcher under a consumer that keeps the device busy and never synchronises
+    host = [types.SimpleNamespace(images=torch.full((4, 64, 64, 3), j, dtype=torch.uint8).pin_memory(), K=torch.full((4, 3, 3), float(j)).pin_memory(),
+                                  TCO=torch.full((4, 4, 4), float(-j)), bboxes=torch.full((4 + (j == 5), 4), 2.0 * j), objects=[j]) for j in range(9)]
+    sink, acc = [], torch.zeros((), device='cuda')
+    busy = torch.randn(2048, 2048, device='cuda')
+    for j, b in enumerate(training.DevicePrefetcher(host)):
+        assert b.images.is_cuda and b.K.is_cuda and b.TCO.is_cuda and b.bboxes.is_cuda and b.objects == [j] and not host[j].images.is_cuda
+        for _ in range(3):
+            acc = acc + (busy * busy).sum() * 0          # the step: queued work the upload of j+1 must not overtake into j-1's slot
+        sink.append(torch.stack([b.images.float().mean(), b.K.mean(), b.TCO.mean(), b.bboxes.mean(), b.images.float().min(), b.images.float().max()]) + acc)
+    got = torch.stack(sink).cpu()
+    want = torch.tensor([[j, j, -j, 2.0 * j, j, j] for j in range(9)], dtype=torch.float32)
+    assert torch.equal(got, want)
+    # 2. the loop with and without them
+    B = 2
+    cfg = argparse.Namespace(n_points_loss=600, loss_disentangled=True, n_pose_dims=9, init_method='v0', lr=3e-4, weight_decay=0.0,
+                             n_epochs_warmup=1, lr_epoch_decay=1, clip_grad_norm=0.5, n_iterations=1)
+
+    def batches(epoch):
+        out = []
+        for b in range(3):
+            frames, K, TCO, obj = syn.make_training_batch(300 + 10 * epoch + b, B)
+            rs = np.random.RandomState(epoch * 7 + b)
+            xy = rs.uniform(150, 300, (B, 2)); wh = rs.uniform(80, 160, (B, 2))
+            out.append(types.SimpleNamespace(images=torch.from_numpy(frames).pin_memory(), K=torch.from_numpy(K), TCO=torch.from_numpy(TCO),
+                                             objects=[dict(name=f'obj_{int(o) + 1:06d}') for o in obj],
+                                             bboxes=torch.from_numpy(np.concatenate([xy, xy + wh], 1).astype(np.float32))))
+        return out
+    runs = []
+    for prefetch in (True, False):
+        model, mesh_db, _ = _train_model(golden_sd)
+        model.drop_connect_rate = 0.0
+        np.random.seed(0)
+        seen = []
+        hist = training.train_loop(model, mesh_db, cfg, batches, n_epochs=2, prefetch=prefetch, lazy_meters=prefetch,
+                                   on_epoch_end=lambda e, m: seen.append(dict(m)))
+        runs.append((hist, seen, {n: p.detach().clone() for n, p in model.named_parameters()}))
+    (h1, m1, w1), (h2, m2, w2) = runs
+    assert h1 == h2 and m1 == m2 and set(m1[0]) >= {'loss_total', 'loss_TCO', 'loss_TCO-iter=1', 'grad_norm'}
+    for n in w1:
+        assert torch.equal(w1[n], w2[n]), n
+
+
 def test_training_loop_checkpoint_and_resume(tmp_path, golden_sd):
     """the loop around the step (cosypose/training/train_pose.py:282-343): warm-up ramp + step decay applied to
     the optimizer, one reference-format checkpoint per epoch ({'state_dict', 'epoch'}, loadable strict=True into the
