@@ -170,6 +170,19 @@ _id_cache = _collections.OrderedDict()       # (device index, shape, bytes) -> i
 _ID_CACHE_ENTRIES, _ID_CACHE_MAX_BYTES = 64, 64 << 10
 
 
+def host_to_device(values, device, dtype=None):
+    """numpy array / CPU tensor -> device tensor through page-locked memory and a non-blocking copy: the host does not wait for the
+    kernels already queued on the stream (torch's .to(device) of pageable memory does)."""
+    import numpy as np
+    import torch
+    host = values if isinstance(values, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(values))
+    if dtype is not None:
+        host = host.to(dtype)
+    if torch.device(device).type == 'cpu' or host.numel() == 0 or host.device.type != 'cpu':
+        return host.to(device)
+    return host.pin_memory().to(device, non_blocking=True)
+
+
 def ints_to_device(values, device):
     """int32 device tensor from host ids (list / numpy / CPU tensor) without draining the stream: the ids go through
     pinned memory and a non-blocking copy, so the host keeps running ahead of the GPU (a pageable H2D copy would wait

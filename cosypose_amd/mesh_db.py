@@ -26,7 +26,8 @@ def sample_points(points, n_points, deterministic=False):
     assert points.dim() == 3
     assert n_points <= points.shape[1]
     rng = np.random.RandomState(0) if deterministic else np.random
-    ids = torch.as_tensor(rng.choice(points.shape[1], size=n_points, replace=False)).to(points.device)
+    from ._lib import host_to_device
+    ids = host_to_device(rng.choice(points.shape[1], size=n_points, replace=False), points.device)      # no wait for the queued kernels
     return torch.index_select(points, 1, ids)
 
 
@@ -61,8 +62,11 @@ class BatchedMeshes(TensorCollection):
 
     def select(self, labels):
         ids = [self.label_to_id[l] for l in labels]
+        # rows gathered with device-resident ids (cached upload, _lib.ints_to_device): indexing with the Python list would copy it to the
+        # device synchronously, i.e. stop the host until every kernel queued so far has run -- once per training step
+        rows = self.object_ids(labels).long() if self.points.is_cuda and len(ids) else torch.as_tensor(ids, dtype=torch.long, device=self.points.device)
         return Meshes(infos=[self.infos[l] for l in labels], labels=self.labels[ids],
-                      points=self.points[ids], symmetries=self.symmetries[ids])
+                      points=torch.index_select(self.points, 0, rows), symmetries=torch.index_select(self.symmetries, 0, rows))
 
     # ---- device-side fast path -------------------------------------------------------------
     def object_ids(self, labels, device=None):

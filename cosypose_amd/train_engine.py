@@ -277,6 +277,9 @@ def param_names():
     return names
 
 
+_keep_prob = {}
+
+
 def make_drop_connect_scales(B, device, rate=DROP_CONNECT_RATE, generator=None):
     """{block index: (B,) mask/keep_prob} as drop_connect draws them (efficientnet_utils.py:83-92): blocks with a skip
     connection only, rate scaled by idx/26 (efficientnet.py:182-185)."""
@@ -285,7 +288,10 @@ def make_drop_connect_scales(B, device, rate=DROP_CONNECT_RATE, generator=None):
         return out
     n = len(arch.B3_BLOCKS)
     ids = [i for i, (k, s, e, cin, cout) in enumerate(arch.B3_BLOCKS) if s == 1 and cin == cout and rate * float(i) / n]
-    keep = torch.tensor([1.0 - rate * float(i) / n for i in ids], device=device).unsqueeze(1)
+    key = (torch.device(device), float(rate))
+    keep = _keep_prob.get(key)
+    if keep is None:       # uploaded once: torch.tensor(..., device=) is a synchronous copy that stops the host until the queued kernels have run
+        keep = _keep_prob[key] = torch.tensor([1.0 - rate * float(i) / n for i in ids], device=device).unsqueeze(1)
     scales = torch.floor(keep + torch.rand(len(ids), B, device=device, generator=generator)) / keep      # all blocks at once
     for j, i in enumerate(ids):
         out[i] = scales[j]
@@ -460,20 +466,49 @@ class _BackboneTrainFn(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads[n] for n in ctx.names)
 
 
-def backbone_train(model, x8, drop=None):
-    """pose outputs (B,9) of `model` (a PosePredictor) in train mode for the packed NHWC8 fp32 input `x8`, attached to
-    the autograd graph of the model's parameters.  BatchNorm running statistics are updated in place."""
-    require_device(x8)
+_registrations = [0]        # bumped whenever ANY module registers a parameter / buffer / submodule: the cached name tables are re-read
+
+
+def _count_registration(*args):
+    _registrations[0] += 1
+
+
+for _hook in ('register_module_parameter_registration_hook', 'register_module_buffer_registration_hook',
+              'register_module_module_registration_hook'):
+    getattr(torch.nn.modules.module, _hook)(_count_registration)
+
+
+def _named_tensors(model):
+    """(reference parameter names, the model's parameters in that order, its named buffers).  Walking the ~300 submodules for
+    named_parameters() + named_buffers() costs ~1 ms of host time per step during which the GPU has nothing queued; the Parameter and
+    buffer OBJECTS only change through a registration on some module (global hooks above), so the tables are kept until one happens
+    (in-place updates, .data re-pointing and load_state_dict keep the objects; a device / dtype move of the module is caught by sentinels)."""
+    cached = model.__dict__.get('_cosy_named_tensors')
+    if cached is not None and cached[0] == _registrations[0]:
+        _, names, params, buffers = cached
+        # Module._apply (.cuda() / .to() / .float()) swaps buffer objects without a registration: two sentinels catch it
+        first, last = next(iter(buffers)), next(reversed(buffers))
+        if model.get_buffer(first) is buffers[first] and model.get_buffer(last) is buffers[last] and model.get_parameter(names[-1]) is params[-1]:
+            return names, params, buffers
     names = param_names()
     named = dict(model.named_parameters())
     missing = [n for n in names if n not in named]
     if missing or len(named) != len(names):
         raise ValueError(f'model parameters do not match the efficientnet-b3 pose network ({len(named)} vs {len(names)}; missing {missing[:3]})')
     params = [named[n] for n in names]
+    buffers = dict(model.named_buffers())
+    model.__dict__['_cosy_named_tensors'] = (_registrations[0], names, params, buffers)
+    return names, params, buffers
+
+
+def backbone_train(model, x8, drop=None):
+    """pose outputs (B,9) of `model` (a PosePredictor) in train mode for the packed NHWC8 fp32 input `x8`, attached to
+    the autograd graph of the model's parameters.  BatchNorm running statistics are updated in place."""
+    require_device(x8)
+    names, params, buffers = _named_tensors(model)
     for p_ in params:
         if p_.dtype != torch.float32 or not p_.is_contiguous():
             raise ValueError('training runs on contiguous fp32 parameters')
-    buffers = dict(model.named_buffers())
     direct = getattr(model, '_cosy_flat_adam', None)
     if direct is not None and not (direct.direct_grads and direct.owns(params)):
         direct = None
