@@ -24,8 +24,8 @@ sys.path.insert(0, REPO)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--kernels', action='store_true', help='per-kernel table from torch.profiler to stderr')
     ap.add_argument('--upload', choices=('prefetch', 'in_step'), default='prefetch',

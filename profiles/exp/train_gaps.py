@@ -22,7 +22,7 @@ print('gpu events', len(k))
 adam = [i for i, e in enumerate(k) if 'adam_kernel' in e['name']]
 print('adam launches', len(adam))
 if len(adam) >= 3:
-    a, b = adam[-3], adam[-2]          # one steady-state step: from the end of one adam to the end of the next
+    a, b = adam[3], adam[4]            # one step of the un-synchronised timed loop (2 warm-up + 4 timed steps, then 3 event-timed ones): from the end of one adam to the end of the next
     seg = k[a:b + 1]
     t0, t1 = seg[0]['ts'] + seg[0]['dur'], seg[-1]['ts'] + seg[-1]['dur']
     busy = sum(e['dur'] for e in seg[1:])
