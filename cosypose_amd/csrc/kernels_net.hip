@@ -60,8 +60,12 @@ PwCfg pw_choose_cfg_late(int K, int N, int HW, bool gated) {
     // A 128 x 256 full-N tile (A read once, 128 workgroups) took 65 us for block 19: what bounds these layers is the LDS-DMA rate of ONE CU
     // (~25 GB/s: 32 KB per 1.3 us interval here, 16 KB per 0.75 us with 8 waves), not a chip-wide byte count -- fewer, larger tiles lose.
     static const int pw16 = tune_int("COSY_PW16", 1);
-    if (pw16 && gated && K >= 1024 && HW % 64 == 0 && N >= 192) return N > 256 && N <= 384 ? PwCfg{3, 4, 16, 2} : PwCfg{2, 4, 16, 2};
-    if (pw8 && K >= 128 && N >= 192 && (!gated || HW % 64 == 0)) return PwCfg{2, 4, 8};
+    // Maps whose pixel count is not a multiple of 64 (240x320 crops: 8x10, 15x20, ...) take the row-side gate.  Measured there (256 crops, fp16,
+    // profiles/r04_rowgate_tiles.txt): the split-K tile loses (blocks 19-23 51 -> 58 us, 24 / 25 51 / 79 -> 74 / 109); the 8-wave tile wins for
+    // N = 384 (blocks 24 / 25: 51 / 79 -> 47 / 74 us); N <= 256 goes to the 4-wave tile with 32 rows per wave (pw_mi below), which wins more.
+    static const int pw16_rg = tune_int("COSY_PW16_RG", 0), pw8_rg = tune_int("COSY_PW8_RG", 1);
+    if (pw16 && gated && K >= 1024 && (HW % 64 == 0 || pw16_rg) && N >= 192) return N > 256 && N <= 384 ? PwCfg{3, 4, 16, 2} : PwCfg{2, 4, 16, 2};
+    if (pw8 && K >= 128 && N >= 192 && (!gated || HW % 64 == 0 || (pw8_rg && N > 256))) return PwCfg{2, 4, 8};
     static const int wide = tune_int("COSY_PW_WIDE", 1);
     if (wide && K >= 96 && HW >= 64 && N > 128 && N <= 160) return PwCfg{5, 2};
     return pw_choose_cfg(N);
@@ -489,16 +493,21 @@ static int launch_pw_dma_mi(PwKArgs k, hipStream_t s) {
     return COSY_OK;
 }
 // MI = 16-row blocks per wave: 4 (64 rows) by default; 2 halves the accumulators (-> more resident workgroups)
-static int pw_mi(const PwKArgs& k) {
-    static const int mi = tune_int("COSY_PW_MI", 4);
-    return (mi == 2 && k.nkb_valid > 2 && (!k.gate || k.HW % 64 == 0)) ? 2 : 4;
+static int pw_mi_for(bool gated, int HW, int nkb, int N, int elem_bytes) {
+    static const int mi = tune_int("COSY_PW_MI", 4), mi_rg = tune_int("COSY_PW_MI_RG", 1);
+    // Row-side gate (pixel count of the map not a multiple of 64) with 128 <= N <= 256, 16-bit types: 32 rows per wave.  The tile count doubles and
+    // a workgroup holds half the accumulators, so more of them are resident: at 240x320 / 256 crops the 600 m-tiles of blocks 13-17 (two rounds on
+    // 512 slots, the second 17 % full) become 1200 small ones, 69 -> 58 us; blocks 18-23 (320 tiles for 256 CUs) 51 -> 42 us.  N = 96 (blocks 8-12)
+    // and N = 384 (blocks 24 / 25) lose with it (34 -> 37, 51 / 79 -> 59 / 101 us) and keep 64 rows per wave (profiles/r04_rowgate_tiles.txt).
+    if (mi_rg && elem_bytes == 2 && gated && HW % 64 != 0 && nkb > 2 && N >= 128 && N <= 256) return 2;
+    return (mi == 2 && nkb > 2 && (!gated || HW % 64 == 0)) ? 2 : 4;
 }
 template <typename T, int NI, int WN, bool GATE, int NS>
 static int launch_pw_dma_ns(const PwKArgs& k, int grid, hipStream_t s) {
     (void)grid;
-    if (pw_mi(k) == 2) {
+    if (pw_mi_for(k.gate != nullptr, k.HW, k.nkb_valid, k.N, (int)sizeof(T)) == 2) {
         if constexpr (!GATE) return launch_pw_dma_mi<T, NI, WN, GATE, NS, 2>(k, s);
-        else if (k.HW % 32 == 0 && k.HW >= 64) return launch_pw_dma_mi<T, NI, WN, GATE, NS, 2>(k, s);
+        else if ((k.HW % 32 == 0 && k.HW >= 64) || k.HW % 64 != 0) return launch_pw_dma_mi<T, NI, WN, GATE, NS, 2>(k, s);
     }
     if constexpr (GATE && NS == 3 && NI >= 3) {       // the fused blocks' project GEMMs: >= 3 k-blocks (Cmid >= 96), tiles of >= 48 columns
         if (k.se_wr) return launch_pw_dma_mi<T, NI, WN, GATE, NS, 4, 4, 1, true>(k, s);
@@ -520,7 +529,7 @@ static int launch_pw_dma(const PwKArgs& k, PwCfg c, int grid, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {   // 8-wave tiles of the late layers: 2 waves per SIMD take turns on the matrix pipe
         if (c.WV == 16) {        // in-workgroup split-K (KG = 2): the K >= 1024 project convs of the 8x8 maps
             if constexpr (GATE) {
-                if (k.nkb_valid > 4 && k.HW % 64 == 0 && c.KG == 2 && c.WN == 4) {
+                if (k.nkb_valid > 4 && (k.HW % 64 == 0 || tune_int("COSY_PW16_RG", 0)) && c.KG == 2 && c.WN == 4) {
                     if (c.NI == 2) return launch_pw_dma_mi<T, 2, 4, GATE, 3, 4, 16, 2>(k, s);
                     if (c.NI == 3) return launch_pw_dma_mi<T, 3, 4, GATE, 3, 4, 16, 2>(k, s);
                 }
@@ -529,7 +538,7 @@ static int launch_pw_dma(const PwKArgs& k, PwCfg c, int grid, hipStream_t s) {
             return COSY_EINVAL;
         }
         if (c.WV == 8) {
-            const bool wave_gate = !GATE || (k.HW % 64 == 0);    // weight-side gate needs a wave's 64 rows inside one sample
+            const bool wave_gate = true;    // the weight-side gate needs a wave's 64 rows inside one sample (HW % 64 == 0); other maps take the row-side gate (k.rowgate)
             if (k.nkb_valid > 2 && wave_gate) {
                 if (c.NI == 2 && c.WN == 4) return launch_pw_dma_mi<T, 2, 4, GATE, 3, 4, 8>(k, s);
             }
@@ -581,8 +590,7 @@ static const char* tname(int dtype) { return dtype == COSY_F32 ? "float" : dtype
 void pw_kernel_name(const PwArgs& a, PwCfg c, int dtype, char* buf, size_t n) {
     const int nkb = cdiv(a.K, pw_kb(dtype));
     static const int deep = tune_int("COSY_PW_NS", 3);
-    static const int mi_env = tune_int("COSY_PW_MI", 4);
-    const int mi = (mi_env == 2 && nkb > 2 && (!a.gate || a.HW % 64 == 0)) ? 2 : 4;
+    const int mi = pw_mi_for(a.gate != nullptr, a.HW, nkb, a.N, dtype == COSY_F32 ? 4 : 2);
     if (c.WV == 16) snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, 3, %s, 4, 16, %d>", tname(dtype), c.NI, c.WN, a.gate ? "true" : "false", c.KG);
     else if (c.WV == 8) snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, 3, %s, 4, 8>", tname(dtype), c.NI, c.WN, a.gate ? "true" : "false");
     else snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, %d, %s, %d>", tname(dtype), c.NI, c.WN,

@@ -444,6 +444,17 @@ __global__ __launch_bounds__(1024) void combine_partials_kernel(const PT* __rest
     double acc = 0.;
     if (j < n) {
         int k = wave;
+        // 16 loads in flight per lane: the pass is a chain of dependent memory round trips (~1 us each), not bytes -- with 4 in flight the
+        // 256 slabs of a weight gradient were 4 rounds per wave (11 us per launch, 52 launches per step)
+        for (; k + 240 < nslab; k += 256) {
+            PT a[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a[u] = partial[(size_t)(k + 16 * u) * n + j];
+            double t[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = ((double)a[4 * q] + (double)a[4 * q + 1]) + ((double)a[4 * q + 2] + (double)a[4 * q + 3]);
+            acc += (t[0] + t[1]) + (t[2] + t[3]);
+        }
         for (; k + 48 < nslab; k += 64) {   // 4 loads in flight
             const double a0 = partial[(size_t)k * n + j], a1 = partial[(size_t)(k + 16) * n + j];
             const double a2 = partial[(size_t)(k + 32) * n + j], a3 = partial[(size_t)(k + 48) * n + j];
@@ -471,6 +482,18 @@ __device__ __forceinline__ void combine2_(const double* __restrict__ partial, in
     double a0 = 0., a1 = 0.;
     if (c < C) {
         int k = wave;
+        for (; k + 240 < nslab; k += 256) {        // 32 loads in flight: up to 1024 slabs are 4 rounds of dependent memory latency per wave instead of 16
+            double p0[16], p1[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { p0[u] = partial[((size_t)(k + 16 * u) * 2) * C + c]; p1[u] = partial[((size_t)(k + 16 * u) * 2 + 1) * C + c]; }
+            double t0[4], t1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                t0[q] = (p0[4 * q] + p0[4 * q + 1]) + (p0[4 * q + 2] + p0[4 * q + 3]);
+                t1[q] = (p1[4 * q] + p1[4 * q + 1]) + (p1[4 * q + 2] + p1[4 * q + 3]);
+            }
+            a0 += (t0[0] + t0[1]) + (t0[2] + t0[3]); a1 += (t1[0] + t1[1]) + (t1[2] + t1[3]);
+        }
         for (; k + 48 < nslab; k += 64) {          // 8 loads in flight
             double p0[4], p1[4];
 #pragma unroll
