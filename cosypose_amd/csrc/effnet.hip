@@ -70,6 +70,12 @@ struct Block {
     float *b0_fold, *dw_w_fold;   // small kernel: log2(e) * BN0 bias; taps * BN1 scale * ln 2 (the BN0 scale is inside exp_wp_fused)
     bool se_batched;      // squeeze-excite as two batched GEMM kernels (late blocks) instead of one workgroup per sample
     bool se_fused;        // squeeze-excite inside the project GEMM's prologue: no launch of its own (blocks with small FC matrices)
+    // Pixel order of the block's tensors inside a sample: row-major (y * W + x) or column-major (x * H + y).  A resolution stage whose wave
+    // kernels all walk the map's COLUMNS (240x320 crops: 30x40 and 15x20 maps -- 15 / 30 pixels fill 16 / 32 lanes, 20 / 40 do not) is stored
+    // column-major from the D of its stride-2 entry block on, so that those walks read and write contiguous runs; 1x1 convolutions, squeeze-excite
+    // and residuals do not care about the order.  in_col: the block input X; out_col: D and the block output; to_rowmajor: the last block of
+    // such a stage when what follows cannot read column-major -- its output goes through one re-ordering copy (launch_pixels_to_rowmajor).
+    bool in_col, out_col, to_rowmajor;
     float *se_wr_p, *se_br_p, *se_we_p;   // zero-padded copies for the batched form: (CseP, Cmid), (CseP), (Cmid, CseP)
 };
 
@@ -125,6 +131,7 @@ static void fold_bn(const float* bn, int C, int Cpad, std::vector<float>& scale,
 }
 
 // One pass = sizing (bump.base == nullptr) or filling.  Returns the number of blob floats consumed.
+static void plan_pixel_order(cosy_net* n);
 static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hipError_t* herr) {
     const float* p0 = p;
     auto up_f32 = [&](const std::vector<float>& v) -> float* {
@@ -281,6 +288,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         h = b.Ho; w_ = b.Wo;
     }
     n->Hf = h; n->Wf = w_;
+    plan_pixel_order(n);
     mk_pw(n->head, p, HEAD_IN, HEAD_C, p + (size_t)HEAD_C * HEAD_IN, n->Hf * n->Wf, false);
     p += (size_t)HEAD_C * HEAD_IN + 4 * HEAD_C;
     {
@@ -290,6 +298,30 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         n->fc_w = up_f32(fw); n->fc_b = up_f32(fb);
     }
     return (long)(p - p0);
+}
+
+// Which resolution stages are stored column-major (Block::in_col / out_col / to_rowmajor).  Measured at 240x320 crops, 256 per forward, fp16
+// (knock-out timing, profiles/r04_colmajor_stages.txt): with row-major storage the column walks' strided input loads and output stores cost
+// 24-41 % of blocks 8-12 and 20-25 % of blocks 14-17 (the arithmetic alone scales with the pixel count: x1.25 against 256x256 crops, the kernels x1.5-1.66).
+static void plan_pixel_order(cosy_net* n) {
+    for (int i = 0; i < 26; ++i) n->blk[i].in_col = n->blk[i].out_col = n->blk[i].to_rowmajor = false;
+    static const int allow = tune_int("COSY_COLMAJOR", 1);
+    if (!allow) return;
+    for (int e = 0; e < 26; ++e) {
+        if (n->blk[e].d.s != 2 || !n->blk[e].wave) continue;          // the entry of a stage: a wave block writes its D in any order
+        int l = e;
+        while (l + 1 < 26 && n->blk[l + 1].d.s == 1) ++l;
+        bool all = l > e;
+        for (int i = e + 1; i <= l && all; ++i) {
+            const Block& b = n->blk[i];
+            all = b.wave && wave_walks_columns(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
+        }
+        if (!all) continue;
+        for (int i = e; i <= l; ++i) n->blk[i].out_col = true;
+        for (int i = e + 1; i <= l; ++i) n->blk[i].in_col = true;
+        if (l + 1 < 26 && n->blk[l + 1].wave) n->blk[l + 1].in_col = true;      // the next stage's entry reads column-major as well as anything
+        else n->blk[l].to_rowmajor = true;
+    }
 }
 
 enum { EARLY_BLOCKS = 9 };  // stem + blocks 0..8 (feature maps >= 32x32 at 256^2) form the "early" segment
@@ -308,6 +340,7 @@ static void layout_ws(cosy_net* n, Bump& b, cosy_net::WS& w, size_t B) {
         act = std::max(act, (size_t)k.Ho * k.Wo * k.d.cout);
         if (i == EARLY_BLOCKS - 1) act_l = std::max(act_l, (size_t)k.Ho * k.Wo * k.d.cout);  // hand-over tensor
         if (k.d.e != 1 && !k.fused) ex = std::max(ex, (size_t)k.H * k.W * k.cmid);
+        if (k.to_rowmajor) ex = std::max(ex, (size_t)k.Ho * k.Wo * k.d.cout);      // the project GEMM writes there, the re-ordering copy into the output
         dw = std::max(dw, (size_t)k.Ho * k.Wo * k.cmid);
         part = std::max(part, (size_t)k.n_tiles * k.cmid * (early ? Bc : B));
         gate = std::max(gate, (size_t)k.cmid);
@@ -360,15 +393,15 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
     char kn[64];
     auto pw_name = [&](const PwLayer& L, const PwArgs& a) { pw_kernel_name(a, L.cfg, n->dtype, kn, sizeof(kn)); };
     auto pw_bytes = [&](const PwArgs& a, int Bc) { return ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N * (a.res ? 2 : 1)) * esz_d + (a.gate ? (double)Bc * a.K * 4 : 0); };
-    auto tap = [&](const void* act, int Bc, int b0, int HW, int C, int idx) -> int {
+    auto tap = [&](const void* act, int Bc, int b0, int HW, int C, int idx, int colH = 0) -> int {
         if (!taps) return COSY_OK;
-        return launch_taps(act, Bc, HW, C, n->dtype, taps + (size_t)b0 * 9 * 16, idx, s);
+        return launch_taps(act, Bc, HW, C, n->dtype, taps + (size_t)b0 * 9 * 16, idx, s, colH);
     };
     // test probe: the whole activation `layer` as fp32 NCHW (layer -1 stem, 0..25 block outputs, 26 head, 100+i depthwise output
     // D of block i, 200+i SE gate of block i as (B, Cmid))
-    auto probe = [&](int layer, const void* act, int Bc, int b0, int HW, int C, int chunked) -> int {
+    auto probe = [&](int layer, const void* act, int Bc, int b0, int HW, int C, int chunked, int colH = 0) -> int {
         if (n->probe_layer != layer || !n->probe_out) return COSY_OK;
-        return launch_nhwc_to_nchw(act, Bc, HW, C, n->dtype, n->probe_out + (size_t)b0 * HW * C, s, chunked);
+        return launch_nhwc_to_nchw(act, Bc, HW, C, n->dtype, n->probe_out + (size_t)b0 * HW * C, s, chunked, colH);
     };
     // one MBConv block on Bc samples: [expand 1x1] -> depthwise (+squeeze partials) -> SE gate -> project 1x1 (+residual)
     auto run_block = [&](int i, const void* in, void* out, int Bc, void* Ebuf, void* Dbuf, int b0) -> int {
@@ -382,6 +415,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
             else { f.s0 = b.exp.scale; f.b0 = b.exp.bias; f.dww = b.dw_w; f.s1 = b.dw_scale; f.b1 = b.dw_bias; f.wparams = b.wave_params; }
             f.D = Dbuf; f.partial = w.partial; f.zeros = n->zeros;
             f.B = Bc; f.H = b.H; f.W = b.W; f.Cin = b.d.cin; f.Cmid = b.cmid; f.Ho = b.Ho; f.Wo = b.Wo; f.k = b.d.k; f.s = b.d.s; f.pad_lo = b.pad_lo;
+            f.x_colmajor = b.in_col; f.d_colmajor = b.out_col;
             if ((rc = b.wave ? launch_mbconv_wave(f, n->dtype, &se_tiles, s) : b.tiled ? launch_mbconv_tile(f, n->dtype, s) : launch_mbconv_small(f, n->dtype, s))) return rc;
             if (b.wave) wave_kernel_name(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W, kn, sizeof(kn));
             else if (b.tiled) tile_kernel_name(b.d.cin, b.d.k, b.d.s, n->dtype, kn, sizeof(kn));
@@ -424,18 +458,22 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
                            4.0 * Bc * b.cse * b.cmid, 2.0 * b.cse * b.cmid * 4))) return rc;
         }
         PwArgs a{};
-        a.A = Dbuf; a.Wp = b.proj.Wp; a.out = out; a.scale = b.proj.scale; a.bias = b.proj.bias;
+        a.A = Dbuf; a.Wp = b.proj.Wp; a.out = b.to_rowmajor ? Ebuf : out; a.scale = b.proj.scale; a.bias = b.proj.bias;
         a.res = b.skip ? in : nullptr; a.gate = w.gate; a.se_fused = b.se_fused ? &se : nullptr;
         a.M = Bc * b.Ho * b.Wo; a.K = b.cmid; a.N = b.d.cout; a.HW = b.Ho * b.Wo; a.silu = 0; a.zeros = n->zeros;
         // the wave front (and the row-mapped 8x8 kernel) write D as [sample][Cmid/16][HW][16]
         a.a_chunked = b.wave || (b.small && small_writes_chunked(b.d.cin, b.cmid, b.H, b.W, b.Ho, b.Wo, b.d.k, b.d.s, n->dtype));
-        if ((rc = probe(100 + i, Dbuf, Bc, b0, b.Ho * b.Wo, b.cmid, a.a_chunked))) return rc;
+        if ((rc = probe(100 + i, Dbuf, Bc, b0, b.Ho * b.Wo, b.cmid, a.a_chunked, b.out_col ? b.Ho : 0))) return rc;
         if ((rc = launch_pw_gemm(a, b.proj.cfg, n->dtype, s))) return rc;
         if (n->probe_layer == 200 + i && n->probe_out)      // behind the GEMM: with the squeeze-excite in its prologue that is where the gate is written
             COSY_CHECK_HIP(hipMemcpyAsync(n->probe_out + (size_t)b0 * b.cmid, w.gate, (size_t)Bc * b.cmid * sizeof(float), hipMemcpyDeviceToDevice, s));
         pw_name(b.proj, a);
         if ((rc = mark(kn, i, pw_bytes(a, Bc), 2.0 * a.M * a.K * a.N, ((double)a.K * a.N + (double)a.M * a.N * (a.res ? 2 : 1)) * esz_d))) return rc;
-        return probe(i, out, Bc, b0, b.Ho * b.Wo, b.d.cout, 0);
+        if (b.to_rowmajor) {
+            if ((rc = launch_pixels_to_rowmajor(Ebuf, out, Bc, b.Ho, b.Wo, b.d.cout, n->dtype, s))) return rc;
+            if ((rc = mark("pixels_to_rowmajor_kernel", i, 2.0 * Bc * b.Ho * b.Wo * b.d.cout * esz_d, 0.0, 0.0))) return rc;
+        }
+        return probe(i, out, Bc, b0, b.Ho * b.Wo, b.d.cout, 0, b.out_col && !b.to_rowmajor ? b.Ho : 0);
     };
     auto stage_tap_index = [&](int i) -> int { for (int q = 0; q < 7; ++q) if (STAGE_END[q] == i) return q + 1; return -1; };
 
@@ -459,7 +497,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
             if ((rc = run_block(i, w.actc[cur], out, Bc, w.Ec, w.Dc, b0))) return rc;
             cur ^= 1;
             const int ti = stage_tap_index(i);
-            if (ti >= 0 && (rc = tap(out, Bc, b0, b.Ho * b.Wo, b.d.cout, ti))) return rc;
+            if (ti >= 0 && (rc = tap(out, Bc, b0, b.Ho * b.Wo, b.d.cout, ti, b.out_col && !b.to_rowmajor ? b.Ho : 0))) return rc;
         }
     }
     // ---- late segment, full batch
@@ -469,7 +507,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         if ((rc = run_block(i, w.act[cur], w.act[cur ^ 1], B, w.E, w.D, 0))) return rc;
         cur ^= 1;
         const int ti = stage_tap_index(i);
-        if (ti >= 0 && (rc = tap(w.act[cur], B, 0, b.Ho * b.Wo, b.d.cout, ti))) return rc;
+        if (ti >= 0 && (rc = tap(w.act[cur], B, 0, b.Ho * b.Wo, b.d.cout, ti, b.out_col && !b.to_rowmajor ? b.Ho : 0))) return rc;
     }
     PwArgs a{};
     a.A = w.act[cur]; a.Wp = n->head.Wp; a.out = w.Hd; a.scale = n->head.scale; a.bias = n->head.bias;

@@ -67,6 +67,9 @@ struct FuseArgs {
     float* partial;      // (B, n_tiles, Cmid)
     const void* zeros;
     int B, H, W, Cin, Cmid, Ho, Wo, k, s, pad_lo;
+    // wave kernel only: pixel order of the block input X / of D inside a sample.  0 = row-major (y * W + x); 1 = column-major (x * H + y): the whole
+    // resolution stage is stored transposed so that a wave that walks the map's columns (wave_walks_columns) reads and writes contiguous runs
+    int x_colmajor, d_colmajor;
 };
 // tiled variant (LDS tile per workgroup) for high-resolution blocks whose row width the wave kernel is not built for
 bool tile_supported(int Cin, int Cmid, int k, int s, int dtype);
@@ -81,6 +84,7 @@ bool small_writes_chunked(int Cin, int Cmid, int H, int W, int Ho, int Wo, int k
 // wave-autonomous variant (kernels_wave.hip): expanded rows in registers, no LDS ring / barriers; expand weights packed with
 // PwCfg{1,1} (16-channel tiles, natural row order); partial has ONE tile per sample
 bool wave_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W);
+bool wave_walks_columns(int Cin, int Cmid, int k, int s, int dtype, int H, int W);   // the job's rows are the map's columns (transposed walk)
 size_t wave_params_floats(int Cmid, int k);
 void wave_pack_params(const float* s0, const float* b0, const float* dww, const float* s1, const float* b1, int Cin, int Cmid, int k, int s,
                       int dtype, int H, int W, float* dst);
@@ -110,8 +114,11 @@ int launch_stem(const void* x_nhwc8, const void* w_packed, const float* scale, c
                 int B, int H, int W, int Ho, int Wo, int dtype, hipStream_t s);
 int launch_pool_fc(const void* head /*(B,HW,1536)*/, const float* fc_w /*(9,1536)*/, const float* fc_b, float* feat_or_null,
                    float* feat_scratch, float* pose, int B, int HW, int dtype, hipStream_t s);
-int launch_nhwc_to_nchw(const void* act /*(B,HW,C)*/, int B, int HW, int C, int dtype, float* out, hipStream_t s, int chunked = 0);
+// colH > 0: the activation's pixels are stored column-major (x * colH + y, colH = the map's height); the probes index them row-major
+int launch_nhwc_to_nchw(const void* act /*(B,HW,C)*/, int B, int HW, int C, int dtype, float* out, hipStream_t s, int chunked = 0, int colH = 0);
 int launch_taps(const void* act /*(B,HW,C)*/, int B, int HW, int C, int dtype, float* taps /*(B,9,16)*/, int tap_index,
-                hipStream_t s);
+                hipStream_t s, int colH = 0);
+// out (B, H*W, C) row-major pixels <- in (B, W*H, C) column-major pixels: the exit of a resolution stage that is stored transposed
+int launch_pixels_to_rowmajor(const void* in, void* out, int B, int H, int W, int C, int dtype, hipStream_t s);
 
 }  // namespace cosy

@@ -1552,18 +1552,20 @@ int launch_pool_fc(const void* head, const float* fc_w, const float* fc_b, float
 // NHWC (T) -> NCHW fp32 export of an activation (API parity for backbone(x) and the test probes; not on the hot path).
 // chunked = 1: the source is in the fused fronts' D layout [sample][C/16][HW][16].
 template <typename T>
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ act, int HW, int C, float* __restrict__ out, int chunked) {
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ act, int HW, int C, float* __restrict__ out, int chunked, int colH) {
     const int b = blockIdx.y;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // index in (C,HW)
     if (i >= (size_t)HW * C) return;
-    const size_t c = i / HW, p = i % HW;
+    const size_t c = i / HW;
+    size_t p = i % HW;
+    if (colH > 0) { const size_t Wm = (size_t)HW / colH; p = (p % Wm) * colH + p / Wm; }      // row-major pixel (y, x) lives at x * H + y
     const size_t src = chunked ? ((size_t)b * (C >> 4) + (c >> 4)) * HW * 16 + p * 16 + (c & 15) : ((size_t)b * HW + p) * C + c;
     out[(size_t)b * HW * C + i] = (float)act[src];
 }
-int launch_nhwc_to_nchw(const void* act, int B, int HW, int C, int dtype, float* out, hipStream_t s, int chunked) {
+int launch_nhwc_to_nchw(const void* act, int B, int HW, int C, int dtype, float* out, hipStream_t s, int chunked, int colH) {
     if (B == 0) return COSY_OK;
     dim3 grid(cdiv((long)HW * C, 256), B);
-    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, grid, dim3(256), 0, s, (const T*)act, HW, C, out, chunked));
+    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, grid, dim3(256), 0, s, (const T*)act, HW, C, out, chunked, colH));
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }
@@ -1572,7 +1574,7 @@ int launch_nhwc_to_nchw(const void* act, int B, int HW, int C, int dtype, float*
 // test probe: [mean, mean|x|, 14 strided samples] of one NHWC activation, indexed as if NCHW-flattened
 // ==========================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void taps_kernel(const T* __restrict__ act, int HW, int C, float* __restrict__ taps, int tap_index) {
+__global__ __launch_bounds__(256) void taps_kernel(const T* __restrict__ act, int HW, int C, float* __restrict__ taps, int tap_index, int colH) {
     __shared__ double s1[256], s2[256];
     const int b = blockIdx.x, tid = threadIdx.x;
     const T* a = act + (size_t)b * HW * C;
@@ -1589,13 +1591,40 @@ __global__ __launch_bounds__(256) void taps_kernel(const T* __restrict__ act, in
     if (tid == 0) { t[0] = (float)(s1[0] / (double)n); t[1] = (float)(s2[0] / (double)n); }
     if (tid < 14) {
         const size_t idx = (size_t)(tid * 2 + 1) * n / 29;  // index in (C,H,W) order
-        const size_t c = idx / HW, p = idx % HW;
+        const size_t c = idx / HW;
+        size_t p = idx % HW;
+        if (colH > 0) { const size_t Wm = (size_t)HW / colH; p = (p % Wm) * colH + p / Wm; }
         t[2 + tid] = (float)a[p * C + c];
     }
 }
-int launch_taps(const void* act, int B, int HW, int C, int dtype, float* taps, int tap_index, hipStream_t s) {
+int launch_taps(const void* act, int B, int HW, int C, int dtype, float* taps, int tap_index, hipStream_t s, int colH) {
     if (B == 0) return COSY_OK;
-    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(taps_kernel<T>, dim3(B), dim3(256), 0, s, (const T*)act, HW, C, taps, tap_index));
+    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(taps_kernel<T>, dim3(B), dim3(256), 0, s, (const T*)act, HW, C, taps, tap_index, colH));
+    COSY_CHECK_HIP(hipGetLastError());
+    return COSY_OK;
+}
+
+// ==========================================================================================
+// exit of a resolution stage stored column-major (240x320 crops: the 30x40 and 15x20 maps, whose columns fill the wave kernel's lanes): one
+// copy puts the last block's output back into row-major order for the kernels behind it.  16 bytes per thread, destination-contiguous.
+// ==========================================================================================
+__global__ __launch_bounds__(256) void pixels_to_rowmajor_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int H, int W, int C16, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;     // destination index in (b, y, x, c16)
+    if (i >= n) return;
+    const int c = (int)(i % C16);
+    long r = i / C16;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const long b = r / H;
+    out[i] = in[((b * W + x) * H + y) * C16 + c];
+}
+int launch_pixels_to_rowmajor(const void* in, void* out, int B, int H, int W, int C, int dtype, hipStream_t s) {
+    if (B == 0) return COSY_OK;
+    const int esz = dtype == COSY_F32 ? 4 : 2;
+    if ((C * esz) % 16 != 0) { set_error("pixels_to_rowmajor: %d channels of %d bytes are not whole 16-byte pieces", C, esz); return COSY_EINVAL; }
+    const int C16 = C * esz / 16;
+    const long n = (long)B * H * W * C16;
+    hipLaunchKernelGGL(pixels_to_rowmajor_kernel, dim3((unsigned)cdiv(n, 256l)), dim3(256), 0, s, (const uint4*)in, (uint4*)out, H, W, C16, n);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }

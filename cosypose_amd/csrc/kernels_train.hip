@@ -444,8 +444,9 @@ __global__ __launch_bounds__(1024) void combine_partials_kernel(const PT* __rest
     double acc = 0.;
     if (j < n) {
         int k = wave;
-        // 16 loads in flight per lane: the pass is a chain of dependent memory round trips (~1 us each), not bytes -- with 4 in flight the
-        // 256 slabs of a weight gradient were 4 rounds per wave (11 us per launch, 52 launches per step)
+        // 16 loads in flight per lane.  (Measured: no faster than 4 in flight, 11.3 us per launch either way -- up to 64 MB of partial tiles per
+        // weight gradient make this pass HBM traffic, not latency; fewer slabs (COSY_WG_CAP 128 / 64) cost the first stage more: 32.2 / 33.8 ms per step
+        // against 31.6.)
         for (; k + 240 < nslab; k += 256) {
             PT a[16];
 #pragma unroll
@@ -482,7 +483,7 @@ __device__ __forceinline__ void combine2_(const double* __restrict__ partial, in
     double a0 = 0., a1 = 0.;
     if (c < C) {
         int k = wave;
-        for (; k + 240 < nslab; k += 256) {        // 32 loads in flight: up to 1024 slabs are 4 rounds of dependent memory latency per wave instead of 16
+        for (; k + 240 < nslab; k += 256) {        // 32 loads in flight (measured: 6.9 us per launch as with 8 -- one workgroup pulls up to 655 KB of partials: a CU's bandwidth; COSY_RED_CAP 512 / 256 / 2048: 31.8 / 34.1 / 32.0 ms per step against 31.6)
             double p0[16], p1[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) { p0[u] = partial[((size_t)(k + 16 * u) * 2) * C + c]; p1[u] = partial[((size_t)(k + 16 * u) * 2 + 1) * C + c]; }

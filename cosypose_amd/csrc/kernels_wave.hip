@@ -438,7 +438,10 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     X(3, 1, 3, 2, 1, false, 3, 1) X(5, 1, 3, 2, 1, false, 2, 1) X(5, 1, 5, 2, 1, false, 2, 1)                                \
     /* rows that do not fill their 16 * PPL lanes, reached by walking the map's COLUMNS (wave_plan: transposed): 240x320 crops */ \
     X(3, 2, 1, 8, 1, false, 2, 4) X(5, 2, 1, 4, 1, false, 3, 1) X(5, 1, 2, 2, 1, false, 3, 2) X(3, 2, 2, 2, 1, false, 4, 2)   \
-    X(3, 1, 3, 1, 1, false, 4, 1) X(5, 1, 3, 1, 1, false, 4, 1) X(5, 1, 5, 1, 1, false, 4, 1)
+    X(3, 1, 3, 1, 1, false, 4, 1) X(5, 1, 3, 1, 1, false, 4, 1) X(5, 1, 5, 1, 1, false, 4, 1)                                \
+    /* block 2 at 240x320 crops: the 160-pixel rows of the 120x160 map fill 16 x 10 lanes-pixels exactly (a column walk of 120 on 128 reads     \
+       8 pixels per lane that are 7.7 KB apart: its loads and stores were 57 % of the kernel, knock-out timing) */                           \
+    X(3, 2, 1, 10, 1, true, 2, 4)
 // fp32 (parity mode): k-blocks are 16 deep (v_mfma_f32_16x16x4_f32 x 4 per fragment), so KBN = ceil(Cin / 16).  Same design, same
 // checks; these instantiations are what test_backbone_fp32_vs_reference holds to the reference's own per-stage outputs at <= 1e-4.
 // Not built (the fragment registers do not fit 256): 128- and 80-pixel rows with 2 k-blocks, 40-pixel rows with 3, 20-pixel rows with 9
@@ -508,6 +511,11 @@ bool wave_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W) {
     if (H <= 0) return false;
     return wave_plan(Cin, Cmid, H, W, k, s, dtype).ok;
 }
+bool wave_walks_columns(int Cin, int Cmid, int k, int s, int dtype, int H, int W) {
+    if (H <= 0) return false;
+    const WavePlan p = wave_plan(Cin, Cmid, H, W, k, s, dtype);
+    return p.ok && p.transposed;
+}
 int wave_max_tiles() { return WAVE_MAX_RSPLIT; }
 void wave_kernel_name(int Cin, int Cmid, int k, int s, int dtype, int H, int W, char* buf, size_t n) {
     const WavePlan p = wave_plan(Cin, Cmid, H, W, k, s, dtype);
@@ -543,10 +551,15 @@ static int launch_wave_t(const FuseArgs& a, int* n_tiles_out, hipStream_t s) {
     k.X = a.X; k.Wp = a.Wp; k.wparams = a.wparams; k.D = a.D; k.partial = a.partial;
     COSY_REQUIRE(a.wparams != nullptr, "mbconv_wave: packed parameters missing (wave_pack_params)%s", "");
     k.zeros = a.zeros; k.B = a.B; k.H = a.H; k.W = a.W; k.Cin = a.Cin; k.Cmid = a.Cmid; k.Ho = a.Ho; k.Wo = a.Wo;
-    k.xs_pix = a.Cin * (int)sizeof(T); k.xs_row = a.W * a.Cin * (int)sizeof(T); k.ds_pix = 16; k.ds_row = a.Wo * 16;
+    // strides of the walked axes through the stored map: a pixel step / a row step of the walk is a y or an x step of the map (transposed walk: rows =
+    // the map's columns), and the map is stored row-major (y * W + x) or column-major (x * H + y; FuseArgs::x_colmajor / d_colmajor)
+    const int px = a.Cin * (int)sizeof(T);
+    const int x_dx = a.x_colmajor ? a.H * px : px, x_dy = a.x_colmajor ? px : a.W * px;          // bytes per x step / y step of the block input
+    const int d_dx = a.d_colmajor ? a.Ho * 16 : 16, d_dy = a.d_colmajor ? 16 : a.Wo * 16;       // elements per x step / y step inside a D chunk
+    k.xs_pix = x_dx; k.xs_row = x_dy; k.ds_pix = d_dx; k.ds_row = d_dy;
     if (p.transposed) {
         k.H = a.W; k.W = a.H; k.Ho = a.Wo; k.Wo = a.Ho;
-        k.xs_pix = a.W * a.Cin * (int)sizeof(T); k.xs_row = a.Cin * (int)sizeof(T); k.ds_pix = a.Wo * 16; k.ds_row = 16;
+        k.xs_pix = x_dy; k.xs_row = x_dx; k.ds_pix = d_dy; k.ds_row = d_dx;
     }
     k.nkb_total = (p.kbn + 1) & ~1; k.nchunks = a.Cmid / (16 * p.ni); k.rsplit = 1; k.rows_per = a.Ho;
     const int ks_ = a.k, st_ = a.s, kbn_ = p.kbn, ppl_ = p.ppl, ni_ = p.ni;
