@@ -140,7 +140,9 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     const int id = blockIdx.x, xcd = id & 7, sidx = (id >> 3) * 4 + wave;
     // a job = (sample, chunk, row band); the jobs of one sample stay on one XCD
     const int jps = a.nchunks * a.rsplit;
-    const int b = (sidx / jps) * 8 + xcd, jrem = sidx % jps, ch = jrem / a.rsplit, band = jrem - ch * a.rsplit;
+    const int b = (sidx / jps) * 8 + xcd, jrem = sidx % jps;
+    int ch = jrem / a.rsplit, band = jrem - ch * a.rsplit;
+    if (COSY_DBG(a.dbg & 32)) { band = jrem / a.nchunks; ch = jrem - band * a.nchunks; }      // dbg 32: chunk-fastest order (the 4 waves of a workgroup share a band)
     const bool active = b < a.B;
     const int c0 = ch * 16 * NI;
 
