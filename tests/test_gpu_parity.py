@@ -216,7 +216,7 @@ L2_TOL = {'bf16': 6e-4, 'fp16': 4e-4}   # relative L2 per tensor, block-local co
                                           # sums cancel heavily: every element within 0.7 storage ulps; 7.7e-5 at the other sizes); a halo or padding slip is >= 1e-2
 
 
-@pytest.mark.parametrize('hw', [(256, 256), (240, 320), (192, 256), (224, 224), (416, 416)], ids=['256x256', '240x320', '192x256', '224x224', '416x416'])
+@pytest.mark.parametrize('hw', [(256, 256), (240, 320), (192, 256), (224, 224), (416, 416), (320, 240)], ids=['256x256', '240x320', '192x256', '224x224', '416x416', '320x240'])
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
 def test_fused_kernels_vs_storage_emulation(model, oracle, golden_sd, dtype, hw):
     """The kernels that set the headline (mbconv_wave_kernel, mbconv_small_kernel, the gated pw_gemm_dma, stem, dwconv in their
@@ -227,7 +227,8 @@ def test_fused_kernels_vs_storage_emulation(model, oracle, golden_sd, dtype, hw)
     fp32 summation order / transcendental approximation in front of a rounding, i.e. isolated values one storage ulp apart:
     asserted as (1) relative L2 error per tensor (a one-pixel halo or padding slip in any variant shows up as >= 1e-2), (2) no
     element further than 1.5 storage ulps of the tensor's scale away (measured: < 0.8), (3) gates (fp32 on both sides) within 5e-6.  256x256 and
-    240x320 reach every fused variant (FULLW and !FULLW wave kernels -- at 240x320 the TRANSPOSED walk of blocks 2 and 5-17, whose
+    240x320 (landscape: the 30x40 and 15x20 stages are stored COLUMN-major there, Block::out_col, and block 2 walks 160-pixel rows with 10 pixels per
+    lane; 320x240 is the portrait counterpart, walked by rows) reach every fused variant (FULLW and !FULLW wave kernels -- at 240x320 the TRANSPOSED walk of blocks 2 and 5-17, whose
     columns fill the lanes better than their rows --, row-mapped and plain small kernels, weight- and row-side gates); 192x256,
     224x224 and 416x416 are sizes the schedule was not tuned for (wave variants by width, at 224x224 the !FULLW ones in the plain
     orientation; the tiled kernel on blocks 3 / 4 of 224x224 and on blocks 2-5 of 416x416: every k / stride form it is built for;
