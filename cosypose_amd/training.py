@@ -169,6 +169,12 @@ class LazyMeters(defaultdict):
 
     def defer(self, names, values):
         """values: 1-D device tensor; names[i]: the meter names that receive values[i]"""
+        if not values.is_cuda:                       # nothing to wait for
+            self._drain(force=len(self._pending))
+            for keys, v in zip(names, values.detach().tolist()):
+                for k in keys:
+                    self[k].add(v)
+            return
         host = torch.empty(values.shape, dtype=values.dtype, pin_memory=True)
         host.copy_(values.detach(), non_blocking=True)
         done = torch.cuda.Event()
