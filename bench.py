@@ -357,30 +357,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    out = None
-    for _ in range(args.warmup):
-        out = step()
-    if out is None:             # --warmup 0: the checks (and the engines' first-call set-up) still happen once, untimed
+    # Python's cyclic collector: a full (generation 2) pass over the process's ~10^6 long-lived objects (torch, pandas) takes
+    # ~60 ms of host time on this box (profiles/exp/gcprobe.py) -- 2.5 steps of GPU work, and the host only leads the GPU by
+    # a few steps.  The long-lived objects are moved to the permanent generation, so passes during the steps only look at what
+    # the steps allocate.  Done behind the FIRST warm-up step (which builds the engines, plans and caches that are to be frozen), not
+    # between the warm-up and the timed steps: 60 ms with nothing queued let the GPU's clocks fall back to idle right in front of
+    # the timed region (COSY_BENCH_GC_LATE=1: the old order, for the A/B in profiles/r04_dead_ends.txt / DESIGN section 5).
+    gc_late = os.environ.get('COSY_BENCH_GC_LATE') == '1'
+    out = step()                # the first warm-up step (--warmup 0: the checks and the engines' first-call set-up still happen once, untimed)
+    if not gc_late:
+        gc.collect()
+        gc.freeze()
+    for _ in range(args.warmup - 1):
         out = step()
     assert torch.isfinite(out).all(), 'non-finite refined poses'
     assert out.shape == (total, 4, 4)
     profile = not args.no_profile
     gather_us.clear()
-    # Python's cyclic collector: a full (generation 2) pass over the process's ~10^6 long-lived objects (torch, pandas) takes
-    # ~60 ms of host time on this box (profiles/exp/gcprobe.py) -- 2.5 steps of GPU work, and the host only leads the GPU by
-    # a few steps.  The long-lived objects are moved to the permanent generation, so passes during the steps only look at what
-    # the steps allocate.
-    gc.collect()
-    gc.freeze()
-    sync()
+    if gc_late:
+        gc.collect()
+        gc.freeze()
+    if os.environ.get('COSY_BENCH_NOSYNC') != '1':      # diagnostic only (step_ms of a run that never drained the queues): the line is not a measurement then
+        sync()
     t0 = time.perf_counter()
     host_ms = []
-    for _ in range(args.steps):
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # one event per step boundary on the caller's stream (no synchronisation)
+    marks[0].record()
+    for i in range(args.steps):
         th = time.perf_counter()
         step()
+        marks[i + 1].record()
         host_ms.append((time.perf_counter() - th) * 1e3)   # host enqueue time of the step (the GPU runs behind)
     sync()
     dt = time.perf_counter() - t0
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     if args.layers and rank == 0:
         print('host enqueue ms/step: ' + ' '.join(f'{v:.2f}' for v in host_ms), file=sys.stderr)
     if world > 1:
@@ -571,6 +581,7 @@ def main():
                        'pose_iterations_per_step': iters_total, 'candidates_per_rank': per_rank, 'bsz_objects': args.bsz_objects, 'streams': args.streams,
                        'parallelism': f'candidate-sharded x{world}, 1 all-gather of refined poses per step' + (' (RCCL, forced 1-rank group)' if use_dist and world == 1 else ''),
                        'single_stream': single,
+                       'step_ms': {'each': [round(v, 2) for v in step_ms], 'note': 'device time between step boundaries on the caller\'s stream (events, rank 0); the first follows a synchronisation: empty queues'},
                        'all_gather_us': round(float(np.median(gather_us)), 1) if gather_us else None,
                        'process_group': process_group_info()},
             'roofline': roofline,

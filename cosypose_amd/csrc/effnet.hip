@@ -620,6 +620,10 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
     ab.base = (char*)n->abase; ab.off = 0;
     layout_workspace(n, ab);
     if (herr == hipSuccess) herr = hipMemset(n->abase, 0, n->abytes);
+    // hipMemset on device memory returns before the fill has run, and it runs on the NULL stream: the caller's streams (torch creates them
+    // non-blocking) are not ordered behind it -- a forward launched right after create() could have its input / workspaces zeroed under it
+    // (seen as a 1-in-15 bit mismatch of test_refinement_loop_with_on_device_renderer, which rebuilds four engines and launches at once).
+    if (herr == hipSuccess) herr = hipDeviceSynchronize();
     if (herr != hipSuccess) {
         set_error("create: weight upload failed: %s", hipGetErrorString(herr));
         (void)hipFree(n->wbase); (void)hipFree(n->abase); free(n);

@@ -145,9 +145,13 @@ class NetEngine:
         self.capacity = 0
 
     def _weights_version(self):
-        ts = list(self.backbone.parameters()) + list(self.backbone.buffers())
+        """(storage, in-place version) of every tensor the engine was built from.  Read from the cached name tables (_modwatch: walking the
+        backbone's ~300 submodules in front of EVERY model call was half of a step's host time, and GPU idle whenever the host is not ahead)."""
+        from . import _modwatch
+        params, buffers = _modwatch.named_tensors(self.backbone)
+        ts = list(params.values()) + list(buffers.values())
         if self.pose_fc is not None:
-            ts += list(self.pose_fc.parameters())
+            ts += list(_modwatch.named_tensors(self.pose_fc)[0].values())
         return tuple((t.data_ptr(), t._version) for t in ts)
 
     def ensure(self, B, H, W, dtype, device):

@@ -21,7 +21,7 @@ import math
 import numpy as np
 import torch
 
-from . import arch
+from . import arch, _modwatch
 from ._lib import lib, check, ptr, stream, require_device
 
 BN_EPS, BN_MOM = arch.BN_EPS, 0.01
@@ -466,38 +466,19 @@ class _BackboneTrainFn(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads[n] for n in ctx.names)
 
 
-_registrations = [0]        # bumped whenever ANY module registers a parameter / buffer / submodule: the cached name tables are re-read
-
-
-def _count_registration(*args):
-    _registrations[0] += 1
-
-
-for _hook in ('register_module_parameter_registration_hook', 'register_module_buffer_registration_hook',
-              'register_module_module_registration_hook'):
-    getattr(torch.nn.modules.module, _hook)(_count_registration)
-
-
 def _named_tensors(model):
-    """(reference parameter names, the model's parameters in that order, its named buffers).  Walking the ~300 submodules for
-    named_parameters() + named_buffers() costs ~1 ms of host time per step during which the GPU has nothing queued; the Parameter and
-    buffer OBJECTS only change through a registration on some module (global hooks above), so the tables are kept until one happens
-    (in-place updates, .data re-pointing and load_state_dict keep the objects; a device / dtype move of the module is caught by sentinels)."""
-    cached = model.__dict__.get('_cosy_named_tensors')
-    if cached is not None and cached[0] == _registrations[0]:
-        _, names, params, buffers = cached
-        # Module._apply (.cuda() / .to() / .float()) swaps buffer objects without a registration: two sentinels catch it
-        first, last = next(iter(buffers)), next(reversed(buffers))
-        if model.get_buffer(first) is buffers[first] and model.get_buffer(last) is buffers[last] and model.get_parameter(names[-1]) is params[-1]:
-            return names, params, buffers
+    """(reference parameter names, the model's parameters in that order, its named buffers), from the cached tables of _modwatch
+    (named_parameters() + named_buffers() walk ~300 submodules: ~1 ms of host time per step during which the GPU has nothing queued)."""
+    named, buffers = _modwatch.named_tensors(model)
+    cached = model.__dict__.get('_cosy_train_order')
+    if cached is not None and cached[0] is named:
+        return cached[1], cached[2], buffers
     names = param_names()
-    named = dict(model.named_parameters())
     missing = [n for n in names if n not in named]
     if missing or len(named) != len(names):
         raise ValueError(f'model parameters do not match the efficientnet-b3 pose network ({len(named)} vs {len(names)}; missing {missing[:3]})')
     params = [named[n] for n in names]
-    buffers = dict(model.named_buffers())
-    model.__dict__['_cosy_named_tensors'] = (_registrations[0], names, params, buffers)
+    model.__dict__['_cosy_train_order'] = (named, names, params)
     return names, params, buffers
 
 

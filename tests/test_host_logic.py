@@ -319,10 +319,18 @@ def test_training_scheduling_helpers_on_the_host():
                        torch.eye(4).reshape(1, 1, 4, 4).repeat(3, 2, 1, 1) * torch.arange(1, 4).view(3, 1, 1, 1))
     sel = db.select(['z', 'x', 'z'])
     assert torch.equal(sel.points, db.points[[2, 0, 2]]) and torch.equal(sel.symmetries, db.symmetries[[2, 0, 2]]) and list(sel.labels) == ['z', 'x', 'z']
-    before = train_engine._registrations[0]
+    from cosypose_amd import _modwatch
+    before = _modwatch.registration_epoch()
     lin = torch.nn.Linear(2, 2)
     lin.register_buffer('extra', torch.zeros(1))
-    assert train_engine._registrations[0] >= before + 3          # weight, bias, buffer
+    assert _modwatch.registration_epoch() >= before + 3          # weight, bias, buffer
+    p1, b1 = _modwatch.named_tensors(lin)
+    assert _modwatch.named_tensors(lin)[0] is p1                 # cached
+    lin.double()                                                 # Module._apply swaps the buffer object without registering: the sentinel sees it
+    p2, b2 = _modwatch.named_tensors(lin)
+    assert b2['extra'] is lin.extra and b2['extra'].dtype == torch.float64 and p2['weight'] is lin.weight
+    lin.more = torch.nn.Parameter(torch.zeros(1))
+    assert 'more' in _modwatch.named_tensors(lin)[0]
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match='no GPU'):
             training.DevicePrefetcher([types.SimpleNamespace(images=torch.zeros(1))])
