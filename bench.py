@@ -578,7 +578,9 @@ def main():
             'config': {'workload': desc + f', coarse {n_coarse} + refiner {n_refine} iterations, {H}x{W} crops, ' +
                                    ('synthetic on-device renders' if args.renderer == 'pregenerated' else
                                     'renders by the on-device HIP rasteriser (6k-triangle meshes) inside the loop'),
-                       'pose_iterations_per_step': iters_total, 'candidates_per_rank': per_rank, 'bsz_objects': args.bsz_objects, 'streams': args.streams,
+                       'pose_iterations_per_step': iters_total, 'candidates_per_rank': per_rank, 'bsz_objects': args.bsz_objects,
+                       'streams': args.streams if predictor._streams_usable() else 1,      # rasterizer.HipBatchRenderer: chunks run one after the other (profiles/r04_raster_streams.txt)
+
                        'parallelism': f'candidate-sharded x{world}, 1 all-gather of refined poses per step' + (' (RCCL, forced 1-rank group)' if use_dist and world == 1 else ''),
                        'single_stream': single,
                        'step_ms': {'each': [round(v, 2) for v in step_ms], 'note': 'device time between step boundaries on the caller\'s stream (events, rank 0); the first follows a synchronisation: empty queues'},

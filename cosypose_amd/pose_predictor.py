@@ -126,6 +126,17 @@ class CoarseRefinePosePredictor(torch.nn.Module):
         # every result collection owns its infos (as after the sequential path's concatenation): a column added to one is not seen by the others
         return {key: tc.PandasTensorCollection(start.infos.reset_index(drop=True).copy(), **full[key]) for key in keys}
 
+    def _streams_usable(self):
+        """False when a model's renderer declares that it must not share the device with launches on other streams (rasterizer.HipBatchRenderer:
+        `concurrent_streams_safe = False`, profiles/r04_raster_streams.txt): the chunks then run one after the other on the caller's stream."""
+        for model in (self.coarse_model, self.refiner_model):
+            r = getattr(model, 'renderer', None)
+            while r is not None:
+                if getattr(r, 'concurrent_streams_safe', True) is False:
+                    return False
+                r = getattr(r, 'r', None) if hasattr(r, 'r') and r is not getattr(r, 'r') else None        # a thin wrapper around a renderer
+        return True
+
     def make_TCO_init(self, detections, K):
         """Initial poses from 2D boxes: 'v0' (identity rotation at 1 m) or 'z-up+auto-depth' (cosypose_ops.py:121-173)."""
         im_ids = detections.infos['batch_im_id'].values
@@ -142,7 +153,7 @@ class CoarseRefinePosePredictor(torch.nn.Module):
         preds = dict()
         assert detections is not None or data_TCO_init is not None, 'get_predictions needs detections or data_TCO_init'
         n_objects = len(detections if data_TCO_init is None else data_TCO_init)
-        if self.n_streams > 1 and n_objects > self.bsz_objects:
+        if self.n_streams > 1 and n_objects > self.bsz_objects and self._streams_usable():
             if data_TCO_init is None:
                 assert detections is not None and self.coarse_model is not None and n_coarse_iterations > 0
                 start = self.make_TCO_init(detections, K)

@@ -83,7 +83,15 @@ FLAT = dict(ambient=0.6, diffuse=0.4, specular=0.0, shininess=1.0, light_dir=(0.
 
 class HipBatchRenderer:
     """shading='flat' (round 1's model, default) or 'opengl' (PyBullet-like: smooth normals, texture, highlight, world-frame
-    light, 8-bit output) or a dict with the keys of `OPENGL_LIKE`; ambient / diffuse / light_dir override single entries."""
+    light, 8-bit output) or a dict with the keys of `OPENGL_LIKE`; ambient / diffuse / light_dir override single entries.
+
+    `concurrent_streams_safe = False`: a render is bit-reproducible on its own and beside other renders, but NOT while the 16-bit
+    backbone's wave-autonomous fused kernels (kernels_wave.hip) run on another HIP stream: ~25 % of the renders then come out with a few
+    hundred wrong pixels (a face that is not the nearest wins, or its shade differs), none with one hardware queue, none beside the fp32
+    backbone, ~2 % with the wave kernels masked out (profiles/r04_raster_streams.txt: memory-ordering, atomics, stray writes and the
+    transcendental pipe were each ruled out as the mechanism; open).  CoarseRefinePosePredictor therefore runs its chunks one after the other when a model renders with
+    this class, whatever n_streams says; callers with their own streams should keep renders and backbone launches on one stream."""
+    concurrent_streams_safe = False
 
     def __init__(self, meshes, ambient=None, diffuse=None, light_dir=None, shading='flat'):
         self.meshes = meshes

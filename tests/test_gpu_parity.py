@@ -1177,10 +1177,12 @@ def test_refinement_loop_with_on_device_renderer(golden_sd):
     m.renderer = RenderOnly(renderer)
     final2, _ = pred.get_predictions(images, K, detections=det, n_coarse_iterations=1, n_refiner_iterations=2)
     assert torch.equal(final2.poses, final.poses)
-    # chunks of a stage on concurrent HIP streams (n_streams): 7 detections as 4 chunks of 2 on 3 streams, each stream with its
-    # own engine and render scratch -> bit-identical to the sequential schedule above, also when the streams' engines are reused
+    # n_streams with THIS renderer: the rasteriser is not reproducible while the 16-bit backbone's wave kernels run on another HIP stream
+    # (HipBatchRenderer.concurrent_streams_safe = False, profiles/r04_raster_streams.txt), so the predictor runs the 4 chunks of 2 one after the
+    # other on the caller's stream whatever n_streams says -- bit-identical to the schedule above, every time
     m.renderer = renderer
     pred3 = CoarseRefinePosePredictor(coarse_model=m, refiner_model=m, bsz_objects=2, n_streams=3)
+    assert not pred3._streams_usable() and pred._streams_usable() is False
     for dtype in ('fp32', 'fp16'):
         m.compute_dtype = dtype
         want, want_all = pred.get_predictions(images, K, detections=det, n_coarse_iterations=1, n_refiner_iterations=2)
@@ -1192,7 +1194,19 @@ def test_refinement_loop_with_on_device_renderer(golden_sd):
                 for tname in ('poses', 'poses_input', 'K_crop', 'boxes_rend', 'boxes_crop'):
                     assert torch.equal(getattr(got_all[k], tname), getattr(want_all[k], tname)), (dtype, k, tname)
     m.compute_dtype = 'fp32'
+    assert len(pred3._lanes) == 0                 # no side stream was ever created
+    # a renderer that is safe beside other streams (pre-rendered images) takes the concurrent path: one engine per side stream
+    class Fixed:
+        def __init__(self): self.img = torch.rand(1, 3, 240, 320, device='cuda')
+        def render(self, obj_infos, TCO, K, resolution): return self.img.expand(len(obj_infos), -1, -1, -1)
+    m.renderer = Fixed()
+    assert pred3._streams_usable()
+    want, want_all = pred.get_predictions(images, K, detections=det, n_coarse_iterations=1, n_refiner_iterations=2)
+    got, got_all = pred3.get_predictions(images, K, detections=det, n_coarse_iterations=1, n_refiner_iterations=2)
+    for k in want_all:
+        assert torch.equal(got_all[k].poses, want_all[k].poses), k
     assert len(m._engines.engines) >= 4          # the default stream's engine + one per side stream
+    m.renderer = renderer
 
 
 def test_crop_pack_all_window_paths(oracle):
