@@ -88,8 +88,8 @@ class HipBatchRenderer:
     `concurrent_streams_safe = False`: a render is bit-reproducible on its own and beside other renders, but NOT while the 16-bit
     backbone's wave-autonomous fused kernels (kernels_wave.hip) run on another HIP stream: ~25 % of the renders then come out with a few
     hundred wrong pixels (a face that is not the nearest wins, or its shade differs), none with one hardware queue, none beside the fp32
-    backbone, ~2 % with the wave kernels masked out (profiles/r04_raster_streams.txt: memory-ordering, atomics, stray writes and the
-    transcendental pipe were each ruled out as the mechanism; open).  CoarseRefinePosePredictor therefore runs its chunks one after the other when a model renders with
+    backbone, ~2 % with the wave kernels masked out, ~1 % with their MFMAs knocked out (profiles/r04_raster_streams.txt: memory ordering, atomics,
+    stray writes and the transcendental pipe were each ruled out; what remains is the 16-bit MFMA traffic of waves sharing the SIMD; open).  CoarseRefinePosePredictor therefore runs its chunks one after the other when a model renders with
     this class, whatever n_streams says; callers with their own streams should keep renders and backbone launches on one stream."""
     concurrent_streams_safe = False
 
