@@ -80,7 +80,7 @@ class CoarseRefinePosePredictor(torch.nn.Module):
     @torch.no_grad()
     def _concurrent_predictions(self, images, K, start, stages):
         """The chunks of `start` each run ALL `stages` = [(name, model, n_iterations)] on their own HIP stream (round-robin over
-        n_streams side streams): a chunk's refiner input is its own coarse output, so nothing crosses streams until the one
+        n_streams side streams; enqueued stage by stage): a chunk's refiner input is its own coarse output, so nothing crosses streams until the one
         join at the end.  Every chunk writes its rows straight into the full-size result tensors (allocated up front on the
         caller's stream), so the caller's stream has nothing to do behind the join: no per-key concatenation on the critical
         path between two calls.  Returns {'stage/iteration=k': collection}."""
@@ -110,17 +110,21 @@ class CoarseRefinePosePredictor(torch.nn.Module):
         for lane in lanes:
             lane.wait_stream(main)             # frames, K, the initial poses and the result buffers are ready on `main`
         _OUT = (('TCO_output', 'poses'), ('K_crop', 'K_crop'), ('boxes_rend', 'boxes_rend'), ('boxes_crop', 'boxes_crop'))
-        for i, (first, chunk) in enumerate(zip(firsts, chunks)):
-            last = min(first + self.bsz_objects, n_objects)
-            labels, im_ids = chunk.infos['label'].values, chunk.infos['batch_im_id'].values
-            with torch.cuda.stream(lanes[i % len(lanes)]):
-                poses = chunk.poses
-                for name, model, n_it in stages:
+        # Host order: STAGE by stage across the chunks (every chunk's coarse call, then every chunk's refiner call), not chunk by chunk: on an idle device
+        # (one call, or the first step behind a synchronisation) the second lane's kernels arrive behind ONE forward's worth of launches of the first lane
+        # instead of five: the first step behind a synchronisation 23.9-24.3 instead of 24.9-26.6 ms (steady steps 21.9-22.0 either way; same call,
+        # driver command: 58.05 vs 58.00 k).  The same four model calls per step, every lane sees its own kernels in the same order: bit-identical results.
+        ids = [(chunk.infos['label'].values, chunk.infos['batch_im_id'].values) for chunk in chunks]
+        poses = [chunk.poses for chunk in chunks]
+        for name, model, n_it in stages:
+            for i, first in enumerate(firsts):
+                last = min(first + self.bsz_objects, n_objects)
+                with torch.cuda.stream(lanes[i % len(lanes)]):
                     dst = {n: {src: full[f'{name}/{_iteration_key(n)}'][field][first:last] for src, field in _OUT} for n in range(1, n_it + 1)}
-                    outputs = model(images=images, K=K, TCO=poses, n_iterations=n_it, labels=labels, im_ids=im_ids, out=dst, **extra)
+                    outputs = model(images=images, K=K, TCO=poses[i], n_iterations=n_it, labels=ids[i][0], im_ids=ids[i][1], out=dst, **extra)
                     for n in range(1, n_it + 1):       # the model wrote into the rows it was given
                         assert outputs[_iteration_key(n)]['TCO_output'].data_ptr() == dst[n]['TCO_output'].data_ptr()
-                    poses = outputs[_iteration_key(n_it)]['TCO_output']
+                    poses[i] = outputs[_iteration_key(n_it)]['TCO_output']
         for lane in lanes:
             main.wait_stream(lane)
         # every result collection owns its infos (as after the sequential path's concatenation): a column added to one is not seen by the others
