@@ -59,6 +59,8 @@ for rnd in range(int(os.environ.get('ROUNDS', 40))):
             bad_d += 1
             if bad_d <= 4:
                 dd = d != d0
+                rel = ((d[dd] - d0[dd]).abs() / d0[dd].abs().clamp_min(1e-9))
+                print(f'   relative depth differences: min {float(rel.min()):.2e} median {float(rel.median()):.2e} max {float(rel.max()):.2e}')
                 print(f'round {rnd} render {j}: DEPTH differs in {int(dd.sum())} pixels of samples {[int(r) for r in torch.nonzero(dd.flatten(1).any(1)).flatten()][:6]}; marker there: {int((d[dd] == -7).sum())}, got==0 there: {int((d[dd] == 0).sum())}, want==0 there: {int((d0[dd] == 0).sum())}')
         elif not torch.equal(rgb, rgb0):
             bad_rgb += 1
