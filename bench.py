@@ -333,7 +333,7 @@ def main():
     coarse = build_model(0, mesh_db, (H, W), dtype, renderer)
     refiner = build_model(1, mesh_db, (H, W), dtype, renderer)
     predictor = CoarseRefinePosePredictor(coarse_model=coarse, refiner_model=refiner, bsz_objects=args.bsz_objects, n_streams=args.streams)
-    if args.streams > 1 and not predictor._streams_usable():      # --renderer hip: the chunks would run one after the other -> one full-size launch instead
+    if args.streams > 1 and not predictor._streams_usable():      # a renderer that declines concurrent streams: the chunks would run one after the other -> one full-size launch instead
         args.streams, args.bsz_objects = 1, min(max(per_rank), full_bsz)
         predictor.n_streams, predictor.bsz_objects = 1, args.bsz_objects
     iters_total = total * (n_coarse + n_refine)
@@ -582,7 +582,7 @@ def main():
                                    ('synthetic on-device renders' if args.renderer == 'pregenerated' else
                                     'renders by the on-device HIP rasteriser (6k-triangle meshes) inside the loop'),
                        'pose_iterations_per_step': iters_total, 'candidates_per_rank': per_rank, 'bsz_objects': args.bsz_objects,
-                       'streams': args.streams,      # 1 with --renderer hip: rasterizer.HipBatchRenderer is not run beside other streams (profiles/r04_raster_streams.txt)
+                       'streams': args.streams,
                        'parallelism': f'candidate-sharded x{world}, 1 all-gather of refined poses per step' + (' (RCCL, forced 1-rank group)' if use_dist and world == 1 else ''),
                        'single_stream': single,
                        'step_ms': {'each': [round(v, 2) for v in step_ms], 'note': 'device time between step boundaries on the caller\'s stream (events, rank 0); the first follows a synchronisation: empty queues'},

@@ -13,6 +13,8 @@ labels = np.array([f'obj_{i:06d}' for i in range(1, 6)])
 v, f, c = syn.make_render_meshes(7, 5)
 meshes = RenderMeshes(labels, v, f, c).cuda()
 renderer = HipBatchRenderer(meshes)
+if os.environ.get('FORCE_STREAMS') == '1':
+    renderer.concurrent_streams_safe = True      # take the concurrent path although the class declines it
 pts = np.stack([vv[np.random.RandomState(0).choice(len(vv), 2500, replace=len(vv) < 2500)] for vv in v])
 mesh_db = BatchedMeshes({l: dict(label=l, n_sym=1) for l in labels}, labels, torch.from_numpy(pts), torch.eye(4).reshape(1, 1, 4, 4).repeat(5, 1, 1, 1)).float().cuda()
 cfg = check_update_config(argparse.Namespace(backbone_str='efficientnet-b3', n_pose_dims=9))
