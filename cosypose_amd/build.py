@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libcosyhip.so')
-SOURCES = ['kernels_geom.hip', 'kernels_dist.hip', 'kernels_raster.hip', 'kernels_train.hip', 'kernels_net.hip',
+SOURCES = ['kernels_geom.hip', 'kernels_dist.hip', 'kernels_raster.hip', 'kernels_train.hip', 'kernels_net.hip', 'kernels_small.hip',
            'kernels_dw.hip', 'kernels_wave.hip', 'effnet.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # No packed-fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) in the kernels that share the chip with another stream's MFMA kernels as SMALL
@@ -28,7 +28,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-u
 # issues no faster than two v_fma_f32 on gfx950 (profiles/exp/valu_bench.hip: 5.85 vs 2 x 3.1 cycles) -- and pays for the pairing
 # with register shuffles (61 v_mov_b32 per row of the k=5 shape) and un-fused multiply + add tails.  Scalar FMAs, no moves.
 FILE_FLAGS = {'kernels_wave.hip': ['-fno-slp-vectorize'], 'kernels_dw.hip': ['-fno-slp-vectorize'], 'kernels_raster.hip': NO_PACKED_FP32,
-              'kernels_geom.hip': NO_PACKED_FP32, 'kernels_dist.hip': NO_PACKED_FP32}      # kernels_train.hip: one compute stream, and 31.5 -> 31.65 ms without the packed forms   # kernels_dw.hip: see its header
+              'kernels_geom.hip': NO_PACKED_FP32, 'kernels_dist.hip': NO_PACKED_FP32, 'kernels_small.hip': NO_PACKED_FP32}      # kernels_train.hip: one compute stream, and 31.5 -> 31.65 ms without the packed forms   # kernels_dw.hip: see its header
 
 
 def _headers():

@@ -77,7 +77,7 @@ def test_gemm_kernels_keep_their_occupancy_and_do_not_spill():
 
 
 def test_small_kernel_objects_hold_no_packed_fp32_arithmetic():
-    """kernels_raster / kernels_geom / kernels_dist are built without the packed-fp32 target feature (build.NO_PACKED_FP32): on gfx950 a wave's
+    """kernels_raster / kernels_geom / kernels_dist / kernels_small (squeeze-excite, pooling + FC, probes) are built without the packed-fp32 target feature (build.NO_PACKED_FP32): on gfx950 a wave's
     v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 results are wrong while another wave of its SIMD -- another HIP stream's backbone kernel -- issues 16-bit
     MFMAs with VGPR accumulators (profiles/r04_raster_streams.txt).  The shipped objects are disassembled and searched for the instructions."""
     import subprocess, re
@@ -86,7 +86,7 @@ def test_small_kernel_objects_hold_no_packed_fp32_arithmetic():
     objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
     bundler = '/opt/rocm/lib/llvm/bin/clang-offload-bundler'
     import tempfile, os
-    for src in ('kernels_raster.hip', 'kernels_geom.hip', 'kernels_dist.hip'):
+    for src in ('kernels_raster.hip', 'kernels_geom.hip', 'kernels_dist.hip', 'kernels_small.hip'):
         assert hipbuild.NO_PACKED_FP32[-1] in hipbuild.FILE_FLAGS.get(src, []), src
         obj = hipbuild._obj(src)
         with tempfile.TemporaryDirectory() as tmp:
