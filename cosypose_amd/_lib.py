@@ -205,16 +205,21 @@ def ints_to_device(values, device):
         hit = _id_cache.get(key)
         if hit is not None:
             _id_cache.move_to_end(key)
-            dev_t, ready = hit
+            dev_t, ready, home = hit
             # the upload was enqueued on the stream that first asked for this content: another stream (a concurrent chunk with the same
-            # ids) must not read it before it has landed
+            # ids) must not read it before it has landed, and the caching allocator -- which would hand the block back to the HOME stream's
+            # pool the moment the entry is evicted -- must know that this stream reads it too
+            cur = torch.cuda.current_stream(device)
             if not ready.query():
-                torch.cuda.current_stream(device).wait_event(ready)
+                cur.wait_event(ready)
+            if cur.cuda_stream != home:
+                dev_t.record_stream(cur)
             return dev_t
         dev_t = host.pin_memory().to(device, non_blocking=True)
         ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream(device))
-        _id_cache[key] = (dev_t, ready)
+        cur = torch.cuda.current_stream(device)
+        ready.record(cur)
+        _id_cache[key] = (dev_t, ready, cur.cuda_stream)
         while len(_id_cache) > _ID_CACHE_ENTRIES:
             _id_cache.popitem(last=False)
         return dev_t

@@ -5,6 +5,7 @@ call (is the engine still built from these weights?) and the training step in fr
 the GPU has nothing queued whenever the host is not already ahead.  The tensor OBJECTS of a module tree only change through a
 registration on some module (torch's global registration hooks bump one counter) or through Module._apply (.cuda() / .to() / .float():
 swaps buffer objects without registering -- caught by identity sentinels on the first and last buffer and the last parameter).
+Module._apply itself is wrapped to bump the counter too (a partial conversion of a submodule swaps tensors the sentinels do not cover).
 In-place updates, `.data` re-pointing and load_state_dict keep the objects, and are seen by whoever reads data_ptr() / _version
 from the cached objects."""
 import torch
@@ -19,6 +20,20 @@ def _bump(*args):
 for _hook in ('register_module_parameter_registration_hook', 'register_module_buffer_registration_hook',
               'register_module_module_registration_hook'):
     getattr(torch.nn.modules.module, _hook)(_bump)
+
+
+# Module._apply (.cuda() / .to() / .float() / .half() on ANY module of a tree) swaps parameter / buffer objects without registering anything; a
+# partial one -- model.backbone._blocks[k].float() -- changes tensors in the middle of the cached tables that the first / last sentinels
+# below cannot see.  The method is wrapped once, process-wide, to bump the same counter (cheap: it runs on explicit conversions only).
+_orig_apply = torch.nn.Module._apply
+if not getattr(_orig_apply, '_cosy_modwatch', False):
+    def _apply(self, fn, *args, **kwargs):
+        _bump()
+        out = _orig_apply(self, fn, *args, **kwargs)
+        _bump()
+        return out
+    _apply._cosy_modwatch = True
+    torch.nn.Module._apply = _apply
 
 
 def registration_epoch():

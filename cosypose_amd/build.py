@@ -14,21 +14,20 @@ LIB = os.path.join(LIBDIR, 'libcosyhip.so')
 SOURCES = ['kernels_geom.hip', 'kernels_dist.hip', 'kernels_raster.hip', 'kernels_train.hip', 'kernels_net.hip', 'kernels_small.hip',
            'kernels_dw.hip', 'kernels_wave.hip', 'effnet.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-# No packed-fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) in the kernels that share the chip with another stream's MFMA kernels as SMALL
-# waves.  Round 4: a wave's packed-fp32 results were WRONG while another wave on its SIMD -- another HIP stream's kernel -- issued 16-bit MFMAs with VGPR
-# accumulators (the wave-autonomous fronts): the rasteriser, whose SLP-vectorised code is dense in v_pk_*_f32, lost triangles in 20-30 % of its renders beside
-# the backbone and in NONE once these instructions were gone (profiles/r04_raster_streams.txt).  The instructions issue no faster than two scalar ones on gfx950
-# (profiles/exp/valu_bench.hip), so nothing is lost; the SLP vectoriser stays on.  NOT applied to kernels_net.hip: without the packed forms its <5,2> GEMM tiles
-# need 186-191 VGPRs beside their 80 AGPRs (one wave per SIMD: blocks 13-17 53 -> ~90 us) -- its kernels are MFMA kernels themselves, run at 1-2 waves per SIMD,
-# and were bit-reproducible beside each other and beside the wave kernels in every test (profiles/exp/race_hunt3.py: 0 of 765 forwards).  The host half of a
-# compile does not know the feature and says so.
+# No packed-fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) anywhere in the library.  Round 4: a wave's packed-fp32 results were WRONG while
+# another wave on its SIMD -- another HIP stream's kernel -- issued 16-bit MFMAs with VGPR accumulators (the wave-autonomous fronts): the rasteriser, whose
+# SLP-vectorised code was dense in v_pk_*_f32, lost triangles in 20-30 % of its renders beside the backbone and in NONE once these instructions were gone
+# (profiles/r04_raster_streams.txt; stand-alone victim / aggressor pair: profiles/exp/pkf32_victim.hip).  The instructions issue no faster than two scalar
+# ones on gfx950 (profiles/exp/valu_bench.hip), so nothing is lost; the SLP vectoriser stays on where it helps.  Round 5: the feature is off for EVERY object
+# (round 4 had kept it in kernels_net.hip, whose <5,2> GEMM tiles needed 186-191 VGPRs beside their 80 AGPRs without the packed forms; their epilogue now
+# walks the tile column group by column group -- 8 instead of 40 live BatchNorm registers -- and sits at 152).  tests/test_build_isa.py disassembles every
+# shipped object and fails on a single v_pk_{mul,add,fma}_f32.  The host half of a compile does not know the feature and says so.
 NO_PACKED_FP32 = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function'] + NO_PACKED_FP32
 # Per-file flags.  kernels_wave.hip: hipcc's SLP vectoriser pairs the depthwise FMAs of the wave front into v_pk_fma_f32 -- which
 # issues no faster than two v_fma_f32 on gfx950 (profiles/exp/valu_bench.hip: 5.85 vs 2 x 3.1 cycles) -- and pays for the pairing
 # with register shuffles (61 v_mov_b32 per row of the k=5 shape) and un-fused multiply + add tails.  Scalar FMAs, no moves.
-FILE_FLAGS = {'kernels_wave.hip': ['-fno-slp-vectorize'], 'kernels_dw.hip': ['-fno-slp-vectorize'], 'kernels_raster.hip': NO_PACKED_FP32,
-              'kernels_geom.hip': NO_PACKED_FP32, 'kernels_dist.hip': NO_PACKED_FP32, 'kernels_small.hip': NO_PACKED_FP32}      # kernels_train.hip: one compute stream, and 31.5 -> 31.65 ms without the packed forms   # kernels_dw.hip: see its header
+FILE_FLAGS = {'kernels_wave.hip': ['-fno-slp-vectorize'], 'kernels_dw.hip': ['-fno-slp-vectorize']}   # kernels_dw.hip: see its header
 
 
 def _headers():

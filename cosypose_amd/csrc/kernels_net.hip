@@ -176,11 +176,11 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
     constexpr bool HALF_GATE = sizeof(T) == 2 && !__is_same(T, bf16_t);   // fp16: the gate multiplies as packed halves
     int gsel = 0, grow[MI];
     // chunked A ([sample][K/16][HW][16]): element offset of this lane's row at k = 0, per DMA slot
-    size_t achunk[L];
+    unsigned achunk[L];       // in 16-element chunk rows (32 bits: the launcher checks M * K / 16 < 2^32)
 #pragma unroll
     for (int i = 0; i < L; ++i) {
         const int m = min(m0 + (KG == 1 ? i * NWV + wave : (i * NWV + wave) % NB) * 16 + row, M - 1), bs = m / a.HW;
-        achunk[i] = a.a_chunked ? ((size_t)bs * (K >> 4) * a.HW + (m - bs * a.HW)) * 16 : 0;
+        achunk[i] = a.a_chunked ? (unsigned)bs * (unsigned)(K >> 4) * (unsigned)a.HW + (unsigned)(m - bs * a.HW) : 0u;
     }
     auto issue = [&](int ks) {              // stage ks = the k-blocks ks * KG .. ks * KG + KG - 1
         char* st = lds + (ks % NS) * SB * 1024;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
                 dst = st + sblk * 1024;
                 if (blk < NA) {
                     const int m = m0 + blk * 16 + row, k = kb * KB + kg * EPL;
-                    if (m < M && k < K) src = a.a_chunked ? A + achunk[i] + (size_t)(k >> 4) * a.HW * 16 + (k & 15) : A + (size_t)m * K + k;
+                    if (m < M && k < K) src = a.a_chunked ? A + (size_t)(achunk[i] + (unsigned)(k >> 4) * (unsigned)a.HW) * 16 + (k & 15) : A + (size_t)m * K + k;
                 } else {
                     src = Wp + ((size_t)(nt * NW + (blk - NA)) * a.nkb_total + kb) * 64 * EPL + lane * EPL;
                 }
@@ -421,53 +421,53 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
             for (int ni = 0; ni < NI; ++ni) acc[mi][ni] += red[(mi * NI + ni) * 64];
     }
 
-    // ---- epilogue: lane holds, for pixel row m, the 4*NI consecutive channels starting at nl
+    // ---- epilogue: lane holds, for pixel row m, the 4*NI consecutive channels starting at nl.  Column-group major (round 5): the BatchNorm
+    // scale / bias of ONE store's channels (4 or 8) are live at a time instead of all 8 * NI of them -- that is what lets the <5,2> tile keep its
+    // two waves per SIMD (152 VGPRs beside 80 accumulators; 186-191 before) without packed-fp32 arithmetic (build.NO_PACKED_FP32 holds for the
+    // whole library).
     const int nl = n0 + wn * 16 * NI + kg * 4 * NI;
-    float sc[NI][4], bi[NI][4];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        load4(a.scale + nl + ni * 4, sc[ni]);
-        load4(a.bias + nl + ni * 4, bi[ni]);
-    }
     T* __restrict__ out = (T*)a.out;
     const T* __restrict__ res = (const T*)a.res;
+    constexpr int CG = (sizeof(T) == 2 && NI % 2 == 0) ? 2 : 1;      // sub-tiles per store (16-byte stores where a lane's run allows)
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + (wm * MI + mi) * 16 + row;
-        if (m >= M) continue;
-        float y[NI * 4];
+    for (int n1 = 0; n1 < NI; n1 += CG) {
+        float sc[CG * 4], bi[CG * 4];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[mi][ni][r] * sc[ni][r] + bi[ni][r];
-                if (a.silu) v = v * sigmoid_t<T>(v);
-                y[ni * 4 + r] = v;
-            }
-        const size_t o = (size_t)m * N + nl;
-        if (res) {
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                if (nl + ni * 4 < N) {
-                    float rv[4];
-                    if constexpr (RES_PREFETCH) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) rv[r] = (float)rpre[mi][ni][r];
-                    } else {
-                        load4(res + o + ni * 4, rv);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) y[ni * 4 + r] += rv[r];
-                }
+        for (int c = 0; c < CG; ++c) {
+            load4(a.scale + nl + (n1 + c) * 4, sc + c * 4);
+            load4(a.bias + nl + (n1 + c) * 4, bi + c * 4);
         }
-        if constexpr (sizeof(T) == 2 && NI % 2 == 0) {
+        if (nl + n1 * 4 < N) {
 #pragma unroll
-            for (int ni = 0; ni < NI; ni += 2)
-                if (nl + ni * 4 < N) store8(out + o + ni * 4, y + ni * 4);
-        } else {
+            for (int mi = 0; mi < MI; ++mi) {
+                const int m = m0 + (wm * MI + mi) * 16 + row;
+                if (m >= M) continue;
+                float y[CG * 4];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                if (nl + ni * 4 < N) store4(out + o + ni * 4, y + ni * 4);
+                for (int c = 0; c < CG; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[mi][n1 + c][r] * sc[c * 4 + r] + bi[c * 4 + r];
+                        if (a.silu) v = v * sigmoid_t<T>(v);
+                        y[c * 4 + r] = v;
+                    }
+                const size_t o = (size_t)m * N + nl + n1 * 4;
+                if (res) {
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) {
+                        float rv[4];
+                        if constexpr (RES_PREFETCH) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) rv[r] = (float)rpre[mi][n1 + c][r];
+                        } else {
+                            load4(res + o + c * 4, rv);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[c * 4 + r] += rv[r];
+                    }
+                }
+                if constexpr (CG == 2) store8(out + o, y); else store4(out + o, y);
+            }
         }
     }
 }
@@ -582,6 +582,7 @@ static int launch_pw_t(const PwArgs& a, PwCfg c, int dtype, hipStream_t s) {
     k.a_nt = tune_int("COSY_PW_ANT", 1) && a.a_chunked && k.NT == 1 && (size_t)a.M * a.K * sizeof(T) >= ((size_t)64 << 20);
     COSY_REQUIRE(a.zeros, "pw_gemm: the zero page is missing");
     if (a.a_chunked && a.K % 16) { set_error("pw_gemm: the chunked activation layout needs K %% 16 == 0 (K=%d)", a.K); return COSY_EINVAL; }
+    COSY_REQUIRE(!a.a_chunked || (size_t)a.M * (size_t)(a.K >> 4) < ((size_t)1 << 32), "pw_gemm: %d rows x %d channels exceed the chunked layout's 32-bit row index", a.M, a.K);
     return a.gate ? launch_pw_dma<T, true>(k, c, grid, s) : launch_pw_dma<T, false>(k, c, grid, s);
 }
 

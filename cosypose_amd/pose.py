@@ -38,6 +38,19 @@ class PosePredictor(nn.Module):
         self.drop_connect_rate = train_engine.DROP_CONNECT_RATE   # train mode only (efficientnet.py:182-185)
         self.__dict__['_engines'] = EnginePool(backbone, self.pose_fc)   # one engine per HIP stream
 
+    # caches hung on the module by this package (name tables, the flat optimizer that re-homed the parameters, ...) are not state: a copy or a
+    # pickle of the model must not drag a 43 MB optimizer (or another model's tensor tables) along; engines are rebuilt lazily by the copy
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in [k for k in state if k.startswith('_cosy_')]:
+            del state[k]
+        state['_engines'] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self.__dict__['_engines'] = EnginePool(self.backbone, self.pose_fc)
+
     def enable_debug(self):
         self.debug = True
 

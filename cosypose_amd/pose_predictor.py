@@ -28,6 +28,9 @@ _ITERATION_FIELDS = (('poses', 'TCO_output'), ('poses_input', 'TCO_input'), ('K_
 _ITERATION_SHAPES = (('poses', (4, 4)), ('poses_input', (4, 4)), ('K_crop', (3, 3)), ('boxes_rend', (4,)), ('boxes_crop', (4,)))
 
 
+_ACCEPTS = {}       # (forward function, keyword) -> bool, see CoarseRefinePosePredictor._accepts
+
+
 def _iteration_key(n):
     return f'iteration={n}'
 
@@ -54,6 +57,25 @@ class CoarseRefinePosePredictor(torch.nn.Module):
         return lanes[:n]
 
     @staticmethod
+    def _accepts(model, name):
+        """does model.forward take the keyword `name` (this package's extensions `frames_nhwc4=` / `out=`)?  A coarse / refiner pair may mix a
+        cosypose_amd PosePredictor with any module that has the reference's forward signature."""
+        import inspect
+        fwd = getattr(model, 'forward', None)
+        if fwd is None:
+            return False
+        key = (getattr(fwd, '__func__', fwd), name)          # per forward FUNCTION: get_predictions asks on every call
+        hit = _ACCEPTS.get(key)
+        if hit is None:
+            try:
+                params = inspect.signature(fwd).parameters
+                hit = name in params or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
+            except (TypeError, ValueError):
+                hit = False
+            _ACCEPTS[key] = hit
+        return hit
+
+    @staticmethod
     def _frames4(model, images):
         """the frames' interleaved copy, made ONCE per call for every model / chunk that crops from them (models without the hook: None)"""
         make = getattr(model, 'frames_to_nhwc4', None)
@@ -65,7 +87,7 @@ class CoarseRefinePosePredictor(torch.nn.Module):
         per_iteration = {_iteration_key(n): [] for n in range(1, n_iterations + 1)}
         n_objects = len(obj_data)
         extra = {}
-        if n_objects > self.bsz_objects or frames_nhwc4 is not None:      # several chunks share one conversion of the frames
+        if (n_objects > self.bsz_objects or frames_nhwc4 is not None) and self._accepts(model, 'frames_nhwc4'):      # several chunks share one conversion of the frames
             f4 = frames_nhwc4 if frames_nhwc4 is not None else self._frames4(model, images)
             if f4 is not None:
                 extra = dict(frames_nhwc4=f4)
@@ -157,7 +179,9 @@ class CoarseRefinePosePredictor(torch.nn.Module):
         preds = dict()
         assert detections is not None or data_TCO_init is not None, 'get_predictions needs detections or data_TCO_init'
         n_objects = len(detections if data_TCO_init is None else data_TCO_init)
-        if self.n_streams > 1 and n_objects > self.bsz_objects and self._streams_usable():
+        stage_models = [m for m, n in ((self.coarse_model, n_coarse_iterations if data_TCO_init is None else 0), (self.refiner_model, n_refiner_iterations)) if n > 0]
+        lanes_ok = all(self._accepts(m, 'out') and self._accepts(m, 'frames_nhwc4') for m in stage_models if m is not None)    # foreign models: sequential path
+        if self.n_streams > 1 and n_objects > self.bsz_objects and self._streams_usable() and lanes_ok:
             if data_TCO_init is None:
                 assert detections is not None and self.coarse_model is not None and n_coarse_iterations > 0
                 start = self.make_TCO_init(detections, K)
@@ -176,7 +200,7 @@ class CoarseRefinePosePredictor(torch.nn.Module):
 
         def run_stage(stage, model, start, n_iterations):
             if 'f4' not in shared:                 # one conversion of the frames for the coarse and the refiner model and all their chunks
-                shared['f4'] = self._frames4(model, images)
+                shared['f4'] = next((self._frames4(m, images) for m in stage_models if m is not None and hasattr(m, 'frames_to_nhwc4')), None)
             out = self.batched_model_predictions(model, images, K, start, n_iterations=n_iterations, frames_nhwc4=shared['f4'])
             for n in range(1, n_iterations + 1):
                 preds[f'{stage}/{_iteration_key(n)}'] = out[_iteration_key(n)]

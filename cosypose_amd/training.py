@@ -93,7 +93,8 @@ class DevicePrefetcher:
     consumer's stream waits for the upload's event (the host does not).  The device tensors live in TWO persistent slots (no
     allocator traffic, no frees that wait for another stream): batch j+1 goes into the slot batch j-1 used, after an event recorded
     on the consumer's stream when batch j is requested -- by then all of step j-1 has been enqueued.  So a batch's device tensors
-    are valid until the batch after next is requested; a consumer that keeps them longer must clone them.  Batches are shallow
+    are valid until the NEXT batch is requested (requesting batch j enqueues the upload of batch j+1 into the slot batch j-1 used, gated
+    only on the work enqueued so far); a consumer that keeps them longer -- logging the previous batch during the next step -- must clone them.  Batches are shallow
     copies: the caller's objects keep their host tensors.  Host tensors should be page-locked (DataLoader(pin_memory=True)) --
     pageable ones are uploaded synchronously by the runtime and only the ordering benefit remains."""
     FIELDS = ('images', 'K', 'TCO', 'bboxes')
@@ -111,6 +112,7 @@ class DevicePrefetcher:
 
     def _upload(self, batch, slot):
         held, moved = self._slots[slot], {}
+        consumer = torch.cuda.current_stream(self.device)        # captured BEFORE the copy-stream context: inside it current_stream is the copy stream
         with torch.cuda.stream(self.stream):
             if self._free[slot] is not None:
                 self.stream.wait_event(self._free[slot])            # the step that read this slot's previous batch is through
@@ -121,7 +123,7 @@ class DevicePrefetcher:
                 buf = held.get(name)
                 if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
                     if buf is not None:
-                        buf.record_stream(torch.cuda.current_stream(self.device))
+                        buf.record_stream(consumer)      # a replaced buffer may still be read by the consumer's queued kernels
                     buf = held[name] = torch.empty(t.shape, dtype=t.dtype, device=self.device)
                 buf.copy_(t, non_blocking=True)
                 moved[name] = buf
@@ -231,9 +233,15 @@ def train_loop(model, mesh_db, cfg, batches, n_epochs, save_dir=None, start_epoc
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     is_ddp = hasattr(model, 'module')
     if optimizer is None:
+        # direct_grads (the backward writes straight into FlatAdam's flat buffer and returns None per parameter) must be OFF under a
+        # DistributedDataParallel wrapper: DDP averages through per-parameter autograd hooks, which would never fire
         optimizer = train_engine.FlatAdam(model.module if is_ddp else model, lr=cfg.lr, weight_decay=getattr(cfg, 'weight_decay', 0.0),
-                                          clip_grad_norm=cfg.clip_grad_norm)
+                                          clip_grad_norm=cfg.clip_grad_norm, direct_grads=not is_ddp)
     flat = isinstance(optimizer, train_engine.FlatAdam)
+    if flat and is_ddp and optimizer.direct_grads:
+        raise ValueError('train_loop: a FlatAdam with direct_grads=True under DistributedDataParallel would skip DDP\'s gradient hooks (the ranks '
+                         'would apply un-averaged gradients): build it with direct_grads=False, or pass the bare module and let train_loop '
+                         'average with train_engine.allreduce_gradients')
     if world > 1 and not is_ddp and not flat:
         raise ValueError('train_loop: %d ranks, but the model is not DistributedDataParallel and the optimizer is not FlatAdam: '
                          'the ranks would train independently (wrap the model in DDP or use train_engine.FlatAdam)' % world)
@@ -247,6 +255,7 @@ def train_loop(model, mesh_db, cfg, batches, n_epochs, save_dir=None, start_epoc
         bpe = cfg.epoch_size // cfg.batch_size
     history = {}
     schedule = None
+    prefetcher = None
     for epoch in range(start_epoch, n_epochs):
         it = batches(epoch) if callable(batches) else batches
         items = list(it) if schedule is None and not hasattr(it, '__len__') else it
@@ -254,7 +263,14 @@ def train_loop(model, mesh_db, cfg, batches, n_epochs, save_dir=None, start_epoc
             schedule = LRSchedule(cfg.lr, cfg.n_epochs_warmup, bpe or len(items), cfg.lr_epoch_decay, start_epoch=start_epoch, faithful=faithful_schedule)
         model.train()
         meters = LazyMeters(_Mean) if lazy_meters and torch.cuda.is_available() else defaultdict(_Mean)
-        feed = DevicePrefetcher(items) if prefetch and torch.cuda.is_available() else items
+        if prefetch and torch.cuda.is_available():       # ONE prefetcher (copy stream + two persistent slots) for all epochs
+            if prefetcher is None:
+                prefetcher = DevicePrefetcher(items)
+            else:
+                prefetcher.batches = items
+            feed = prefetcher
+        else:
+            feed = items
         for b, sample in enumerate(feed):
             schedule.apply(optimizer, epoch, b)
             optimizer.zero_grad()

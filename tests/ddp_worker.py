@@ -51,7 +51,28 @@ def main(rank, world, port, q):
         loss.backward()
         torch.cuda.synchronize()
         grads = {n: p.grad.detach().double().cpu().numpy() for n, p in model.named_parameters()}
-        q.put((rank, float(loss.item()), {n: (float(g.sum()), float(np.abs(g).sum())) for n, g in grads.items()}))
+        report = {n: (float(g.sum()), float(np.abs(g).sum())) for n, g in grads.items()}
+        # train_loop(DDP(model)) with its default optimizer (FlatAdam): two steps on rank-specific batches.  FlatAdam's direct gradient path
+        # writes into its flat buffer and returns None per parameter -- under DDP that would skip the averaging hooks; train_loop must build
+        # it with direct_grads=False, and the ranks must end with identical weights (round 4's advisor finding).
+        if world > 1:
+            from cosypose_amd import training, train_engine
+            tcfg = argparse.Namespace(**vars(cfg), lr=3e-4, weight_decay=0.0, n_epochs_warmup=0, lr_epoch_decay=10, clip_grad_norm=0.5, n_iterations=1)
+            for p_ in model.parameters():
+                p_.grad = None
+            hist = training.train_loop(ddp, mesh_db, tcfg, lambda e: [data, data], n_epochs=1, prefetch=False, lazy_meters=False)
+            opt = model.__dict__['_cosy_flat_adam']
+            assert isinstance(opt, train_engine.FlatAdam) and not opt.direct_grads
+            try:
+                training.train_loop(ddp, mesh_db, tcfg, lambda e: [data], n_epochs=1, optimizer=train_engine.FlatAdam(model, direct_grads=True))
+                report['__refused__'] = (0.0, 0.0)
+            except ValueError:
+                report['__refused__'] = (1.0, 1.0)
+            torch.cuda.synchronize()
+            w = torch.cat([p_.detach().reshape(-1) for p_ in model.parameters()]).double()
+            report['__weights__'] = (float(w.sum()), float(w.abs().sum()))
+            report['__loss__'] = (float(hist[0]), 1.0)
+        q.put((rank, float(loss.item()), report))
         if world > 1:
             dist.barrier()
         dist.destroy_process_group()

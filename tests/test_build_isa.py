@@ -76,27 +76,34 @@ def test_gemm_kernels_keep_their_occupancy_and_do_not_spill():
             assert r['scratch'] <= 32 and r['agpr'] == 0, (name, r)
 
 
-def test_small_kernel_objects_hold_no_packed_fp32_arithmetic():
-    """kernels_raster / kernels_geom / kernels_dist / kernels_small (squeeze-excite, pooling + FC, probes) are built without the packed-fp32 target feature (build.NO_PACKED_FP32): on gfx950 a wave's
+def test_no_object_holds_packed_fp32_arithmetic():
+    """Every object of the library is built without the packed-fp32 target feature (build.NO_PACKED_FP32 is part of build.FLAGS): on gfx950 a wave's
     v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 results are wrong while another wave of its SIMD -- another HIP stream's backbone kernel -- issues 16-bit
-    MFMAs with VGPR accumulators (profiles/r04_raster_streams.txt).  The shipped objects are disassembled and searched for the instructions."""
+    MFMAs with VGPR accumulators (profiles/r04_raster_streams.txt, profiles/r05_pkf32_victim.txt).  Round 4 held this for the small-wave kernels only;
+    since round 5 ALL shipped objects are disassembled and searched for the instructions (the GEMM epilogues were restructured to fit their register
+    budget without the packed forms)."""
     import subprocess, re
     from cosypose_amd import build as hipbuild
     hipbuild.build()
+    assert all(f in hipbuild.FLAGS for f in hipbuild.NO_PACKED_FP32)
     objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
     bundler = '/opt/rocm/lib/llvm/bin/clang-offload-bundler'
     import tempfile, os
-    for src in ('kernels_raster.hip', 'kernels_geom.hip', 'kernels_dist.hip', 'kernels_small.hip'):
-        assert hipbuild.NO_PACKED_FP32[-1] in hipbuild.FILE_FLAGS.get(src, []), src
+    with_device_code = 0
+    for src in hipbuild.SOURCES:
         obj = hipbuild._obj(src)
         with tempfile.TemporaryDirectory() as tmp:
             co, fat = os.path.join(tmp, 'dev.co'), os.path.join(tmp, 'fat.bin')
             r = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-objcopy', f'--dump-section=.hip_fatbin={fat}', obj], capture_output=True, text=True)
-            assert r.returncode == 0, r.stderr[-400:]
+            if r.returncode != 0 or not os.path.exists(fat):
+                assert src == 'effnet.hip', (src, r.stderr[-400:])       # the schedule: host code only
+                continue
             r = subprocess.run([bundler, '--unbundle', '--type=o', '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', f'--input={fat}', f'--output={co}'],
                                capture_output=True, text=True)
             assert r.returncode == 0 and os.path.getsize(co) > 0, r.stderr[-400:]
             asm = subprocess.run([objdump, '-d', co], capture_output=True, text=True).stdout
         assert 'v_' in asm, 'empty disassembly of ' + src
+        with_device_code += 1
         hits = re.findall(r'v_pk_(?:mul|add|fma)_f32', asm)
         assert not hits, (src, len(hits))
+    assert with_device_code >= 8

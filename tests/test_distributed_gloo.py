@@ -142,6 +142,28 @@ def _worker_body(rank, world, port, q):
     ok &= _same(_drop_external(out), _drop_external(r2))
     final, out = get_predictions_sharded(pred, images, K, detections=det[np.zeros(0, np.int64)], n_refiner_iterations=1)
     ok &= len(final) == 0
+    if world == 8:
+        # BASELINE configs[3] rehearsed at its real rank count: 8 ranks, the bench's skew [512,384,320,256,224,160,128,64] scaled down 16x
+        # (128 candidates), then with the last rank's share EMPTY, through the real collective -- SCALE's 8-GPU run must not be the first
+        # 8-rank execution of this path (replaces cosypose/utils/tensor_collection.py:142-163's file-system gather).
+        from cosypose_amd.distributed import get_predictions_sharded_scenes, plan_shards
+        det8, images8, K8 = _global_table(128, 9)
+        _, ref8 = pred.get_predictions(images8, K8, detections=det8, n_coarse_iterations=1, n_refiner_iterations=4)
+        skew8 = [32, 24, 20, 16, 14, 10, 8, 4]
+        assert [len(p) for p in plan_shards(128, 8, 'counts', counts=skew8)] == skew8
+        for counts in (skew8, [36, 24, 20, 16, 14, 10, 8, 0], [0, 0, 0, 128, 0, 0, 0, 0]):
+            final, out = get_predictions_sharded(pred, images8, K8, detections=det8, n_coarse_iterations=1, n_refiner_iterations=4,
+                                                 balance='counts', counts=counts)
+            ok &= _same(out, ref8) and torch.equal(final.poses, ref8['refiner/iteration=4'].poses)
+        # mixed frame sizes (7 scenes as in bench.py --config 3), skewed and cost-balanced, one collective per call
+        scenes = []
+        for g, (Dg, nf) in enumerate(((19, 3), (18, 2), (18, 4), (18, 2), (18, 3), (18, 2), (19, 5))):
+            dg, ig, kg = _global_table(Dg, nf)
+            scenes.append((ig[:, :, :4 + g], kg, dg))           # different frame sizes per scene
+        ref_sc = torch.cat([pred.get_predictions(i, k, detections=t, n_coarse_iterations=1, n_refiner_iterations=4)[0].poses for i, k, t in scenes])
+        for kw in (dict(balance='counts', counts=skew8), dict(balance='cost'), dict(balance='contiguous')):
+            poses_sc, plan_sc = get_predictions_sharded_scenes(pred, scenes, 1, 4, **kw)
+            ok &= torch.equal(poses_sc, ref_sc) and sum(len(p) for p in plan_sc) == 128
     # training: DDP's gradient averaging as one all-reduce of the flat gradient buffer
     from cosypose_amd.train_engine import allreduce_gradients
     gflat = torch.full((1000,), float(rank + 1))
@@ -152,7 +174,7 @@ def _worker_body(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 4])
+@pytest.mark.parametrize('world', [2, 4, 8])
 def test_gather_and_sharded_predictor_gloo(world):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()

@@ -334,3 +334,40 @@ def test_training_scheduling_helpers_on_the_host():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match='no GPU'):
             training.DevicePrefetcher([types.SimpleNamespace(images=torch.zeros(1))])
+
+
+def test_predictor_accepts_models_with_the_reference_forward_signature():
+    """A coarse / refiner pair may mix this package's PosePredictor with any module that has the REFERENCE's forward signature
+    (models/pose.py:89: images, K, labels, TCO, n_iterations): the package's extensions (`frames_nhwc4=`, `out=`, concurrent lanes) are only used
+    with models that take them -- a foreign model runs the sequential path also under n_streams > 1 (round 4's advisor finding: TypeError)."""
+    import pandas as pd
+    import torch
+    from cosypose_amd import tensor_collection as tc
+    from cosypose_amd.pose_predictor import CoarseRefinePosePredictor
+
+    class Foreign(torch.nn.Module):
+        calls = 0
+
+        def forward(self, images, K, labels, TCO, n_iterations=1, im_ids=None):
+            Foreign.calls += 1
+            out, cur = {}, TCO
+            for n in range(1, n_iterations + 1):
+                nxt = cur.clone(); nxt[:, 2, 3] += 0.125
+                B = len(labels)
+                out[f'iteration={n}'] = dict(TCO_input=cur, TCO_output=nxt, K_crop=K[torch.as_tensor(im_ids)], model_outputs={},
+                                             boxes_rend=torch.zeros(B, 4), boxes_crop=torch.ones(B, 4))
+                cur = nxt
+            return out
+
+    D = 5
+    infos = pd.DataFrame(dict(label=[f'o{i}' for i in range(D)], batch_im_id=[0, 1, 0, 1, 0], score=1.0))
+    init = tc.PandasTensorCollection(infos=infos, poses=torch.eye(4).repeat(D, 1, 1))
+    images, K = torch.zeros(2, 3, 8, 8), torch.eye(3).repeat(2, 1, 1)
+    for n_streams in (1, 2):
+        pred = CoarseRefinePosePredictor(coarse_model=None, refiner_model=Foreign(), bsz_objects=2, n_streams=n_streams)
+        final, allp = pred.get_predictions(images, K, data_TCO_init=init, n_coarse_iterations=0, n_refiner_iterations=2)
+        assert list(allp) == ['external_coarse', 'refiner/iteration=1', 'refiner/iteration=2']
+        assert torch.equal(final.poses[:, 2, 3], torch.full((D,), 0.25)) and len(final) == D
+    assert Foreign.calls == 6 and not CoarseRefinePosePredictor._accepts(Foreign(), 'out')
+    from cosypose_amd.pose import PosePredictor
+    assert CoarseRefinePosePredictor._accepts(PosePredictor.__new__(PosePredictor), 'out')
