@@ -94,7 +94,7 @@ def build(force=False, verbose=False, tune=False):
         _write_resources(s, r.stderr, tune)
 
     def compile_one(s):
-        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(s, []) + (['-DCOSY_TUNE'] if tune else []) + ['-c', os.path.join(CSRC, s), '-o', _obj(s, tune)]
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(s, []) + (['-DCOSY_TUNE'] + (['-DCOSY_WAVE_STAMPS'] if os.environ.get('COSY_WAVE_STAMPS') else []) if tune else []) + ['-c', os.path.join(CSRC, s), '-o', _obj(s, tune)]
         if s == 'kernels_wave.hip' and not tune:
             # keep the device assembly of this very compile: the ISA check reads what was linked, not a second compile
             tmp = tempfile.mkdtemp(prefix='cosy_wave_')

@@ -158,7 +158,8 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
     static_assert(GW * KG == NWV && WM * WN == GW, "wave grid");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* dummy = lds + NS * SB * 1024;
-    float* gl = (float*)(dummy + 1024);   // GATE: [nsamp][Kpad] gate rows of the samples under this m-tile
+    float* sbl = (float*)(dummy + 1024);  // [256] BatchNorm scale + [256] bias of this n-tile's columns (DMA'd in front of the first stage, read by the epilogue)
+    float* gl = (float*)(dummy + 3072);   // GATE: [nsamp][Kpad] gate rows of the samples under this m-tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kgp = KG == 1 ? 0 : wave / GW, wq = KG == 1 ? wave : wave % GW;      // K-group, wave inside the group (constants for the plain tiles)
@@ -213,6 +214,17 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // BatchNorm scale / bias of the tile's columns -> LDS by two DMAs per wave, OLDER than every operand DMA (so any wait that proves stage 0 proves
+    // them; all waves write the same bytes).  The epilogue reads them column group by column group at LDS latency: neither 8 * NI live registers
+    // (what made the <5,2> tile need the packed-fp32 forms to stay at 176 VGPRs) nor one dependent L2 round trip per column group.
+    {
+        static_assert(BN <= 256, "scale / bias staging holds 256 columns");
+        const int c4 = min(lane * 4, BN - 4);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.scale + n0 + c4),
+                                         (__attribute__((address_space(3))) void*)sbl, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.bias + n0 + c4),
+                                         (__attribute__((address_space(3))) void*)(sbl + 256), 16, 0, 0);
+    }
 #pragma unroll
     for (int s0 = 0; s0 < NS - 1; ++s0) issue(s0);
     // Behind the first DMAs, in the same latency shadow: the residual rows this lane will add in the epilogue (2-byte types:
@@ -362,14 +374,15 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
                     a8 = a8 * g8;
                     fa[mi] = __builtin_bit_cast(raw_t, a8);
                 } else {
-                    float g[EPL], f[EPL];
                     const float* gp = gl + grow[mi] + kb * KB + kg * EPL;
 #pragma unroll
-                    for (int e = 0; e < EPL; e += 4) load4(gp + e, g + e);
-                    to_f32(fa[mi], f);
+                    for (int e0 = 0; e0 < EPL; e0 += 4) {      // four elements at a time, repacked before the next four are unpacked (left alone,
+                        float g[4];                            // hipcc keeps all MI * EPL products live: one register too many for the <2,1> tile)
+                        load4(gp + e0, g);
 #pragma unroll
-                    for (int e = 0; e < EPL; ++e) f[e] *= g[e];
-                    from_f32(fa[mi], f);
+                        for (int e = 0; e < 4; ++e) fa[mi][e0 + e] = (T)((float)fa[mi][e0 + e] * g[e]);
+                        asm volatile("" : "+v"(fa[mi]));
+                    }
                 }
             }
         } else if constexpr (GATE && HALF_GATE) {
@@ -434,8 +447,8 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
         float sc[CG * 4], bi[CG * 4];
 #pragma unroll
         for (int c = 0; c < CG; ++c) {
-            load4(a.scale + nl + (n1 + c) * 4, sc + c * 4);
-            load4(a.bias + nl + (n1 + c) * 4, bi + c * 4);
+            load4(sbl + (nl - n0) + (n1 + c) * 4, sc + c * 4);
+            load4(sbl + 256 + (nl - n0) + (n1 + c) * 4, bi + c * 4);
         }
         if (nl + n1 * 4 < N) {
 #pragma unroll
@@ -480,7 +493,7 @@ static int launch_pw_dma_mi(PwKArgs k, hipStream_t s) {
     const int grid = cdiv(k.MT, 8) * 8 * k.NT;
     k.rowgate = GATE && (k.HW % 64 != 0);
     k.nsamp = k.rowgate ? pw_gate_nsamp(16 * MI * WM, k.HW) : 2;
-    const size_t lds = (size_t)NS * NB * 1024 + 1024 + (GATE ? (size_t)k.nsamp * k.nkb_total * DT<T>::KB * 4 : 0) +
+    const size_t lds = (size_t)NS * NB * 1024 + 3072 + (GATE ? (size_t)k.nsamp * k.nkb_total * DT<T>::KB * 4 : 0) +
                        (GATE && k.se_wr ? ((size_t)k.nkb_total * DT<T>::KB + 128) * 4 : 0);       // + pooled[Kpad], redv[<= 128]
     COSY_REQUIRE(lds <= 160 * 1024, "pw_gemm_dma: the gate rows of %d samples x K=%d do not fit the LDS (map of %d pixels too small)", k.nsamp, k.K, k.HW);
     // once per instantiation and process, race-free: function-local statics are initialised exactly once (C++11), also when two
@@ -903,7 +916,7 @@ struct FuseSKArgs {
 };
 
 template <typename T, int KS, int S, int R, int KBN, int MPW, bool ROWMAP = false>
-__global__ __launch_bounds__(512) void mbconv_small_kernel(FuseSKArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) void mbconv_small_kernel(FuseSKArgs a) {
     using raw_t = typename DT<T>::raw_t;
     constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
     constexpr int NI = 3, CC = 48, PITCH = et_pitch(4, S), CPT = 4, NG = CC / CPT;

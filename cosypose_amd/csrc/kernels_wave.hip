@@ -43,7 +43,12 @@ struct WaveKArgs {
     // map's columns; only the four strides below and the order of the taps know: the map is addressed through them.
     int xs_pix, xs_row;      // bytes between two neighbouring pixels of a row / between two rows of the block input
     int ds_pix, ds_row;      // elements between two neighbouring pixels of a row / between two rows inside a D chunk
+    // -DCOSY_TUNE only (null in the shipping library): s_memtime stamps of one job in every `stamp_stride`-th workgroup (wave 0), see WAVE_STAMP
+    unsigned long long* stamps; int stamp_stride, stamp_slots;
 };
+// Timeline of a job (-DCOSY_WAVE_STAMPS build only): the shader clock (s_memtime) at the job's start, behind its prologue, at the start of every
+// input row (scalar bookkeeping: sum / min / max of the row-to-row intervals) and at its end -> 8 words per recorded job.  A first version with
+// five LDS-parked stamps per row pinned hipcc's schedule so hard that the kernels ran 3-5x slower and spilled: a timeline of a different kernel.
 
 template <int CTRL> __device__ __forceinline__ float dpp_mov0(float v) {   // lanes without a source read 0 (bound_ctrl:0)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
@@ -148,6 +153,24 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
 
     float* P = smem_w + wave * PFW;
     char* Wl = (char*)(P + PF);
+#ifdef COSY_WAVE_STAMPS
+    // timeline build (python -m cosypose_amd.build --tune with COSY_WAVE_STAMPS=1 in the environment): scalar-only bookkeeping, no LDS, no VGPRs
+    const bool stamping = a.stamps != nullptr && wave == 0 && blockIdx.x % a.stamp_stride == 0 && (int)(blockIdx.x / a.stamp_stride) < a.stamp_slots;
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long st_t1 = 0, st_first = 0;
+    unsigned st_prev = 0, st_sum = 0, st_min = 0xffffffffu, st_max = 0, st_n = 0;
+#define WAVE_STAMP_ROW()                                                                  \
+    do {                                                                                  \
+        const unsigned long long t64_ = __builtin_amdgcn_s_memtime();                     \
+        const unsigned t_ = (unsigned)t64_;                                               \
+        const unsigned d_ = t_ - st_prev;                                                 \
+        if (st_n == 0) st_first = t64_;                                                   \
+        else { st_sum += d_; st_min = min(st_min, d_); st_max = max(st_max, d_); }        \
+        st_prev = t_; ++st_n;                                                             \
+    } while (0)
+#else
+#define WAVE_STAMP_ROW() do { } while (0)
+#endif
 
     const T* __restrict__ X = (const T*)a.X + (size_t)min(b, a.B - 1) * a.H * a.W * a.Cin;
     const float* Pl = P + kg * 4;            // this lane's channel quad inside every 16-float group
@@ -236,6 +259,9 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
         }
     }
     if (!active) return;
+#ifdef COSY_WAVE_STAMPS
+    st_t1 = __builtin_amdgcn_s_memtime();
+#endif
 
     float acc[NOPEN][TO][NCH];               // output rows in flight (input-stationary accumulation)
 #pragma unroll
@@ -284,6 +310,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
             if constexpr (!IN) { if (iy < iy_first || iy > iy_last) return; }
             // ---- A. expanded row iy (transient registers); its global loads were issued one row ago
             float Er[RP][NCH];
+            WAVE_STAMP_ROW();
             wait_row();
             if (IN || iy < a.H) {
                 float sc0[NCH], bi0[NCH];
@@ -421,6 +448,13 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
         for (int ni = 0; ni < NI; ++ni)
             *(f32x4*)(a.partial + ((size_t)b * a.rsplit + band) * a.Cmid + c0 + ni * 16 + kg * 4) = f32x4{sum[ni * 4], sum[ni * 4 + 1], sum[ni * 4 + 2], sum[ni * 4 + 3]};
     }
+#ifdef COSY_WAVE_STAMPS
+    if (stamping && lane == 0) {
+        unsigned long long* dst = a.stamps + (size_t)(blockIdx.x / a.stamp_stride) * 8;
+        dst[0] = st_n; dst[1] = st_t0; dst[2] = st_t1; dst[3] = st_first; dst[4] = __builtin_amdgcn_s_memtime();
+        dst[5] = st_sum; dst[6] = st_min; dst[7] = st_max;      // over the row-start-to-row-start intervals (st_n - 1 of them)
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -531,8 +565,21 @@ void wave_kernel_name(int Cin, int Cmid, int k, int s, int dtype, int H, int W, 
 
 template <typename T, int KS, int S, int KBN, int PPL, int NI, bool FW, int MW, int RSP>
 static int launch_wave_k(WaveKArgs k, int* n_tiles_out, hipStream_t s) {
-    const size_t lds = (size_t)4 * ((4 + KS * KS) * 16 * NI * sizeof(float) + (wave_wlds(KBN, MW) ? NI * KBN * 1024 : 0));
+    size_t lds = (size_t)4 * ((4 + KS * KS) * 16 * NI * sizeof(float) + (wave_wlds(KBN, MW) ? NI * KBN * 1024 : 0));
     k.dbg = tune_int("COSY_WAVE_DBG", 0);
+    k.stamps = nullptr; k.stamp_stride = 1; k.stamp_slots = 0;
+#ifdef COSY_TUNE
+    // COSY_WAVE_STAMP_PTR = device address of a (slots, WAVE_STAMPS_MAX + 2) uint64 buffer; only launches whose Cmid equals COSY_WAVE_STAMP_CMID
+    // record (profiles/exp/wave_timeline.py sets both around one forward)
+    if (const char* sp = getenv("COSY_WAVE_STAMP_PTR")) {
+        const char* sc = getenv("COSY_WAVE_STAMP_CMID");
+        if (sc && atoi(sc) == k.Cmid) {
+            k.stamps = (unsigned long long*)strtoull(sp, nullptr, 0);
+            k.stamp_stride = getenv("COSY_WAVE_STAMP_STRIDE") ? atoi(getenv("COSY_WAVE_STAMP_STRIDE")) : 64;
+            k.stamp_slots = getenv("COSY_WAVE_STAMP_SLOTS") ? atoi(getenv("COSY_WAVE_STAMP_SLOTS")) : 64;
+        }
+    }
+#endif
     k.rsplit = tune_int("COSY_WAVE_RSPLIT", RSP);
     if (k.rsplit < 1) k.rsplit = 1;
     if (k.rsplit > WAVE_MAX_RSPLIT) k.rsplit = WAVE_MAX_RSPLIT;

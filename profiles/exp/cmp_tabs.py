@@ -10,5 +10,5 @@ tabs={n:tab(n) for n in names}
 base=tabs[names[0]]
 for k in sorted(base):
     vals=[tabs[n].get(k,-1) for n in names]
-    if max(vals)-min(vals)>2.0: print(k, " ".join("%7.1f"%v for v in vals))
+    if max(vals)-min(vals)>float(__import__("os").environ.get("THR","2.0")): print(k, " ".join("%7.1f"%v for v in vals))
 print("total", " ".join("%7.1f"%sum(tabs[n].values()) for n in names))

@@ -57,8 +57,13 @@ __global__ __launch_bounds__(256, 4) void aggressor(const _Float16* __restrict__
     dst[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
 }
 
-enum { V_PKFMA = 0, V_PKMULADD, V_PKVEC, V_SCALAR, V_N };
-static const char* v_name[V_N] = {"v_pk_fma_f32 (asm)", "v_pk_mul_f32 + v_pk_add_f32 (asm)", "float2 C++ (compiler's pk forms)", "scalar v_fma_f32 (control)"};
+enum { V_PKFMA = 0, V_PKMULADD, V_PKVEC, V_PKFMA_SGPR, V_PKFMA_OPSEL, V_PKFMA_NEG, V_PAIR_PLAIN, V_PAIR_SWZ, V_PAIR_NOP, V_SRC1_SWZ, V_SRC1_SWZ_NEG, V_EXACT, V_SCALAR, V_N };
+static const char* v_name[V_N] = {"v_pk_fma_f32 v,v,v,v (asm, no modifiers)", "v_pk_mul_f32 + v_pk_add_f32 (asm, no modifiers)", "float2 C++ (compiler's pk forms: SGPR operands, op_sel, neg)",
+                                  "v_pk_fma_f32 with an SGPR-pair source (asm)", "v_pk_fma_f32 with op_sel / op_sel_hi swizzle (asm)", "v_pk_fma_f32 with neg_lo / neg_hi (asm)",
+                                  "two DEPENDENT v_pk_fma_f32 back to back, no modifiers (asm)", "v_pk_fma_f32 -> dependent v_pk_fma_f32 reading the halves SWAPPED (op_sel), back to back (asm)",
+                                  "the same swapped pair with s_nop 4 between the two (asm)",
+                                  "v_pk_fma_f32 -> dependent v_pk_fma_f32 taking the result as SRC1 with swapped halves (asm)", "the same with neg_lo / neg_hi on src2 (asm)",
+                                  "hipcc's exact sequence: pk_fma, two scalar v_fma, dependent pk_fma (src1 swapped, src2 negated) (asm)", "scalar v_fma_f32 (control)"};
 
 // out[i] = packed-chain result (2 floats), chk[i] = number of chain steps at which the lane's packed result differed from its scalar twin
 template <int FORM>
@@ -84,6 +89,34 @@ __global__ __launch_bounds__(256) void victim(const float* __restrict__ in, floa
         } else if constexpr (FORM == V_PKVEC) {
             p = p * m + y;          // contracts to v_pk_fma_f32 (fp-contract=fast is hipcc's default)
             p = f32x2{p[1], p[0]} * m - y;      // a swizzled form (op_sel)
+        } else if constexpr (FORM == V_PKFMA_SGPR) {
+            // the multiplier pair from SGPRs (wave-uniform: a function of the loop counter), as hipcc emits for uniform operands
+            const float u0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m0)));
+            const float u1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m1)));
+            const f32x2 ms = {u0, u1};
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p) : "s"(ms), "v"(y));
+        } else if constexpr (FORM == V_PKFMA_OPSEL) {
+            // lo = p.hi * m.lo + y.lo, hi = p.lo * m.hi + y.hi
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "+v"(p) : "v"(m), "v"(y));
+        } else if constexpr (FORM == V_PKFMA_NEG) {
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "+v"(p) : "v"(m), "v"(y));
+        } else if constexpr (FORM == V_PAIR_PLAIN) {
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p) : "v"(m), "v"(y));
+        } else if constexpr (FORM == V_PAIR_SWZ) {
+            // second: lo = p.hi * m.lo + y.lo, hi = p.lo * m.hi + y.hi -- it needs BOTH halves of the first one's result for each of its halves
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "+v"(p) : "v"(m), "v"(y));
+        } else if constexpr (FORM == V_SRC1_SWZ) {
+            // second: lo = m.lo * p.hi + y.lo, hi = m.hi * p.lo + y.hi  (the first one's result enters as src1)
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %1, %0, %2 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "+v"(p) : "v"(m), "v"(y));
+        } else if constexpr (FORM == V_SRC1_SWZ_NEG) {
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %1, %0, %2 op_sel:[0,1,0] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "+v"(p) : "v"(m), "v"(y));
+        } else if constexpr (FORM == V_EXACT) {
+            float d0 = s0, d1 = s1;
+            asm volatile("v_pk_fma_f32 %0, %0, %3, %4\n v_fma_f32 %1, %1, %5, %6\n v_fma_f32 %2, %2, %7, %8\n"
+                         "v_pk_fma_f32 %0, %3, %0, %4 op_sel:[0,1,0] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]"
+                         : "+v"(p), "+v"(d0), "+v"(d1) : "v"(m), "v"(y), "v"(m0), "v"(y[0]), "v"(m1), "v"(y[1]));
+        } else if constexpr (FORM == V_PAIR_NOP) {
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2\n s_nop 4\n v_pk_fma_f32 %0, %0, %1, %2 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "+v"(p) : "v"(m), "v"(y));
         } else {
             float q0 = __builtin_fmaf(p[0], m0, y[0]);
             asm volatile("" : "+v"(q0));       // (kept apart: the SLP vectoriser would pair the two into a v_pk_fma_f32)
@@ -92,7 +125,28 @@ __global__ __launch_bounds__(256) void victim(const float* __restrict__ in, floa
             p = f32x2{q0, q1};
         }
         if constexpr (FORM == V_PKMULADD) {
-            s0 = __fadd_rn(__fmul_rn(s0, m[0]), y[0]); s1 = __fadd_rn(__fmul_rn(s1, m[1]), y[1]);
+            float t0 = s0 * m0, t1 = s1 * m1;
+            asm volatile("" : "+v"(t0), "+v"(t1));        // two roundings, as the packed pair: no contraction into an fma
+            s0 = t0 + y[0]; s1 = t1 + y[1];
+        } else if constexpr (FORM == V_PKFMA_OPSEL) {
+            const float t0 = __builtin_fmaf(s1, m0, y[0]), t1 = __builtin_fmaf(s0, m1, y[1]);
+            s0 = t0; s1 = t1;
+        } else if constexpr (FORM == V_PKFMA_NEG) {
+            s0 = __builtin_fmaf(s0, m0, -y[0]); s1 = __builtin_fmaf(s1, m1, -y[1]);
+        } else if constexpr (FORM == V_PAIR_PLAIN) {
+            s0 = __builtin_fmaf(s0, m0, y[0]); s1 = __builtin_fmaf(s1, m1, y[1]);
+            asm volatile("" : "+v"(s0), "+v"(s1));
+            s0 = __builtin_fmaf(s0, m0, y[0]); s1 = __builtin_fmaf(s1, m1, y[1]);
+        } else if constexpr (FORM == V_PAIR_SWZ || FORM == V_PAIR_NOP || FORM == V_SRC1_SWZ) {
+            s0 = __builtin_fmaf(s0, m0, y[0]); s1 = __builtin_fmaf(s1, m1, y[1]);
+            asm volatile("" : "+v"(s0), "+v"(s1));
+            const float t0 = __builtin_fmaf(s1, m0, y[0]), t1 = __builtin_fmaf(s0, m1, y[1]);
+            s0 = t0; s1 = t1;
+        } else if constexpr (FORM == V_SRC1_SWZ_NEG || FORM == V_EXACT) {
+            s0 = __builtin_fmaf(s0, m0, y[0]); s1 = __builtin_fmaf(s1, m1, y[1]);
+            asm volatile("" : "+v"(s0), "+v"(s1));
+            const float t0 = __builtin_fmaf(s1, m0, -y[0]), t1 = __builtin_fmaf(s0, m1, -y[1]);
+            s0 = t0; s1 = t1;
         } else if constexpr (FORM == V_PKVEC) {
             s0 = __builtin_fmaf(s0, m[0], y[0]); s1 = __builtin_fmaf(s1, m[1], y[1]);
             const float t0 = __builtin_fmaf(s1, m[0], -y[0]), t1 = __builtin_fmaf(s0, m[1], -y[1]);
@@ -122,6 +176,15 @@ static void run_victim(int form, int grid, size_t lds, hipStream_t s, const floa
         case V_PKFMA: launch_victim<V_PKFMA>(grid, lds, s, in, out, chk, n, steps); break;
         case V_PKMULADD: launch_victim<V_PKMULADD>(grid, lds, s, in, out, chk, n, steps); break;
         case V_PKVEC: launch_victim<V_PKVEC>(grid, lds, s, in, out, chk, n, steps); break;
+        case V_PKFMA_SGPR: launch_victim<V_PKFMA_SGPR>(grid, lds, s, in, out, chk, n, steps); break;
+        case V_PKFMA_OPSEL: launch_victim<V_PKFMA_OPSEL>(grid, lds, s, in, out, chk, n, steps); break;
+        case V_PKFMA_NEG: launch_victim<V_PKFMA_NEG>(grid, lds, s, in, out, chk, n, steps); break;
+        case V_PAIR_PLAIN: launch_victim<V_PAIR_PLAIN>(grid, lds, s, in, out, chk, n, steps); break;
+        case V_PAIR_SWZ: launch_victim<V_PAIR_SWZ>(grid, lds, s, in, out, chk, n, steps); break;
+        case V_PAIR_NOP: launch_victim<V_PAIR_NOP>(grid, lds, s, in, out, chk, n, steps); break;
+        case V_SRC1_SWZ: launch_victim<V_SRC1_SWZ>(grid, lds, s, in, out, chk, n, steps); break;
+        case V_SRC1_SWZ_NEG: launch_victim<V_SRC1_SWZ_NEG>(grid, lds, s, in, out, chk, n, steps); break;
+        case V_EXACT: launch_victim<V_EXACT>(grid, lds, s, in, out, chk, n, steps); break;
         default: launch_victim<V_SCALAR>(grid, lds, s, in, out, chk, n, steps); break;
     }
 }
