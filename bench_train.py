@@ -21,6 +21,82 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 
+HBM_PEAK_GBS = 8000.0
+
+
+def bn_tensor_bytes(B, H, W):
+    """fp32 bytes of every tensor a train-mode BatchNorm of EfficientNet-B3 normalises, for B crops of H x W (stem, bn0 / bn1 / bn2 of the 26
+    blocks, head): the unit the BatchNorm kernels stream several times per step"""
+    from cosypose_amd import arch
+    h, w = arch.conv_out(H, 3, 2), arch.conv_out(W, 3, 2)
+    n = float(h * w * 40)
+    for (k, s, e, cin, cout) in arch.B3_BLOCKS:
+        ho, wo = arch.conv_out(h, k, s), arch.conv_out(w, k, s)
+        if e != 1:
+            n += h * w * cin * e
+        n += ho * wo * cin * e + ho * wo * cout
+        h, w = ho, wo
+    n += h * w * 1536
+    return 4.0 * B * n
+
+
+def bn_roofline(torch, run_step, B, H, W):
+    """roofline object of the step's dominant kernel family: the train-mode BatchNorm kernels (statistics, apply + Swish, backward reduce,
+    backward apply: cosypose_amd/csrc/kernels_train.hip), HBM-bound.  Their device time comes from ONE torch.profiler step behind the timed
+    region; algorithmic bytes = 8 passes over the normalised tensors (forward: statistics read, apply read + write; backward: the reduce
+    reads dy and x, the apply reads dy and x and writes dx) -- the gated forms read the (B, C) gate rows besides, which is noise."""
+    from collections import defaultdict
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        run_step()
+    fam, total = defaultdict(lambda: [0.0, 0]), 0.0
+    for e in prof.key_averages():
+        t = getattr(e, 'self_device_time_total', None)
+        if t is None:
+            t = e.self_cuda_time_total
+        total += t / 1e3
+        k = e.key
+        name = ('batchnorm (bn_stats / bn_apply / bn_bwd_reduce / bn_bwd_apply)' if 'bn_' in k else 'depthwise (dw_fwd / dw_bwd_data / dw_bwd_weight)' if 'dw_' in k else
+                '1x1-conv GEMMs (pw_gemm_dma_kernel<float>)' if 'pw_gemm' in k or 'pw_pack' in k else 'weight gradients (wgrad)' if 'wgrad' in k else
+                'per-sample reductions / squeeze-excite' if 'rows_' in k or 'se_' in k else 'other')
+        fam[name][0] += t / 1e3; fam[name][1] += e.count
+    bn_ms, bn_n = fam['batchnorm (bn_stats / bn_apply / bn_bwd_reduce / bn_bwd_apply)']
+    alg = 8.0 * bn_tensor_bytes(B, H, W)
+    ach = alg / (bn_ms * 1e-3) / 1e9 if bn_ms else 0.0
+    return dict(bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                kernel='bn_* kernels of kernels_train.hip (family: %d launches per step)' % bn_n, family_ms_per_step=round(bn_ms, 2),
+                algorithmic_bytes_per_step=int(alg), launches_per_step=bn_n, device_ms_per_step=round(total, 2),
+                families_ms={k: round(v[0], 2) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])},
+                source='one torch.profiler step behind the timed region; bytes = 8 passes over the fp32 tensors the BatchNorms normalise')
+
+
+def cpu_baseline_train(H, W, B=8, repeats=3):
+    """the oracle's training step (torch-CPU autograd over the functional restatement of the reference's network + disentangled loss) on a
+    bounded sample: B crops, forward + backward, warm-up then the median of `repeats`, 16 threads"""
+    sys.path.insert(0, os.path.join(REPO, 'oracle'))
+    import torch
+    import cosy_oracle as O
+    from cosypose_amd import synthetic as syn
+    threads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    rs = np.random.RandomState(0)
+    x = rs.rand(B, 6, H, W).astype(np.float32)
+    TCO = syn.make_TCO(1, B)
+    gt = TCO[:, None].copy()                       # (B, n_sym = 1, 4, 4) ground truths
+    gt[:, 0, :3, 3] += rs.normal(0, 0.02, (B, 3)).astype(np.float32)
+    K = syn.make_K(B, H, W)
+    pts = (rs.uniform(-1, 1, (B, 2600, 3)) * rs.uniform(0.03, 0.12, (B, 1, 3))).astype(np.float32)
+    ts = []
+    for i in range(repeats + 1):
+        ref = O.TorchRef(syn.golden_state_dict(1))
+        t0 = time.time()
+        ref.train_forward_backward(x, gt, TCO, K, pts)
+        ts.append(time.time() - t0)
+    v = B / float(np.median(ts[1:]))
+    return dict(value=round(v, 3), unit='crops/s (forward + backward)', cores=threads, kind='port',
+                sample=f'{B} crops of {H}x{W}, fp32, train-mode forward + disentangled loss + backward of the torch-CPU oracle, warm-up then median of {repeats}')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -28,6 +104,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--kernels', action='store_true', help='per-kernel table from torch.profiler to stderr')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true', help='skip the profiled step (no roofline object)')
     ap.add_argument('--upload', choices=('prefetch', 'in_step'), default='prefetch',
                     help="prefetch: batch i+1 is uploaded on a copy stream while step i runs (training.DevicePrefetcher, what train_loop does); "
                          "in_step: h_pose's .cuda() uploads the batch at the top of its own step (the reference's order)")
@@ -144,6 +222,11 @@ def main():
         print('time by family (ms/step): ' + ', '.join(f'{k} {v:.2f}' for k, v in sorted(fam.items(), key=lambda kv: -kv[1])), file=sys.stderr)
         for t, n, k in sorted(gemms, reverse=True)[:8]:
             print(f'  gemm {t:8.2f} ms  x{n:3d}  {k}', file=sys.stderr)
+    roofline = cpu_base = None
+    if rank == 0 and not args.no_profile:
+        roofline = bn_roofline(torch, lambda: (step(False), torch.cuda.synchronize()), B, H, W)
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu_base = cpu_baseline_train(H, W)
     if rank == 0:
         ms = 1e3 * dt / args.steps
         print(json.dumps({
@@ -157,6 +240,7 @@ def main():
                        'n_points_loss': 2600, 'drop_connect_rate': model.drop_connect_rate, 'process_group': process_group_info()},
             'split_ms': {k: round(v / nsp, 2) for k, v in split.items()},
             'peak_memory_gb': round(torch.cuda.max_memory_allocated() / 1e9, 2),
+            'roofline': roofline, 'cpu_baseline': cpu_base,
         }))
 
 

@@ -85,6 +85,10 @@ struct cosy_net {
     int dtype, H, W, maxB, esz, Hs, Ws, Hf, Wf;
     void* stem_w;
     float *stem_scale, *stem_bias, *fc_w, *fc_b;
+    // stem conv + block 0's depthwise front as one kernel (kernels_stem.hip): 16-bit types, 256-pixel-wide inputs.  A forward that is asked for
+    // the stem tensor itself (test probe -1, the per-stage taps) runs stem_kernel + dwconv instead -- both sets of weights exist.
+    bool stem_fused;
+    void* stemf_w; float* stemf_params; void* dump;
     cosy::Block blk[26];
     cosy::PwLayer head;
     void* X;
@@ -155,10 +159,12 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         L.scale = up_f32(sc); L.bias = up_f32(bi);
     };
     // stem: (40,6,3,3) -> MFMA fragment blocks (implicit GEMM, K = 9 taps x 8 channels)
+    const float* stem_w_host = p;
+    std::vector<float> stem_sc_host, stem_bi_host;
     {
         const size_t ne = stem_packed_elems(n->dtype);
         n->stem_w = bump.take(ne * n->esz);
-        std::vector<float> sc, bi;
+        std::vector<float>& sc = stem_sc_host; std::vector<float>& bi = stem_bi_host;
         if (fill) {
             std::vector<char> tmp(ne * n->esz);
             stem_pack_weights(p, n->dtype, tmp.data());
@@ -232,6 +238,19 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
             if (fill) fold_bn(p, b.cmid, b.cmid, sc, bi); else { sc.assign(b.cmid, 0.f); bi.assign(b.cmid, 0.f); }
             p += 4 * b.cmid;
             b.dw_w = up_f32(w); b.dw_scale = up_f32(sc); b.dw_bias = up_f32(bi);
+            if (i == 0 && n->stem_fused) {      // the fused stem + depthwise front: stem weights per 16-channel chunk, both BatchNorms + taps per chunk
+                n->stemf_w = bump.take(stem_front_weight_elems() * n->esz);
+                std::vector<float> sp(stem_front_param_floats(), 0.f);
+                if (fill) {
+                    std::vector<char> tmp(stem_front_weight_elems() * n->esz);
+                    stem_front_pack_weights(stem_w_host, n->dtype, tmp.data());
+                    hipError_t e2 = hipMemcpy(n->stemf_w, tmp.data(), tmp.size(), hipMemcpyHostToDevice);
+                    if (e2 != hipSuccess) *herr = e2;
+                    stem_front_pack_params(stem_sc_host.data(), stem_bi_host.data(), w.data(), sc.data(), bi.data(), sp.data());
+                }
+                n->stemf_params = up_f32(sp);
+                b.n_tiles = std::max(b.n_tiles, stem_front_tiles(n->H));
+            }
             if (b.wave) {
                 std::vector<float> wp(wave_params_floats(b.cmid, b.d.k), 0.f);
                 if (fill) wave_pack_params(exp_sc.data(), exp_bi.data(), w.data(), sc.data(), bi.data(), b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W, wp.data());
@@ -341,7 +360,7 @@ static void layout_ws(cosy_net* n, Bump& b, cosy_net::WS& w, size_t B) {
         if (i == EARLY_BLOCKS - 1) act_l = std::max(act_l, (size_t)k.Ho * k.Wo * k.d.cout);  // hand-over tensor
         if (k.d.e != 1 && !k.fused) ex = std::max(ex, (size_t)k.H * k.W * k.cmid);
         if (k.to_rowmajor) ex = std::max(ex, (size_t)k.Ho * k.Wo * k.d.cout);      // the project GEMM writes there, the re-ordering copy into the output
-        dw = std::max(dw, (size_t)k.Ho * k.Wo * k.cmid);
+        dw = std::max(dw, (size_t)k.Ho * k.Wo * (i == 0 && n->stem_fused ? (size_t)((k.cmid + 15) & ~15) : (size_t)k.cmid));     // (stem front: chunked D, 40 -> 48 channels)
         part = std::max(part, (size_t)k.n_tiles * k.cmid * (early ? Bc : B));
         gate = std::max(gate, (size_t)k.cmid);
     }
@@ -361,7 +380,8 @@ static void layout_ws(cosy_net* n, Bump& b, cosy_net::WS& w, size_t B) {
 }
 static void layout_workspace(cosy_net* n, Bump& b) {
     n->X = b.take((size_t)n->maxB * n->H * n->W * 8 * n->esz);
-    n->zeros = b.take(256);   // stays zero: the workspace is memset at creation and nothing writes here
+    n->zeros = b.take(256);   // stays zero: the workspace is memset at creation and nothing writes here (directly behind X: the stem front reaches it by a 32-bit offset)
+    n->dump = b.take(stem_front_dump_bytes());
     n->crop_taps = b.take(crop_taps_bytes(n->maxB, n->H, n->W));
     layout_ws(n, b, n->ws[0], n->maxB);
     if (n->nstreams == 2) layout_ws(n, b, n->ws[1], (n->maxB + 1) / 2);
@@ -404,11 +424,21 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         return launch_nhwc_to_nchw(act, Bc, HW, C, n->dtype, n->probe_out + (size_t)b0 * HW * C, s, chunked, colH);
     };
     // one MBConv block on Bc samples: [expand 1x1] -> depthwise (+squeeze partials) -> SE gate -> project 1x1 (+residual)
-    auto run_block = [&](int i, const void* in, void* out, int Bc, void* Ebuf, void* Dbuf, int b0) -> int {
+    // stem_x != nullptr (block 0 only): the front is the fused stem + depthwise kernel reading the network input; `in` is unused then
+    auto run_block = [&](int i, const void* in, void* out, int Bc, void* Ebuf, void* Dbuf, int b0, const void* stem_x = nullptr) -> int {
         const Block& b = n->blk[i];
         const void* src = in;
         int se_tiles = b.fused ? b.n_tiles : b.dw_tiles;     // partial-sum tiles per sample the front kernel writes (the wave kernel decides per launch)
-        if (b.fused) {
+        if (stem_x) {
+            StemFrontArgs f{};
+            f.X = stem_x; f.Wp = n->stemf_w; f.params = n->stemf_params; f.D = Dbuf; f.partial = w.partial; f.dump = n->dump; f.zeros = n->zeros;
+            f.B = Bc; f.H = n->H; f.W = n->W;
+            if ((rc = launch_stem_front(f, n->dtype, s))) return rc;
+            se_tiles = stem_front_tiles(n->H);
+            snprintf(kn, sizeof(kn), "stem_front_kernel<%s>", dt_name(n->dtype));
+            if ((rc = mark(kn, 0, ((double)Bc * n->H * n->W * 8 + (double)Bc * b.Ho * b.Wo * 48) * esz_d,
+                           2.0 * Bc * n->Hs * n->Ws * STEM_C * IN_C * 9 + 2.0 * Bc * b.Ho * b.Wo * b.cmid * 9, (double)Bc * n->H * n->W * 8 * esz_d))) return rc;
+        } else if (b.fused) {
             FuseArgs f{};
             f.X = in; f.Wp = b.exp_wp_fused;
             if (b.small) { f.b0 = b.b0_fold; f.dww = b.dw_w_fold; f.b1 = b.dw_bias; }
@@ -462,7 +492,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         a.res = b.skip ? in : nullptr; a.gate = w.gate; a.se_fused = b.se_fused ? &se : nullptr;
         a.M = Bc * b.Ho * b.Wo; a.K = b.cmid; a.N = b.d.cout; a.HW = b.Ho * b.Wo; a.silu = 0; a.zeros = n->zeros;
         // the wave front (and the row-mapped 8x8 kernel) write D as [sample][Cmid/16][HW][16]
-        a.a_chunked = b.wave || (b.small && small_writes_chunked(b.d.cin, b.cmid, b.H, b.W, b.Ho, b.Wo, b.d.k, b.d.s, n->dtype));
+        a.a_chunked = stem_x != nullptr || b.wave || (b.small && small_writes_chunked(b.d.cin, b.cmid, b.H, b.W, b.Ho, b.Wo, b.d.k, b.d.s, n->dtype));
         if ((rc = probe(100 + i, Dbuf, Bc, b0, b.Ho * b.Wo, b.cmid, a.a_chunked, b.out_col ? b.Ho : 0))) return rc;
         if ((rc = launch_pw_gemm(a, b.proj.cfg, n->dtype, s))) return rc;
         if (n->probe_layer == 200 + i && n->probe_out)      // behind the GEMM: with the squeeze-excite in its prologue that is where the gate is written
@@ -484,17 +514,22 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int Bc = std::min(chunk, B - b0);
         const char* x = (const char*)n->X + (size_t)(x_off + b0) * n->H * n->W * 8 * e;
-        if ((rc = launch_stem(x, n->stem_w, n->stem_scale, n->stem_bias, w.actc[0], Bc, n->H, n->W, n->Hs, n->Ws, n->dtype, s))) return rc;
-        snprintf(kn, sizeof(kn), "stem_kernel<%s>", dt_name(n->dtype));
-        if ((rc = mark(kn, -1, ((double)Bc * n->H * n->W * 8 + (double)Bc * n->Hs * n->Ws * STEM_C) * esz_d, 2.0 * Bc * n->Hs * n->Ws * STEM_C * IN_C * 9,
-                       ((double)Bc * n->H * n->W * 8 + (double)Bc * n->Hs * n->Ws * STEM_C) * esz_d))) return rc;
-        if ((rc = tap(w.actc[0], Bc, b0, n->Hs * n->Ws, STEM_C, 0))) return rc;
-        if ((rc = probe(-1, w.actc[0], Bc, b0, n->Hs * n->Ws, STEM_C, 0))) return rc;
+        // the stem tensor only exists when somebody wants to look at it (per-stage taps, test probe -1); otherwise the stem conv runs inside
+        // block 0's front kernel
+        const bool stemf = n->stem_fused && !taps && n->probe_layer != -1;
+        if (!stemf) {
+            if ((rc = launch_stem(x, n->stem_w, n->stem_scale, n->stem_bias, w.actc[0], Bc, n->H, n->W, n->Hs, n->Ws, n->dtype, s))) return rc;
+            snprintf(kn, sizeof(kn), "stem_kernel<%s>", dt_name(n->dtype));
+            if ((rc = mark(kn, -1, ((double)Bc * n->H * n->W * 8 + (double)Bc * n->Hs * n->Ws * STEM_C) * esz_d, 2.0 * Bc * n->Hs * n->Ws * STEM_C * IN_C * 9,
+                           ((double)Bc * n->H * n->W * 8 + (double)Bc * n->Hs * n->Ws * STEM_C) * esz_d))) return rc;
+            if ((rc = tap(w.actc[0], Bc, b0, n->Hs * n->Ws, STEM_C, 0))) return rc;
+            if ((rc = probe(-1, w.actc[0], Bc, b0, n->Hs * n->Ws, STEM_C, 0))) return rc;
+        }
         int cur = 0;
         for (int i = 0; i < EARLY_BLOCKS; ++i) {
             const Block& b = n->blk[i];
             void* out = (i == EARLY_BLOCKS - 1) ? (void*)((char*)w.act[0] + (size_t)b0 * handover) : w.actc[cur ^ 1];
-            if ((rc = run_block(i, w.actc[cur], out, Bc, w.Ec, w.Dc, b0))) return rc;
+            if ((rc = run_block(i, w.actc[cur], out, Bc, w.Ec, w.Dc, b0, i == 0 && stemf ? x : nullptr))) return rc;
             cur ^= 1;
             const int ti = stage_tap_index(i);
             if (ti >= 0 && (rc = tap(out, Bc, b0, b.Ho * b.Wo, b.d.cout, ti, b.out_col && !b.to_rowmajor ? b.Ho : 0))) return rc;
@@ -596,6 +631,8 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
         // Same-box A/B against the round-3 tree (profiles/r04_vs_r03_layers.txt): blocks 5-13 gain 2-6 us each; blocks 14-17 (Cse = 34,
         // Cmid = 816: the largest prologue) lose 1.7 us each -> not fused.
         n->se_fuse_mask = (unsigned)tune_int("COSY_SE_FUSE_MASK", 0x3fe0);
+        n->stem_fused = n->fuse && stem_front_supported(dtype, H, W);
+        n->stemf_w = nullptr; n->stemf_params = nullptr;
         n->small_mask = (unsigned)tune_int("COSY_SMALL_MASK", 0x3f80000);
         n->tile_mask = (unsigned)tune_int("COSY_TILE_MASK", 0x13c);         // blocks 2-5 and 8 (measured in round 1: it loses on the k=5 stride-1 blocks 6/7)   // blocks 19-25 (8x8 / 7x10 maps): whole-image kernel
         n->wave_mask = (unsigned)tune_int("COSY_WAVE_MASK", 0x3fffc);   // blocks 2-17: maps 16..128 pixels wide, stride per shape table
@@ -691,7 +728,7 @@ int cosy_effnet_b3_block_info(const cosy_net_t* n, int i, int* dims) {
     // where the project GEMM applies the squeeze-excite gate: to the weight fragments (maps of a multiple of 64 pixels: a wave's 64
     // rows belong to one sample) or to the activation rows
     const int gate_w = (b.Ho * b.Wo) % 64 == 0;
-    const int v[11] = {b.H, b.W, b.Ho, b.Wo, b.d.cin, b.cmid, b.d.cout, b.wave ? 1 : b.small ? 2 : b.tiled ? 3 : 0, b.d.k, b.d.s, gate_w};
+    const int v[11] = {b.H, b.W, b.Ho, b.Wo, b.d.cin, b.cmid, b.d.cout, i == 0 && n->stem_fused ? 4 : b.wave ? 1 : b.small ? 2 : b.tiled ? 3 : 0, b.d.k, b.d.s, gate_w};
     for (int q = 0; q < 11; ++q) dims[q] = v[q];
     return COSY_OK;
 }

@@ -92,6 +92,26 @@ void wave_kernel_name(int Cin, int Cmid, int k, int s, int dtype, int H, int W, 
 int wave_max_tiles();   // upper bound of the row bands (partial-sum tiles per sample) a launch may use
 int launch_mbconv_wave(const FuseArgs& a, int dtype, int* n_tiles_out, hipStream_t s);
 
+// stem conv + block 0's depthwise front in one wave-autonomous kernel (kernels_stem.hip): the stem tensor never exists in memory.
+// 16-bit storage types, 256-pixel-wide inputs; D is written chunked as [sample][3][Hs * Ws][16] (channels 40..47 zero)
+struct StemFrontArgs {
+    const void* X;          // (B, H, W, 8) network input
+    const void* Wp;         // stem_front_pack_weights
+    const float* params;    // stem_front_pack_params
+    void* D; float* partial;
+    void* dump;             // stem_front_dump_bytes() of scratch (finished rows outside a job's band land there)
+    const void* zeros;      // the zero page: must lie behind X, within 4 GB of it (the padding taps are fetched from it by offset)
+    int B, H, W;
+};
+bool stem_front_supported(int dtype, int H, int W);
+int stem_front_tiles(int H);                 // squeeze partial-sum tiles per sample the kernel writes
+size_t stem_front_weight_elems();
+size_t stem_front_param_floats();
+size_t stem_front_dump_bytes();
+void stem_front_pack_weights(const float* w_oihw /*(40,6,3,3)*/, int dtype, void* dst);
+void stem_front_pack_params(const float* s0, const float* b0, const float* dww /*[tap][40]*/, const float* s1, const float* b1, float* dst);
+int launch_stem_front(const StemFrontArgs& a, int dtype, hipStream_t s);
+
 struct SeArgs {
     const float* partial;  // (B, n_tiles, C)
     int n_tiles;

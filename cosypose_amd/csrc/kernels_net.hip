@@ -181,7 +181,7 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
 #pragma unroll
     for (int i = 0; i < L; ++i) {
         const int m = min(m0 + (KG == 1 ? i * NWV + wave : (i * NWV + wave) % NB) * 16 + row, M - 1), bs = m / a.HW;
-        achunk[i] = a.a_chunked ? (unsigned)bs * (unsigned)(K >> 4) * (unsigned)a.HW + (unsigned)(m - bs * a.HW) : 0u;
+        achunk[i] = a.a_chunked ? (unsigned)bs * (unsigned)((K + 15) >> 4) * (unsigned)a.HW + (unsigned)(m - bs * a.HW) : 0u;
     }
     auto issue = [&](int ks) {              // stage ks = the k-blocks ks * KG .. ks * KG + KG - 1
         char* st = lds + (ks % NS) * SB * 1024;
@@ -594,8 +594,8 @@ static int launch_pw_t(const PwArgs& a, PwCfg c, int dtype, hipStream_t s) {
     // NOT for the NHWC outputs of the unfused depthwise kernel (blocks 0 / 1: 131.6 -> 154.9, 127.9 -> 133.8 us with the hint).
     k.a_nt = tune_int("COSY_PW_ANT", 1) && a.a_chunked && k.NT == 1 && (size_t)a.M * a.K * sizeof(T) >= ((size_t)64 << 20);
     COSY_REQUIRE(a.zeros, "pw_gemm: the zero page is missing");
-    if (a.a_chunked && a.K % 16) { set_error("pw_gemm: the chunked activation layout needs K %% 16 == 0 (K=%d)", a.K); return COSY_EINVAL; }
-    COSY_REQUIRE(!a.a_chunked || (size_t)a.M * (size_t)(a.K >> 4) < ((size_t)1 << 32), "pw_gemm: %d rows x %d channels exceed the chunked layout's 32-bit row index", a.M, a.K);
+    // chunked A: [sample][ceil(K / 16)][HW][16]; a last chunk that is half full (K = 40: stem front) is read up to K only (K % 8 == 0)
+    COSY_REQUIRE(!a.a_chunked || (size_t)a.M * (size_t)((a.K + 15) >> 4) < ((size_t)1 << 32), "pw_gemm: %d rows x %d channels exceed the chunked layout's 32-bit row index", a.M, a.K);
     return a.gate ? launch_pw_dma<T, true>(k, c, grid, s) : launch_pw_dma<T, false>(k, c, grid, s);
 }
 

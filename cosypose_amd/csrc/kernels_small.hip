@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__
     const size_t c = i / HW;
     size_t p = i % HW;
     if (colH > 0) { const size_t Wm = (size_t)HW / colH; p = (p % Wm) * colH + p / Wm; }      // row-major pixel (y, x) lives at x * H + y
-    const size_t src = chunked ? ((size_t)b * (C >> 4) + (c >> 4)) * HW * 16 + p * 16 + (c & 15) : ((size_t)b * HW + p) * C + c;
+    const size_t src = chunked ? ((size_t)b * ((C + 15) >> 4) + (c >> 4)) * HW * 16 + p * 16 + (c & 15) : ((size_t)b * HW + p) * C + c;
     out[(size_t)b * HW * C + i] = (float)act[src];
 }
 int launch_nhwc_to_nchw(const void* act, int B, int HW, int C, int dtype, float* out, hipStream_t s, int chunked, int colH) {

@@ -463,11 +463,13 @@ class TorchRef:
             return t.clamp(-65504.0, 65504.0).half().float()
         return t
 
-    def stem_emulated(self, x, storage):
-        """x (B,6,H,W) fp32 (rounded to the storage type here, as the crop kernel does) -> stem output"""
+    def stem_emulated(self, x, storage, round_output=True):
+        """x (B,6,H,W) fp32 (rounded to the storage type here, as the crop kernel does) -> stem output.  round_output=False: the stem tensor as
+        the fused stem + block-0 front holds it (kernels_stem.hip: fp32 rows in registers, never stored)"""
         R = lambda t: self._rnd(t, storage)
         sw = lambda t: t * self.torch.sigmoid(t)
-        return R(sw(self._bn(self._conv(R(x), R(self.sd['backbone._conv_stem.weight']), 3, 2), 'backbone._bn0')))
+        y = sw(self._bn(self._conv(R(x), R(self.sd['backbone._conv_stem.weight']), 3, 2), 'backbone._bn0'))
+        return R(y) if round_output else y
 
     def block_emulated(self, i, x, storage, fused, gate_on_weights=None):
         """MBConv block i on a block input that is already in the storage type -> (D, gate (B,Cmid), block output).
@@ -528,16 +530,19 @@ class TorchRef:
 
     def extract_features_emulated(self, x, storage, fused, probes=None, gate_w=None):
         """x (B,6,H,W) fp32; storage 'bf16' | 'fp16'; fused[i] = front kernel of block i as cosy_effnet_b3_block_info reports it
-        (0 unfused: E is stored; 1 wave, 2 small: E never stored).
+        (0 unfused: E is stored; 1 wave, 2 small: E never stored; 4: block 0 behind the fused stem, the stem tensor never stored).
         probes: dict filled with {-1: stem, i: block output, 100+i: D of block i, 200+i: gate (B,Cmid), 26: head}.
         NOTE: two evaluations of a 26-block network that round at every layer decorrelate with depth (a value one ulp apart
         perturbs the next layer's roundings), so the END-TO-END distance between this and the device grows to the size of
         the storage type's own rounding noise; kernels are therefore checked block by block on the DEVICE's block inputs
         (tests/test_gpu_parity.py: test_fused_kernels_vs_storage_emulation), where the distance stays at isolated ulps."""
         put = (lambda k, v: probes.__setitem__(k, v.clone())) if probes is not None else (lambda k, v: None)
+        x_in = x
         x = self.stem_emulated(x, storage)
         put(-1, x)
         for i in range(len(B3_BLOCKS)):
+            if i == 0 and fused[0] == 4:      # block 0 behind the fused stem: the stem tensor is never stored (fp32 in registers)
+                x = self.stem_emulated(x_in, storage, round_output=False)
             D, g, x = self.block_emulated(i, x, storage, fused[i], None if gate_w is None else gate_w[i])
             put(100 + i, D); put(200 + i, g); put(i, x)
         x = self.head_emulated(x, storage)

@@ -239,6 +239,7 @@ def test_fused_kernels_vs_storage_emulation(model, oracle, golden_sd, dtype, hw)
     x = np.random.RandomState(40 + hw[0]).random_sample((B, 6) + tuple(hw)).astype(np.float32)
     h, plan = _block_plan(model, hw, dtype, B)
     kinds = [p[7] for p in plan]
+    assert (kinds[0] == 4) == (hw[1] == 256), kinds       # the stem + block-0 front: 256-pixel-wide crops (kernels_stem.hip), the unfused kernels elsewhere
     if hw in ((256, 256), (240, 320)):     # blocks 2-17 wave (240x320: block 2's 160-pixel rows are walked as 120-pixel columns), 19-25 small
         assert all(k == 1 for k in kinds[2:18]) and all(k == 2 for k in kinds[19:26]) and kinds[18] == 0, kinds
     if hw == (224, 224):                   # 56-pixel rows of blocks 3 / 4: no wave variant -> tiled; every other front has a !FULLW wave variant
@@ -264,7 +265,11 @@ def test_fused_kernels_vs_storage_emulation(model, oracle, golden_sd, dtype, hw)
         cur = _probe(model, h, x, -1, (B, 40, Hs, Ws))
         compare('stem', cur, tr.stem_emulated(T(x), dtype))
         for i, (H_, W_, Ho, Wo, cin, cmid, cout, kind, k, s_, gate_w) in enumerate(plan):
-            D_e, g_e, y_e = tr.block_emulated(i, T(cur), dtype, kinds[i], bool(gate_w))
+            blk_in = T(cur)
+            if kind == 4:      # block 0 behind the fused stem (kernels_stem.hip): its input is the stem tensor as the kernel holds it -- fp32, never stored
+                assert i == 0
+                blk_in = tr.stem_emulated(T(x), dtype, round_output=False)
+            D_e, g_e, y_e = tr.block_emulated(i, blk_in, dtype, kinds[i], bool(gate_w))
             compare(f'D{i}', _probe(model, h, x, 100 + i, (B, cmid, Ho, Wo)), D_e)
             compare(f'g{i}', _probe(model, h, x, 200 + i, (B, cmid)), g_e, gate=True)
             cur = _probe(model, h, x, i, (B, cout, Ho, Wo))
