@@ -40,13 +40,16 @@ def bn_tensor_bytes(B, H, W):
     return 4.0 * B * n
 
 
-def bn_roofline(torch, run_step, B, H, W):
+def bn_roofline(torch, run_step, B, H, W, profile_on=True):
     """roofline object of the step's dominant kernel family: the train-mode BatchNorm kernels (statistics, apply + Swish, backward reduce,
     backward apply: cosypose_amd/csrc/kernels_train.hip), HBM-bound.  Their device time comes from ONE torch.profiler step behind the timed
     region; algorithmic bytes = 8 passes over the normalised tensors (forward: statistics read, apply read + write; backward: the reduce
     reads dy and x, the apply reads dy and x and writes dx) -- the gated forms read the (B, C) gate rows besides, which is noise."""
     from collections import defaultdict
     from torch.profiler import profile, ProfilerActivity
+    if not profile_on:
+        run_step()
+        return None
     with profile(activities=[ProfilerActivity.CUDA]) as prof:
         run_step()
     fam, total = defaultdict(lambda: [0.0, 0]), 0.0
@@ -223,8 +226,8 @@ def main():
         for t, n, k in sorted(gemms, reverse=True)[:8]:
             print(f'  gemm {t:8.2f} ms  x{n:3d}  {k}', file=sys.stderr)
     roofline = cpu_base = None
-    if rank == 0 and not args.no_profile:
-        roofline = bn_roofline(torch, lambda: (step(False), torch.cuda.synchronize()), B, H, W)
+    if not args.no_profile:          # every rank runs the profiled step (it holds the gradient all-reduce); rank 0's profile makes the object
+        roofline = bn_roofline(torch, lambda: (step(False), torch.cuda.synchronize()), B, H, W, profile_on=rank == 0)
     if rank == 0 and not args.no_cpu_baseline:
         cpu_base = cpu_baseline_train(H, W)
     if rank == 0:

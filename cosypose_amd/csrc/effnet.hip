@@ -433,9 +433,8 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
             StemFrontArgs f{};
             f.X = stem_x; f.Wp = n->stemf_w; f.params = n->stemf_params; f.D = Dbuf; f.partial = w.partial; f.dump = n->dump; f.zeros = n->zeros;
             f.B = Bc; f.H = n->H; f.W = n->W;
-            if ((rc = launch_stem_front(f, n->dtype, s))) return rc;
-            se_tiles = stem_front_tiles(n->H);
-            snprintf(kn, sizeof(kn), "stem_front_kernel<%s>", dt_name(n->dtype));
+            if ((rc = launch_stem_front(f, n->dtype, &se_tiles, s))) return rc;
+            snprintf(kn, sizeof(kn), "stem_front_kernel<%s, %d>", dt_name(n->dtype), n->W / 64);
             if ((rc = mark(kn, 0, ((double)Bc * n->H * n->W * 8 + (double)Bc * b.Ho * b.Wo * 48) * esz_d,
                            2.0 * Bc * n->Hs * n->Ws * STEM_C * IN_C * 9 + 2.0 * Bc * b.Ho * b.Wo * b.cmid * 9, (double)Bc * n->H * n->W * 8 * esz_d))) return rc;
         } else if (b.fused) {
@@ -628,8 +627,9 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
         // fewer per forward.  NOT for blocks 0-4 (their project GEMMs stream 8,000-16,000 workgroups and every one would redo the
         // gate: block 0 160 -> 458 us, blocks 2-4 +13..22 us), block 18 (+3 us) or blocks 19-25 (0.65 / 1.77 MB of FC weights per gate:
         // the size rule in build_weights keeps them on the batched kernels, where a 16-sample tile shares one read of them).
-        // Same-box A/B against the round-3 tree (profiles/r04_vs_r03_layers.txt): blocks 5-13 gain 2-6 us each; blocks 14-17 (Cse = 34,
-        // Cmid = 816: the largest prologue) lose 1.7 us each -> not fused.
+        // Same-box A/B against the round-3 tree (profiles/r04_vs_r03_layers.txt): blocks 5-13 gain 2-6 us each.  Blocks 14-17 (Cse = 34, Cmid = 816:
+        // the largest prologue): fused or not makes no measurable difference (round 5, alternating same-call A/B: backbone 4.551 vs 4.553 ms,
+        // profiles/r05_se_fused_ab.txt; round 4's two records disagreed) -> they keep the batched kernels.
         n->se_fuse_mask = (unsigned)tune_int("COSY_SE_FUSE_MASK", 0x3fe0);
         n->stem_fused = n->fuse && stem_front_supported(dtype, H, W);
         n->stemf_w = nullptr; n->stemf_params = nullptr;

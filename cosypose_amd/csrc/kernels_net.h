@@ -104,13 +104,14 @@ struct StemFrontArgs {
     int B, H, W;
 };
 bool stem_front_supported(int dtype, int H, int W);
-int stem_front_tiles(int H);                 // squeeze partial-sum tiles per sample the kernel writes
+int stem_front_tiles(int H);                 // upper bound of the squeeze partial-sum tiles per sample a launch writes
 size_t stem_front_weight_elems();
 size_t stem_front_param_floats();
 size_t stem_front_dump_bytes();
 void stem_front_pack_weights(const float* w_oihw /*(40,6,3,3)*/, int dtype, void* dst);
 void stem_front_pack_params(const float* s0, const float* b0, const float* dww /*[tap][40]*/, const float* s1, const float* b1, float* dst);
-int launch_stem_front(const StemFrontArgs& a, int dtype, hipStream_t s);
+int launch_stem_front(const StemFrontArgs& a, int dtype, int* n_tiles_out, hipStream_t s);
+
 
 struct SeArgs {
     const float* partial;  // (B, n_tiles, C)

@@ -1,4 +1,4 @@
-// Stem + block 0 front as ONE wave-autonomous kernel (16-bit storage types, 256-pixel-wide crops):
+// Stem + block 0 front as ONE wave-autonomous kernel (16-bit storage types, 256- and 320-pixel-wide crops):
 //     stem conv 3x3 s2 6->40 (MFMA, implicit GEMM) -> BN -> SiLU -> block 0's depthwise 3x3 -> BN -> SiLU -> D, squeeze sums
 // The stem tensor (B x 128 x 128 x 40: 335 MB per 256 crops in a 16-bit type) is never written to or read from memory: it lives as fp32
 // rows in registers exactly as the expanded tensor of the MBConv fronts does (kernels_wave.hip).  Block 0 has no expansion
@@ -6,8 +6,8 @@
 // Reference: EfficientNet.extract_features' stem (efficientnet.py:174-176: _swish(_bn0(_conv_stem(x)))) + MBConvBlock.forward of block 0
 // (:71-84, depthwise + BN + swish; the squeeze-excite gate and the project conv follow in their own kernels).
 //
-//   * job = one wavefront = (sample, 16-channel chunk of the 40 -> 48 stem channels, 64-pixel half of the 128-pixel rows, band of output rows);
-//   * lane (p = lane & 15, kg = lane >> 4) owns the PPL = 4 stem pixels x = 64 * seg + 16 q + p (q = 0..3) and the channel quad kg: the 16 lanes
+//   * job = one wavefront = (sample, 16-channel chunk of the 40 -> 48 stem channels, half of a stem row -- 64 of 128 or 80 of 160 pixels --, band of output rows);
+//   * lane (p = lane & 15, kg = lane >> 4) owns the PPL = 4 (5) stem pixels x = 16 PPL * seg + 16 q + p (q < PPL) and the channel quad kg: the 16 lanes
 //     of a fragment are 16 CONSECUTIVE pixels, so a fragment load touches 16 input pixels 32 bytes apart (the stride-2 window) -- one 512-byte
 //     span per tap -- and an output store covers 512 contiguous bytes.  (First version: x = 4 p + q, neighbours in the lane's own registers as
 //     in kernels_wave.hip; its fragment loads touched 64 different 128-byte lines each and the kernel ran 427 us, bound by the texture
@@ -27,6 +27,7 @@
 // D is written in the chunked layout [sample][3][Hs * Ws][16] (channels 40..47 are exact zeros: zero weights, zero BatchNorm rows), which the
 // project GEMM reads directly (PwArgs::a_chunked with K = 40).
 #include "net_device.h"
+#include <algorithm>
 #include <type_traits>
 #include <vector>
 
@@ -77,12 +78,13 @@ struct StemFrontKArgs {
     int B, H, W, Hs, Ws, rsplit, rows_per, n_tiles;
 };
 
-enum { SF_PPL = 4, SF_KBN = 3, SF_NQ = 5, SF_PF = (4 + 9) * 16 };
+enum { SF_KBN = 3, SF_PF = (4 + 9) * 16 };
 
-template <typename T>
+// PPL = pixels per lane = half-row width / 16: 4 for 256-pixel-wide inputs (128-pixel stem rows), 5 for 320-pixel-wide ones (160-pixel rows)
+template <typename T, int PPL>
 __global__ __launch_bounds__(192, 2) void stem_front_kernel(StemFrontKArgs a) {
     using raw_t = typename DT<T>::raw_t;
-    constexpr int PPL = SF_PPL, KBN = SF_KBN, NQ = SF_NQ, PF = SF_PF;
+    constexpr int KBN = SF_KBN, NQ = PPL + 1, PF = SF_PF, SEGW = 16 * PPL;      // SEGW: stem pixels of a half row
     typedef T out_t __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float sf_smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -115,14 +117,14 @@ __global__ __launch_bounds__(192, 2) void stem_front_kernel(StemFrontKArgs a) {
     // fragment (q, kb) of the lane's own pixels sits at xo[kb] + 512 q (an immediate of the load); so[kb]: the pixel beyond the seam
     unsigned xo[KBN], so[KBN];
     bool ky2[KBN], xoob[KBN];                   // this lane's tap lies in window row 2 / (q = 3 only) beyond the last input column
-    const int xs = seg == 0 ? 64 : 63;          // stem pixel beyond the seam: the right neighbour of the left half, the left neighbour of the right half
+    const int xs = seg == 0 ? SEGW : SEGW - 1;  // stem pixel beyond the seam: the right neighbour of the left half, the left neighbour of the right half
 #pragma unroll
     for (int kb = 0; kb < KBN; ++kb) {
         const int t = 4 * kb + kg, tt = t < 9 ? t : 0;      // taps 9..11: zero weights, any valid pixel will do
         const int ky = tt / 3, kx = tt - ky * 3;
         ky2[kb] = ky == 2;
-        xo[kb] = (unsigned)(ky * rowb + (2 * (seg * 64 + p) + kx) * 16);
-        xoob[kb] = 2 * (seg * 64 + 16 * (PPL - 1) + p) + kx >= a.W;
+        xo[kb] = (unsigned)(ky * rowb + (2 * (seg * SEGW + p) + kx) * 16);
+        xoob[kb] = 2 * (seg * SEGW + 16 * (PPL - 1) + p) + kx >= a.W;
         so[kb] = (unsigned)(ky * rowb + (2 * xs + kx) * 16);
     }
     const char* Xs = (const char*)a.X + (size_t)b * a.H * rowb;
@@ -166,10 +168,10 @@ __global__ __launch_bounds__(192, 2) void stem_front_kernel(StemFrontKArgs a) {
     // ([15 fragment loads][4 row stores]), so hipcc's wait in front of a row's first MFMA is the counted vmcnt(4) on both paths -- without them
     // it has to assume the worst of the two orders and drains the queue (vmcnt(0): the acknowledgement of the row just stored) every third row.
 #pragma unroll
-    for (int t = 0; t < PPL; ++t) *(out_t*)((T*)a.dump + (seg * 64 + 16 * t + p) * 16 + kg * 4) = out_t{(T)0.f, (T)0.f, (T)0.f, (T)0.f};
+    for (int t = 0; t < PPL; ++t) *(out_t*)((T*)a.dump + (seg * SEGW + 16 * t + p) * 16 + kg * 4) = out_t{(T)0.f, (T)0.f, (T)0.f, (T)0.f};
     const float sl = seg == 1 ? 1.f : 0.f, sr = seg == 0 ? 1.f : 0.f;      // which side of this half is the seam (the other is the image border)
     T* __restrict__ Dch = (T*)a.D + (size_t)(b * 3 + ch) * a.Hs * a.Ws * 16;
-    const int dlane = (seg * 64 + p) * 16 + kg * 4;            // element offset of the lane's first pixel (q = 0) inside a row of the chunk; q adds 256
+    const int dlane = (seg * SEGW + p) * 16 + kg * 4;            // element offset of the lane's first pixel (q = 0) inside a row of the chunk; q adds 256
     const int drow = a.Ws * 16;
 
     auto row = [&](auto uc, const int base) {
@@ -282,16 +284,18 @@ __global__ __launch_bounds__(192, 2) void stem_front_kernel(StemFrontKArgs a) {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-enum { SF_RSPLIT = 4 };     // row bands per (sample, chunk, half): 256 crops x 3 x 2 x 4 = 6144 jobs = 3 rounds of the chip's 2048 wave slots
+// row bands per (sample, half).  Measured at 256 crops of 256x256, fp16 (gpurun_out/r05g): 2 / 3 / 4 / 6 / 8 bands -> 302 / 267 / 285 / 280 / 287 us
+// (3 bands = 1536 workgroups of 3 chunk waves; two recomputed stem rows per 43)
+enum { SF_RSPLIT = 3, SF_RSPLIT_MAX = 8 };
 
 bool stem_front_supported(int dtype, int H, int W) {
     static const int on = tune_int("COSY_STEM_FRONT", 1);
-    return on && dtype != COSY_F32 && W == 256 && H >= 64 && H % 2 == 0;
+    return on && dtype != COSY_F32 && (W == 256 || W == 320) && H >= 64 && H % 2 == 0;
 }
-int stem_front_tiles(int H) { (void)H; return 2 * SF_RSPLIT; }
+int stem_front_tiles(int H) { (void)H; return 2 * SF_RSPLIT_MAX; }      // upper bound (sizing); a launch reports what it wrote
 size_t stem_front_weight_elems() { return (size_t)3 * 4 * 64 * 8; }
 size_t stem_front_param_floats() { return (size_t)3 * SF_PF; }
-size_t stem_front_dump_bytes() { return 8192; }      // one row of a chunk: 128 pixels x 32 bytes (the lanes keep their in-row offsets)
+size_t stem_front_dump_bytes() { return 16384; }     // one row of a chunk: <= 160 pixels x 32 bytes (the lanes keep their in-row offsets)
 
 // w: reference layout (40, 6, 3, 3) -> A fragments per 16-channel chunk: row i of chunk c = channel 16 c + i, k = tap * 8 + ci (tap = 3 ky + kx)
 void stem_front_pack_weights(const float* w, int dtype, void* dst) {
@@ -315,21 +319,28 @@ void stem_front_pack_params(const float* s0, const float* b0, const float* dww, 
         }
 }
 
-int launch_stem_front(const StemFrontArgs& f, int dtype, hipStream_t s) {
+int launch_stem_front(const StemFrontArgs& f, int dtype, int* n_tiles_out, hipStream_t s) {
+    static const int rsplit = std::min(std::max(tune_int("COSY_STEM_RSPLIT", SF_RSPLIT), 1), (int)SF_RSPLIT_MAX);
+    *n_tiles_out = 2 * rsplit;
     if (f.B == 0) return COSY_OK;
     COSY_REQUIRE(stem_front_supported(dtype, f.H, f.W), "stem_front: unsupported input %dx%d / dtype %d", f.H, f.W, dtype);
     StemFrontKArgs k;
     k.X = f.X; k.Wp = f.Wp; k.params = f.params; k.D = f.D; k.partial = f.partial; k.dump = f.dump;
     k.B = f.B; k.H = f.H; k.W = f.W; k.Hs = f.H / 2; k.Ws = f.W / 2;
-    k.rsplit = SF_RSPLIT; k.rows_per = cdiv(k.Hs, k.rsplit); k.n_tiles = 2 * SF_RSPLIT;
+    k.rsplit = rsplit; k.rows_per = cdiv(k.Hs, k.rsplit); k.n_tiles = 2 * rsplit;
     k.zrel = (long)((const char*)f.zeros - (const char*)f.X);
     COSY_REQUIRE(k.zrel >= 0 && k.zrel < ((long)1 << 32) - ((long)1 << 24) && (long)f.B * f.H * f.W * 16 <= k.zrel,
                  "stem_front: the zero page must lie behind the input, within 4 GB of its start (zrel %ld)", k.zrel);
     const long wgs_per_xcd = (long)cdiv(f.B, 8) * 2 * k.rsplit;
     const dim3 grid((unsigned)(wgs_per_xcd * 8)), block(192);
     const size_t lds = (size_t)3 * (SF_PF + SF_KBN * 256) * sizeof(float);
-    if (dtype == COSY_BF16) hipLaunchKernelGGL(stem_front_kernel<bf16_t>, grid, block, lds, s, k);
-    else hipLaunchKernelGGL(stem_front_kernel<f16_t>, grid, block, lds, s, k);
+    if (f.W == 256) {
+        if (dtype == COSY_BF16) hipLaunchKernelGGL((stem_front_kernel<bf16_t, 4>), grid, block, lds, s, k);
+        else hipLaunchKernelGGL((stem_front_kernel<f16_t, 4>), grid, block, lds, s, k);
+    } else {
+        if (dtype == COSY_BF16) hipLaunchKernelGGL((stem_front_kernel<bf16_t, 5>), grid, block, lds, s, k);
+        else hipLaunchKernelGGL((stem_front_kernel<f16_t, 5>), grid, block, lds, s, k);
+    }
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }

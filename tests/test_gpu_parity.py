@@ -239,7 +239,7 @@ def test_fused_kernels_vs_storage_emulation(model, oracle, golden_sd, dtype, hw)
     x = np.random.RandomState(40 + hw[0]).random_sample((B, 6) + tuple(hw)).astype(np.float32)
     h, plan = _block_plan(model, hw, dtype, B)
     kinds = [p[7] for p in plan]
-    assert (kinds[0] == 4) == (hw[1] == 256), kinds       # the stem + block-0 front: 256-pixel-wide crops (kernels_stem.hip), the unfused kernels elsewhere
+    assert (kinds[0] == 4) == (hw[1] in (256, 320)), kinds       # the stem + block-0 front: 256- and 320-pixel-wide crops (kernels_stem.hip), the unfused kernels elsewhere
     if hw in ((256, 256), (240, 320)):     # blocks 2-17 wave (240x320: block 2's 160-pixel rows are walked as 120-pixel columns), 19-25 small
         assert all(k == 1 for k in kinds[2:18]) and all(k == 2 for k in kinds[19:26]) and kinds[18] == 0, kinds
     if hw == (224, 224):                   # 56-pixel rows of blocks 3 / 4: no wave variant -> tiled; every other front has a !FULLW wave variant
