@@ -172,7 +172,7 @@ def main():
         e[1].record()
         loss.backward()
         e[2].record()
-        train_engine.allreduce_gradients(opt.grad)
+        train_engine.allreduce_gradients(opt)       # no-op when the backward launched its own bucketed all-reduce (FlatAdam.overlap_allreduce: on with > 1 rank)
         e[3].record()
         opt.step()
         e[4].record()
@@ -240,6 +240,7 @@ def main():
                                    f'loss + backward + gradient all-reduce ({opt.grad.numel() * 4 / 1e6:.1f} MB fp32) + clip 0.5 + Adam',
                        'upload': {'mode': args.upload, 'bytes_per_step': int(data.images.numel())},
                        'host_syncs_per_step': 0,
+                       'gradient_allreduce': 'bucketed (8 MB), launched from inside the backward' if world > 1 else 'none (1 rank)',
                        'n_points_loss': 2600, 'drop_connect_rate': model.drop_connect_rate, 'process_group': process_group_info()},
             'split_ms': {k: round(v / nsp, 2) for k, v in split.items()},
             'peak_memory_gb': round(torch.cuda.max_memory_allocated() / 1e9, 2),

@@ -391,7 +391,10 @@ class _Net:
             torch._foreach_add_(nbt, 1)      # every BatchNorm saw one more batch: one launch for all 79 counters
         return pose, tape
 
-    def backward(self, tape, dpose):
+    def backward(self, tape, dpose, region_done=None):
+        """region_done(name): called when every parameter gradient of a region has been ENQUEUED -- 'head' (conv head, bn1, pose_fc), then block
+        25 .. 0, then 'stem' -- i.e. when a growing suffix of the flat gradient (named_parameters() order) is final: FlatAdam launches the bucketed
+        gradient all-reduce from here, beside the rest of the backward."""
         P = self.P
         grads = {}
         x_head, feat, B, H, W = tape['head']
@@ -405,6 +408,8 @@ class _Net:
         wh = P['backbone._conv_head.weight']
         grads['backbone._conv_head.weight'] = wgrad(draw, x_head, out=D('backbone._conv_head.weight')).view_as(wh)
         dx = gemm(draw, wh.view(arch.HEAD_C, -1), w_is_kn=True, packed=pk)
+        if region_done is not None:
+            region_done('head')
         for i in reversed(range(len(arch.B3_BLOCKS))):
             k, s, e, cin, cout = arch.B3_BLOCKS[i]
             p = f'backbone._blocks.{i}.'
@@ -436,6 +441,8 @@ class _Net:
                 dx = gemm(draw, we.view(cmid, cin), w_is_kn=True, add=dout if skip else None, packed=pk)
             else:
                 dx = da0             # (+ dout for a skip block: already added inside dw_backward)
+            if region_done is not None:
+                region_done(i)
         draw = self._bn_b(tape, grads, 'backbone._bn0', dx)
         cols = tape['stem']
         gstem = wgrad(draw, cols)[:, :54].reshape(arch.STEM_C, 3, 3, 6).permute(0, 3, 1, 2)
@@ -443,6 +450,8 @@ class _Net:
             D('backbone._conv_stem.weight').copy_(gstem)
         else:
             grads['backbone._conv_stem.weight'] = gstem.contiguous()
+        if region_done is not None:
+            region_done('stem')
         return grads
 
 
@@ -456,8 +465,11 @@ class _BackboneTrainFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dpose):
-        grads = ctx.net.backward(ctx.tape, dpose.contiguous().float())
+        overlap = ctx.direct is not None and ctx.direct.begin_overlapped_allreduce()
+        grads = ctx.net.backward(ctx.tape, dpose.contiguous().float(), region_done=ctx.direct.region_done if overlap else None)
         ctx.tape = None
+        if overlap:
+            ctx.direct.finish_overlapped_allreduce()      # waits for the buckets, divides by the world size; accumulate_staged below adds the AVERAGED gradients
         if ctx.direct is not None:
             # every kernel wrote its parameter gradient straight into FlatAdam's staging buffer: ONE add accumulates all 340 of them
             # into the flat gradient (instead of 340 AccumulateGrad launches), and autograd gets nothing to accumulate
@@ -548,7 +560,8 @@ class FlatAdam:
     ONE flat fp32 buffer.  Construction re-homes the parameters (and their .grad) as views of flat buffers, in
     named_parameters() order; the module keeps working as before."""
 
-    def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_grad_norm=0.5, direct_grads=True):
+    def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_grad_norm=0.5, direct_grads=True, overlap_allreduce=None,
+                 bucket_bytes=8 << 20):
         params = [p for p in model.parameters()]
         dev = params[0].device
         require_device(params[0])
@@ -569,16 +582,64 @@ class FlatAdam:
         # wrapper -- its reducer hangs on the per-parameter hooks that never fire then; average with allreduce_gradients(opt) instead
         # (or pass direct_grads=False).
         self.direct_grads = bool(direct_grads)
+        # overlap_allreduce (None = automatic: on when a process group with more than one rank exists): the backward launches the gradient
+        # all-reduce itself, bucket by bucket (>= bucket_bytes of finished gradients each: head + late blocks first), beside the rest of the
+        # backward; the staged gradients are averaged before they are accumulated, `reduced` tells train_loop / allreduce_gradients that this
+        # backward's gradients are already averaged.  Buckets are slices of ONE buffer: elementwise sums, so the result equals the single
+        # all-reduce bit for bit at 2 ranks (any order of two addends) and up to the collective's own chunking beyond.
+        self.overlap_allreduce = overlap_allreduce
+        self.bucket_bytes = int(bucket_bytes)
+        self.reduced = False
+        self._pending, self._hi = [], n
         self.gstage = torch.zeros(n, device=dev)
         self.stage, off = {}, 0
+        self._region_lo = {}          # region ('stem', block index, 'head') -> offset of its first parameter in the flat layout
         for name, p in model.named_parameters():
             self.stage[name] = self.gstage[off:off + p.numel()].view_as(p.data)
+            m_ = name.split('.')
+            region = int(m_[2]) if name.startswith('backbone._blocks.') else ('stem' if name in ('backbone._conv_stem.weight', 'backbone._bn0.weight', 'backbone._bn0.bias') else 'head')
+            self._region_lo.setdefault(region, off)
             off += p.numel()
+        # the regions must tile the buffer in the order the backward finishes them backwards: stem < block 0 < ... < block 25 < head
+        order = ['stem'] + [i for i in range(len(arch.B3_BLOCKS))] + ['head']
+        los = [self._region_lo.get(r, -1) for r in order]
+        self._regions_ok = all(v >= 0 for v in los) and los == sorted(los) and los[0] == 0
         model.__dict__['_cosy_flat_adam'] = self          # found by backbone_train (not a submodule / parameter: invisible to state_dict)
         self.m = torch.zeros(n, device=dev); self.v = torch.zeros(n, device=dev)
         self.norm_coef = torch.ones(2, device=dev)
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, clip_grad_norm
         self.step_count = 0
+
+    def begin_overlapped_allreduce(self):
+        """-> True when this backward is to launch its own bucketed all-reduce (called by the backward node before it starts)"""
+        import torch.distributed as dist
+        on = self.overlap_allreduce
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if on is None:
+            on = multi
+        if not (on and multi and self._regions_ok):
+            return False
+        self._pending, self._hi = [], self.gstage.numel()
+        return True
+
+    def region_done(self, region):
+        """the gradients of `region` and of everything behind it in the flat layout have been enqueued: all-reduce the finished suffix once it holds
+        bucket_bytes (and whatever is left when the stem is done)"""
+        import torch.distributed as dist
+        lo = self._region_lo[region]
+        if (self._hi - lo) * 4 >= self.bucket_bytes or region == 'stem':
+            if self._hi > lo:
+                self._pending.append(dist.all_reduce(self.gstage[lo:self._hi], op=dist.ReduceOp.SUM, async_op=True))
+            self._hi = lo
+
+    def finish_overlapped_allreduce(self):
+        import torch.distributed as dist
+        assert self._hi == 0, 'the backward did not report every region'
+        for work in self._pending:
+            work.wait()
+        self._pending = []
+        self.gstage.div_(dist.get_world_size())
+        self.reduced = True
 
     def owns(self, params):
         """the given parameters are exactly this optimizer's, still living in its flat buffer"""
@@ -599,6 +660,7 @@ class FlatAdam:
 
     def zero_grad(self):
         self.grad.zero_()
+        self.reduced = False
         off = 0
         for p in self.params:       # re-attach views in case something set .grad to None
             if p.grad is None:
@@ -642,6 +704,8 @@ def allreduce_gradients(flat_grad, force=False):
     what is reduced is what the step will use).  force=True runs the collective in a 1-rank group too (RCCL smoke test)."""
     import torch.distributed as dist
     if isinstance(flat_grad, FlatAdam):
+        if flat_grad.reduced and not force:       # the backward launched its own bucketed all-reduce (FlatAdam.overlap_allreduce): already averaged
+            return flat_grad.grad
         flat_grad._collect_stray_gradients()
         flat_grad = flat_grad.grad
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):

@@ -68,6 +68,23 @@ def main(rank, world, port, q):
                 report['__refused__'] = (0.0, 0.0)
             except ValueError:
                 report['__refused__'] = (1.0, 1.0)
+            # bucketed all-reduce launched from inside the backward (FlatAdam.overlap_allreduce) == one all-reduce behind it, bit for bit at 2 ranks
+            flat = []
+            for overlap in (False, True):
+                m2 = create_model_refiner(cfg, R(), mesh_db)
+                m2.load_state_dict({k: torch.as_tensor(v) for k, v in syn.golden_state_dict(0).items()}, strict=True)
+                m2 = m2.cuda().train()
+                m2.drop_connect_rate = 0.0
+                o2 = train_engine.FlatAdam(m2, overlap_allreduce=overlap, bucket_bytes=4 << 20)
+                o2.zero_grad()
+                np.random.seed(7)
+                l2 = pfl.h_pose(model=m2, mesh_db=mesh_db, data=data, meters=defaultdict(M), cfg=cfg, n_iterations=1, input_generator='fixed')
+                l2.backward()
+                assert o2.reduced == overlap
+                train_engine.allreduce_gradients(o2)          # the plain path reduces here; the overlapped one has nothing left to do
+                torch.cuda.synchronize()
+                flat.append(o2.grad.clone())
+            report['__overlap_equal__'] = (1.0 if torch.equal(flat[0], flat[1]) else 0.0, float(flat[1].abs().sum()))
             torch.cuda.synchronize()
             w = torch.cat([p_.detach().reshape(-1) for p_ in model.parameters()]).double()
             report['__weights__'] = (float(w.sum()), float(w.abs().sum()))

@@ -1641,6 +1641,9 @@ def test_ddp_two_ranks_on_one_gpu():
     # different batches both ranks hold the same weights (sum and abs-sum of all 12 M parameters agree exactly: same averaged gradients, same kernels)
     w0, w1 = g0.pop('__weights__'), g1.pop('__weights__')
     assert g0.pop('__refused__') == (1.0, 1.0) and g1.pop('__refused__') == (1.0, 1.0)
+    # the gradient all-reduce launched bucket by bucket from inside the backward gives the flat gradient of one all-reduce behind it, bit for bit
+    ov0, ov1 = g0.pop('__overlap_equal__'), g1.pop('__overlap_equal__')
+    assert ov0[0] == 1.0 and ov1[0] == 1.0 and ov0[1] > 0 and ov0 == ov1, (ov0, ov1)
     assert g0.pop('__loss__')[0] != g1.pop('__loss__')[0]
     assert w0 == w1, (w0, w1)
     assert pair[0][1] != pair[1][1]                                       # different batches -> different losses
