@@ -252,7 +252,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
                 b.n_tiles = std::max(b.n_tiles, stem_front_tiles(n->H));
             }
             if (b.wave) {
-                std::vector<float> wp(wave_params_floats(b.cmid, b.d.k), 0.f);
+                std::vector<float> wp(wave_params_floats(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W), 0.f);
                 if (fill) wave_pack_params(exp_sc.data(), exp_bi.data(), w.data(), sc.data(), bi.data(), b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W, wp.data());
                 b.wave_params = up_f32(wp);
             }
@@ -728,7 +728,7 @@ int cosy_effnet_b3_block_info(const cosy_net_t* n, int i, int* dims) {
     // where the project GEMM applies the squeeze-excite gate: to the weight fragments (maps of a multiple of 64 pixels: a wave's 64
     // rows belong to one sample) or to the activation rows
     const int gate_w = (b.Ho * b.Wo) % 64 == 0;
-    const int v[11] = {b.H, b.W, b.Ho, b.Wo, b.d.cin, b.cmid, b.d.cout, i == 0 && n->stem_fused ? 4 : b.wave ? 1 : b.small ? 2 : b.tiled ? 3 : 0, b.d.k, b.d.s, gate_w};
+    const int v[11] = {b.H, b.W, b.Ho, b.Wo, b.d.cin, b.cmid, b.d.cout, i == 0 && n->stem_fused ? 4 : b.wave ? (wave_taps_on_mfma(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W) ? 5 : 1) : b.small ? 2 : b.tiled ? 3 : 0, b.d.k, b.d.s, gate_w};
     for (int q = 0; q < 11; ++q) dims[q] = v[q];
     return COSY_OK;
 }

@@ -85,7 +85,8 @@ bool small_writes_chunked(int Cin, int Cmid, int H, int W, int Ho, int Wo, int k
 // PwCfg{1,1} (16-channel tiles, natural row order); partial has ONE tile per sample
 bool wave_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W);
 bool wave_walks_columns(int Cin, int Cmid, int k, int s, int dtype, int H, int W);   // the job's rows are the map's columns (transposed walk)
-size_t wave_params_floats(int Cmid, int k);
+size_t wave_params_floats(int Cin, int Cmid, int k, int s, int dtype, int H, int W);
+bool wave_taps_on_mfma(int Cin, int Cmid, int k, int s, int dtype, int H, int W);     // the wave kernel applies this block's depthwise taps with small MFMAs (E and the taps in the storage type)
 void wave_pack_params(const float* s0, const float* b0, const float* dww, const float* s1, const float* b1, int Cin, int Cmid, int k, int s,
                       int dtype, int H, int W, float* dst);
 void wave_kernel_name(int Cin, int Cmid, int k, int s, int dtype, int H, int W, char* buf, size_t n);

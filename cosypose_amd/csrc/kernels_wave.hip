@@ -100,6 +100,29 @@ template <int TOP, int I> __device__ __forceinline__ f32x4 xfrag_read() {
                  : "n"(TOP - 4 * (I + 1)), "n"(TOP - 4 * (I + 1) + 1), "n"(TOP - 4 * (I + 1) + 2), "n"(TOP - 4 * (I + 1) + 3));
     return f32x4{x0, x1, x2, x3};
 }
+// 16-bit types: the expansion's MFMAs read the fragments WHERE THEY LANDED -- inline-asm v_mfma with the reserved quad as one operand -- so no copy
+// (4 v_mov_b32 and 4 registers per fragment and row) is made at all.  XA: the fragment is the A operand (pixels as the MFMA's rows: the form with
+// the taps on the matrix pipe), else the B operand.  FIRST: SrcC = 0.  hipcc does not look inside the asm: a chain of these is issued back to back
+// (dependent MFMAs on one accumulator need no wait states) and closed by xfrag_mma_done(), the wait states a VALU read of the last result needs
+// (hipcc's own code puts s_nop 7 there; two more for margin).  fp32 (parity mode) keeps the copies: its 16x16x4 MFMAs take single registers.
+#ifndef COSY_WAVE_XASM
+#define COSY_WAVE_XASM 1
+#endif
+template <typename T, int TOP, int I, bool FIRST, bool XA, typename W> __device__ __forceinline__ void xfrag_mma(f32x4& m, const W& w) {
+    constexpr int lo = TOP - 4 * (I + 1), hi = TOP - 4 * I - 1;
+    if constexpr (__is_same(T, f16_t)) {
+        if constexpr (FIRST && XA) asm volatile("s_nop 1\n v_mfma_f32_16x16x32_f16 %0, v[%2:%3], %1, 0 ; XMMA" : "=&v"(m) : "v"(w), "n"(lo), "n"(hi));
+        else if constexpr (FIRST) asm volatile("s_nop 1\n v_mfma_f32_16x16x32_f16 %0, %1, v[%2:%3], 0 ; XMMA" : "=&v"(m) : "v"(w), "n"(lo), "n"(hi));
+        else if constexpr (XA) asm volatile("v_mfma_f32_16x16x32_f16 %0, v[%2:%3], %1, %0 ; XMMA" : "+v"(m) : "v"(w), "n"(lo), "n"(hi));
+        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, v[%2:%3], %0 ; XMMA" : "+v"(m) : "v"(w), "n"(lo), "n"(hi));
+    } else {
+        if constexpr (FIRST && XA) asm volatile("s_nop 1\n v_mfma_f32_16x16x32_bf16 %0, v[%2:%3], %1, 0 ; XMMA" : "=&v"(m) : "v"(w), "n"(lo), "n"(hi));
+        else if constexpr (FIRST) asm volatile("s_nop 1\n v_mfma_f32_16x16x32_bf16 %0, %1, v[%2:%3], 0 ; XMMA" : "=&v"(m) : "v"(w), "n"(lo), "n"(hi));
+        else if constexpr (XA) asm volatile("v_mfma_f32_16x16x32_bf16 %0, v[%2:%3], %1, %0 ; XMMA" : "+v"(m) : "v"(w), "n"(lo), "n"(hi));
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, v[%2:%3], %0 ; XMMA" : "+v"(m) : "v"(w), "n"(lo), "n"(hi));
+    }
+}
+__device__ __forceinline__ void xfrag_mma_done(f32x4& m) { asm volatile("s_nop 7\n s_nop 1 ; XMMA" : "+v"(m)); }
 // Fence: an empty asm that CLOBBERS the reserved fragment registers.  No value that is live across it can be allocated there, so
 // placing one at every point of the row loop where fragments are (or are about to be) in flight -- after the loads are issued,
 // in front of the wait -- keeps every long-lived value of the kernel out of the range by construction; what is left to luck
@@ -110,8 +133,43 @@ template <int TOP, int NFRAG> __device__ __forceinline__ void xfrag_fence() {
 template <int MINW> __device__ __forceinline__ void xfrag_reserve() {
     if constexpr (MINW == 2) asm volatile("; XRESERVE" ::: "v255");
     else if constexpr (MINW == 3) asm volatile("; XRESERVE" ::: "v167");
+    else if constexpr (MINW == 5) asm volatile("; XRESERVE" ::: "v95");
     else asm volatile("; XRESERVE" ::: "v127");
 }
+
+// ---- depthwise taps on the matrix pipe (16-bit types, stride 1, 16-pixel rows: blocks 9-17 at 256x256 crops).
+// v_mfma_f32_4x4x4_16B computes 16 independent 4x4x4 products, D_b[i][j] = sum_k A_b[i][k] * B_b[k][j], block b in lanes 4b .. 4b+3 (lane 4b+i holds
+// row i of A, lane 4b+j holds column j of B and of D; checked on the device by profiles/exp/mfma_depthwise.hip).  With block = channel, j = a quad of
+// 4 neighbouring pixels of the row, A = the Toeplitz matrix of one tap row (A[i][k] = w[ky][x_k - x_i + LO]) and B = the expanded values of the
+// quad (W1) or of the two pixels either side of it (W2), one instruction applies a tap row to 16 pixels x 16 channels: 2 KS instructions per input row
+// instead of KS * KS * 4 fp32 FMAs + 4 (KS - 1) DPP moves + KS * KS LDS reads (micro-benchmark of the tap phase alone, same file: 1.5x with its
+// operands staged through LDS).  What it takes:
+//   * the expansion runs with its operands SWAPPED (pixels as the MFMA's rows), so a lane leaves it with 4 neighbouring pixels of ONE channel
+//     (lane = channel + 16 * quad) -- the operand format of the small MFMA up to a lane permutation (lane -> 4 * channel + quad: one ds_bpermute per
+//     packed register); BatchNorm parameters are one scalar per lane;
+//   * the expanded values and the taps are rounded to the storage type (what the unfused kernels store for E; the oracle's emulation follows:
+//     block_info kind 5), products are exact in fp32 and accumulate in fp32;
+//   * the halo operand W2 = (upper half of the previous quad, lower half of the next one): two quad_perm DPP moves, zeroed at the row ends;
+//   * a finished output row (lane = (channel, quad): 4 pixels) goes through BatchNorm + SiLU + the squeeze sums where it is, is rounded, permuted
+//     back and TRANSPOSED by one v_mfma_f32_16x16x16 against the identity (A lane (row r, 4 k) -> C lane (column k, 4 rows): exact), which leaves
+//     lane = (pixel, 4 channels): the 8-byte D store of the other form.
+// The chunk's parameters arrive as [s0][b0][s1][b1] (16 floats each) + 2 KS ready-made A fragments (wave_pack_params); no LDS parameter block.
+#ifndef COSY_WAVE_MX
+#define COSY_WAVE_MX 1
+#endif
+constexpr bool wave_mx(int esz, int ks, int s, int ppl, bool fullw) { return COSY_WAVE_MX && esz == 2 && s == 1 && ppl == 1 && fullw && (ks == 3 || ks == 5); }
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 mma4(f16x4 a, f16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x4f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mma4(bf16x4 a, bf16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma16(f16x4 a, f16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mma16(bf16x4 a, bf16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma4(f32x4, f32x4, f32x4 c) { return c; }      // never instantiated for fp32 (wave_mx), only parsed
+__device__ __forceinline__ f32x4 mma16(f32x4, f32x4, f32x4 c) { return c; }
 
 template <typename F, int... Us>
 __device__ __forceinline__ void unroll_seq(F&& f, std::integer_sequence<int, Us...>) { (f(std::integral_constant<int, Us>{}), ...); }
@@ -120,7 +178,10 @@ constexpr int wave_lcm(int a, int b) { int x = a; while (x % b) x += a; return x
 // shapes whose straight-line interior row does not fit the register budget (the scheduler hoists every tap read: spills, and
 // temporaries in the reserved fragment range -- profiles/check_wave_isa.py) keep the branchy boundary form for every row
 constexpr bool wave_interior_form(int ks, int s, int kbn, int ppl, int minw) { return !(ks == 3 && s == 1 && kbn == 1 && ppl == 4 && minw == 3); }
-constexpr bool wave_wlds(int kbn, int minw) { return (kbn >= 5 && minw >= 4) || kbn >= 9; }
+#ifndef COSY_WAVE_WLDS
+#define COSY_WAVE_WLDS 1
+#endif
+constexpr bool wave_wlds(int kbn, int minw) { return (COSY_WAVE_WLDS && kbn >= 5 && minw >= 4) || kbn >= 9; }
 
 template <typename T, int KS, int S, int KBN, int PPL, int NI, bool FULLW, int MINW>
 __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
@@ -135,7 +196,9 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     constexpr int U = S * NOPEN;                              // input rows per unrolled super-iteration
     constexpr int PF = (4 + KS * KS) * 16 * NI;               // floats of the parameter block
     constexpr bool WLDS = wave_wlds(KBN, MINW);               // expand-weight fragments parked in LDS instead of registers
-    constexpr int PFW = PF + (WLDS ? NI * KBN * 256 : 0);
+    constexpr bool MX = wave_mx(sizeof(T), KS, S, PPL, FULLW);  // depthwise taps on the matrix pipe
+    constexpr int PFX = 64 + 2 * KS * 128;                    // floats of the parameter block of that form
+    constexpr int PFW = (MX ? 0 : PF) + (WLDS ? NI * KBN * 256 : 0);
     static_assert(PPL % S == 0, "a lane's pixel run must hold whole output pixels");
     typedef T out_t __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float smem_w[];
@@ -152,7 +215,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     const int c0 = ch * 16 * NI;
 
     float* P = smem_w + wave * PFW;
-    char* Wl = (char*)(P + PF);
+    char* Wl = (char*)(P + (MX ? 0 : PF));
 #ifdef COSY_WAVE_STAMPS
     // timeline build (python -m cosypose_amd.build --tune with COSY_WAVE_STAMPS=1 in the environment): scalar-only bookkeeping, no LDS, no VGPRs
     const bool stamping = a.stamps != nullptr && wave == 0 && blockIdx.x % a.stamp_stride == 0 && (int)(blockIdx.x / a.stamp_stride) < a.stamp_slots;
@@ -193,10 +256,12 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     // acknowledgement of the output row stored a moment ago as well (knock-out timing: 30 % of block 3's time).  Here the
     // next row's loads are issued FIRST and the previous output row's stores behind them, so vmcnt(#stores) in front of
     // the next row's MFMAs covers the loads and leaves the stores in flight.
-    constexpr int XTOP = MINW == 2 ? 256 : MINW == 3 ? 168 : 128;
-    static_assert(MINW >= 2 && MINW <= 4);
+    constexpr int XTOP = MINW == 2 ? 256 : MINW == 3 ? 168 : MINW == 4 ? 128 : 96;
+    static_assert(MINW >= 2 && MINW <= 5);
     xfrag_reserve<MINW>();
-    f32x4 xc[PPL][KBN];
+    constexpr bool XASM = COSY_WAVE_XASM && sizeof(T) == 2;   // the MFMAs read the fragments in place (xfrag_mma)
+    raw_t wf[NI][KBN];                       // the chunk's expand-weight fragments (WLDS: parked in LDS instead)
+    f32x4 xc[XASM ? 1 : PPL][XASM ? 1 : KBN];
     int st_in_flight = 0;                    // stores issued behind the newest loads (wave-uniform)
     auto load_row = [&](int iy) {            // B fragments of input row iy: fragment q holds the lanes' pixels p*PPL + q
         const char* rowp = (const char*)X + (size_t)min(iy, a.H - 1) * xrow_bytes;    // rows below the map are never used
@@ -207,16 +272,28 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
         xfrag_fence<XTOP, PPL * KBN>();
         st_in_flight = 0;
     };
-    auto wait_row = [&]() {
+    // XASM: the expansion's MFMA chains are issued HERE, in the basic block of the wait (rows below the map expand a valid row for nothing: load_row
+    // clamps) -- one chain per pixel fragment into mq[], all chains first (asm blocks keep their order), then one set of wait states
+    auto wait_row = [&](f32x4* mq) {
         constexpr int NST = (PPL / S) * NI;
         xfrag_fence<XTOP, PPL * KBN>();
         if (st_in_flight) asm volatile("s_waitcnt vmcnt(%0) ; XWAIT" :: "n"(NST) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) ; XWAIT" ::: "memory");
-        unroll_seq([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            xc[i / KBN][i % KBN] = xfrag_read<XTOP, i>();
-        }, std::make_integer_sequence<int, PPL * KBN>{});
-        asm volatile("s_nop 1");             // VALU write -> MFMA read
+        if constexpr (XASM) {
+            unroll_seq([&](auto ic) {
+                constexpr int i = decltype(ic)::value, q = i / KBN, kb = i % KBN;
+                if constexpr (WLDS) xfrag_mma<T, XTOP, i, kb == 0, MX>(mq[q], *(const raw_t*)(Wl + kb * 1024 + lane * 16));
+                else xfrag_mma<T, XTOP, i, kb == 0, MX>(mq[q], wf[0][kb]);
+            }, std::make_integer_sequence<int, PPL * KBN>{});
+            xfrag_mma_done(mq[PPL - 1]);
+        }
+        if constexpr (!XASM) {
+            unroll_seq([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                xc[i / KBN][i % KBN] = xfrag_read<XTOP, i>();
+            }, std::make_integer_sequence<int, PPL * KBN>{});
+            asm volatile("s_nop 1");             // VALU write -> MFMA read
+        }
     };
     // this job's output rows [oy_a, oy_b) and the input rows they need (rows above a band are recomputed, KS-S of them)
     const int oy_a = band * a.rows_per, oy_b = min(a.Ho, oy_a + a.rows_per);
@@ -225,19 +302,28 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     // ---- everything a job needs from memory before its first row, issued back to back under ONE latency: the first input
     // row (asm loads, oldest), the chunk's expand-weight fragments, the parameter block (staged to LDS: its wait is a vmcnt(0)
     // that covers all three).  Issued one after the other they cost three memory latencies per job -- 15 % of a 16-row job.
-    raw_t wf[NI][KBN];
     // The chunk's parameters arrive PACKED (host: wave_pack_params): one contiguous block [s0*log2e][b0*log2e][s1][b1][taps*ln2 in
     // walked order] of PF floats per chunk, so a lane fetches its one or two 16-byte pieces without address arithmetic.  (The
     // expansion's SiLU runs on t = log2(e) * v: t / (1 + 2^-t) = log2(e) * silu(v) -- one multiply fewer per expanded element,
     // v_exp_f32 takes the negation as a source modifier; the inverse factor rides in the taps, the only consumers of the
     // expanded values.)  Round 3: these loads used to be issued BEHIND the wait for the weight fragments, one pass of a rolled
     // loop at a time -- three serial memory latencies per job where the comment above promised one.
-    constexpr int NPL = (PF / 4 + 63) / 64;
+    constexpr int NPL = MX ? 1 : (PF / 4 + 63) / 64;
     f32x4 pv[NPL];
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    t4 Af[MX ? KS : 1][2];                   // MX: Toeplitz fragments of the tap rows, [ky][quad | halo operand]
+    float mxp[4] = {0.f, 0.f, 0.f, 0.f};     // MX: s0, b0 of this lane's expansion channel (lane & 15), s1, b1 of its depthwise channel (lane >> 2)
     if (active) {
-        const f32x4* PP = (const f32x4*)(a.wparams + (size_t)ch * PF);
+        if constexpr (MX) {
+            const float* PP = a.wparams + (size_t)ch * PFX;
+            mxp[0] = PP[lane & 15]; mxp[1] = PP[16 + (lane & 15)]; mxp[2] = PP[32 + (lane >> 2)]; mxp[3] = PP[48 + (lane >> 2)];
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) pv[j] = PP[min(lane + 64 * j, PF / 4 - 1)];
+            for (int f = 0; f < 2 * KS; ++f) Af[f >> 1][f & 1] = *(const t4*)(PP + 64 + (f * 64 + lane) * 2);
+        } else {
+            const f32x4* PP = (const f32x4*)(a.wparams + (size_t)ch * PF);
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) pv[j] = PP[min(lane + 64 * j, PF / 4 - 1)];
+        }
         load_row(iy_first);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
@@ -246,9 +332,11 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
                 wf[ni][kb] = *(const raw_t*)((const T*)a.Wp + ((size_t)(ch * NI + ni) * a.nkb_total + kb) * 64 * EPL + lane * EPL);
         // -> the wave-private LDS block (no workgroup barrier: a wave reads only what it wrote itself, and LDS operations of one
         // wave execute in order)
+        if constexpr (!MX) {
 #pragma unroll
-        for (int j = 0; j < NPL; ++j)
-            if (lane + 64 * j < PF / 4) *(f32x4*)(P + (lane + 64 * j) * 4) = pv[j];
+            for (int j = 0; j < NPL; ++j)
+                if (lane + 64 * j < PF / 4) *(f32x4*)(P + (lane + 64 * j) * 4) = pv[j];
+        }
         if constexpr (WLDS) {
             // 4 * KBN registers that a 4-waves-per-SIMD budget does not have: parked in the wave's LDS block and re-read in front
             // of every row's MFMAs (one conflict-free ds_read_b128 per fragment and row)
@@ -273,6 +361,19 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     float sum[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) sum[c] = 0.f;
+    // MX: the accumulators are the small MFMA's C operands (lane = (channel lane >> 2, quad lane & 3): 4 pixels); lane permutations to and from
+    // the expansion's layout (lane = channel + 16 * quad); the identity fragment of the transposing MFMA
+    f32x4 accx[NOPEN];
+#pragma unroll
+    for (int s = 0; s < NOPEN; ++s) accx[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int bp_in = ((lane >> 2) + 16 * (lane & 3)) * 4, bp_out = (4 * (lane & 15) + (lane >> 4)) * 4;
+    const int jq = lane & 3;
+    t4 ident;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ident[e] = (T)(4 * kg + e == p ? 1.f : 0.f);
+    auto cvt = [](float v) -> T {           // fp16 saturates (as to_f16_sat; one v_med3_f32)
+        if constexpr (__is_same(T, f16_t)) return (T)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); else return (T)v;
+    };
     out_t yv[TO][NI];                        // finished output row waiting for its store (issued one row later)
     int oy_pending = -1;
     // D is written in the CHUNKED layout [sample][Cmid/16][Ho*Wo][16]: this wave's output row is one contiguous run of
@@ -311,7 +412,36 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
             // ---- A. expanded row iy (transient registers); its global loads were issued one row ago
             float Er[RP][NCH];
             WAVE_STAMP_ROW();
-            wait_row();
+            f32x4 mq[XASM ? PPL : 1];
+            wait_row(mq);
+            t4 W1, W2;                       // MX: the row's operands of the tap MFMAs
+            if constexpr (MX) {
+                if (IN || iy < a.H) {
+                    f32x4 m = f32x4{0.f, 0.f, 0.f, 0.f};
+                    // operands swapped: rows = pixels -> lane (channel lane & 15, quad lane >> 4) holds 4 pixels
+                    if constexpr (XASM) m = mq[0];
+                    else {
+#pragma unroll
+                        for (int kb = 0; kb < KBN; ++kb) {
+                            raw_t xv = __builtin_bit_cast(raw_t, xc[0][kb]);
+                            if constexpr (WLDS) mma(m, xv, *(const raw_t*)(Wl + kb * 1024 + lane * 16));
+                            else mma(m, xv, wf[0][kb]);
+                        }
+                    }
+                    float y4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y4[e] = m[e] * mxp[0] + mxp[1];
+                    if (!COSY_DBG(a.dbg & 512)) silu4<false>(y4);      // dbg 512: no SiLU (timing)
+                    const t4 hv = t4{cvt(y4[0]), cvt(y4[1]), cvt(y4[2]), cvt(y4[3])};      // E in the storage type, as the unfused kernels store it
+                    const i32x2 hh = __builtin_bit_cast(i32x2, hv);
+                    int lo = hh[0], hi = hh[1];
+                    if (!COSY_DBG(a.dbg & 128)) { lo = __builtin_amdgcn_ds_bpermute(bp_in, hh[0]); hi = __builtin_amdgcn_ds_bpermute(bp_in, hh[1]); }   // dbg 128: no lane permutation (timing)
+                    int hp = __builtin_amdgcn_update_dpp(0, hi, 0x90, 0xf, 0xf, false);     // quad_perm [0,0,1,2]: the previous quad's pixels 2, 3
+                    int ln = __builtin_amdgcn_update_dpp(0, lo, 0xF9, 0xf, 0xf, false);     // quad_perm [1,2,3,3]: the next quad's pixels 0, 1
+                    hp = jq == 0 ? 0 : hp; ln = jq == 3 ? 0 : ln;                           // zero padding at the row ends
+                    W1 = __builtin_bit_cast(t4, i32x2{lo, hi}); W2 = __builtin_bit_cast(t4, i32x2{hp, ln});
+                }
+            } else
             if (IN || iy < a.H) {
                 float sc0[NCH], bi0[NCH];
 #pragma unroll
@@ -321,11 +451,14 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
                         f32x4 m = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if constexpr (XASM) m = mq[q];
+                        else {
 #pragma unroll
-                        for (int kb = 0; kb < KBN; ++kb) {
-                            raw_t xv = __builtin_bit_cast(raw_t, xc[q][kb]);
-                            if constexpr (WLDS) mma(m, *(const raw_t*)(Wl + (ni * KBN + kb) * 1024 + lane * 16), xv);
-                            else mma(m, wf[ni][kb], xv);
+                            for (int kb = 0; kb < KBN; ++kb) {
+                                raw_t xv = __builtin_bit_cast(raw_t, xc[q][kb]);
+                                if constexpr (WLDS) mma(m, *(const raw_t*)(Wl + (ni * KBN + kb) * 1024 + lane * 16), xv);
+                                else mma(m, wf[ni][kb], xv);
+                            }
                         }
                         float y4[4];
 #pragma unroll
@@ -377,6 +510,12 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
                 const int os = (((num - (((num % S) + S) % S)) / S) % NOPEN + NOPEN) % NOPEN;   // accumulator slot of that output row
                 const int oy = (iy + LO - ky) / S;
                 if constexpr (!IN) { if (iy + LO - ky < 0 || oy < oy_a || oy >= oy_b) continue; }   // wave-uniform
+                if constexpr (MX) {
+                    if ((IN || iy < a.H) && !COSY_DBG(a.dbg & 64)) {       // dbg 64: no tap MFMAs (timing)
+                        accx[os] = mma4(Af[ky][0], W1, accx[os]);
+                        accx[os] = mma4(Af[ky][1], W2, accx[os]);
+                    }
+                } else
                 if (IN || iy < a.H) {
 #pragma unroll
                     for (int kx = 0; kx < KS; ++kx) {
@@ -389,6 +528,28 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
                             for (int c = 0; c < NCH; ++c) acc[os][t][c] += w[c] * Er[t * S + kx][c];
                     }
                 }
+                if constexpr (MX) {
+                    if (ky == KS - 1) {
+                        float y4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y4[e] = accx[os][e] * mxp[2] + mxp[3];
+                        if (!COSY_DBG(a.dbg & 512)) silu4<false>(y4);      // dbg 512: no SiLU (timing)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sum[0] += y4[e];
+                        const t4 hv = t4{cvt(y4[0]), cvt(y4[1]), cvt(y4[2]), cvt(y4[3])};
+                        const i32x2 hh = __builtin_bit_cast(i32x2, hv);
+                        if (COSY_DBG(a.dbg & 256)) {                      // dbg 256: no permutation / transposition of the output row (timing)
+                            ynew[0][0] = hv;
+                        } else {
+                        const int lo = __builtin_amdgcn_ds_bpermute(bp_out, hh[0]), hi = __builtin_amdgcn_ds_bpermute(bp_out, hh[1]);
+                        const f32x4 tr = mma16(__builtin_bit_cast(t4, i32x2{lo, hi}), ident, f32x4{0.f, 0.f, 0.f, 0.f});   // -> lane (pixel, 4 channels), exact
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ynew[0][0][e] = (T)tr[e];
+                        }
+                        accx[os] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        done = true; oy_done = oy;
+                    }
+                } else
                 if (ky == KS - 1) {                                   // last tap row: the output row is complete
                     float sc1[NCH], bi1[NCH];
 #pragma unroll
@@ -437,6 +598,12 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     }
     flush();
     // ---- squeeze sums: fixed-order tree over the 16 lanes of a row (one channel quad per row), lane 15 writes
+    if constexpr (MX) {      // a lane summed the 4 pixels of its quad per row: the channel's total = the 4 lanes of its MFMA block (fixed order)
+        float v = sum[0];
+        v += dpp_mov0<0xB1>(v);      // quad_perm [1,0,3,2]
+        v += dpp_mov0<0x4E>(v);      // quad_perm [2,3,0,1]
+        if (jq == 0) a.partial[((size_t)b * a.rsplit + band) * a.Cmid + c0 + (lane >> 2)] = v;
+    } else {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         float v = sum[c];
@@ -447,6 +614,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
             *(f32x4*)(a.partial + ((size_t)b * a.rsplit + band) * a.Cmid + c0 + ni * 16 + kg * 4) = f32x4{sum[ni * 4], sum[ni * 4 + 1], sum[ni * 4 + 2], sum[ni * 4 + 3]};
+    }
     }
 #ifdef COSY_WAVE_STAMPS
     if (stamping && lane == 0) {
@@ -469,7 +637,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
 // across batch sizes.
 #define COSY_WAVE_VARIANTS(X)                                                                                      \
     X(3, 2, 1, 8, 1, true, 2, 4) X(3, 1, 1, 4, 1, true, 3, 2) X(5, 2, 1, 4, 1, true, 3, 1) X(5, 1, 2, 2, 1, true, 3, 2)      \
-    X(3, 2, 2, 2, 1, true, 4, 2) X(3, 1, 3, 1, 1, true, 4, 1) X(5, 1, 3, 1, 1, true, 4, 1) X(5, 1, 5, 1, 1, true, 4, 1)      \
+    X(3, 2, 2, 2, 1, true, 4, 2) X(3, 1, 3, 1, 1, true, 5, 1) X(5, 1, 3, 1, 1, true, 4, 1) X(5, 1, 5, 1, 1, true, 4, 1)      \
     X(3, 1, 1, 5, 1, true, 2, 2) X(5, 2, 1, 6, 1, false, 2, 1) X(5, 1, 2, 3, 1, false, 2, 2) X(3, 2, 2, 4, 1, false, 3, 1)   \
     X(3, 1, 3, 2, 1, false, 3, 1) X(5, 1, 3, 2, 1, false, 2, 1) X(5, 1, 5, 2, 1, false, 2, 1)                                \
     /* rows that do not fill their 16 * PPL lanes, reached by walking the map's COLUMNS (wave_plan: transposed): 240x320 crops */ \
@@ -488,7 +656,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     X(5, 2, 2, 6, 1, false, 2, 1) X(3, 2, 3, 4, 1, false, 2, 1) X(3, 1, 6, 2, 1, false, 2, 1) X(5, 1, 6, 2, 1, false, 2, 1)
 enum { WAVE_MAX_RSPLIT = 4 };
 
-struct WavePlan { int kbn, ppl, ni; bool fullw, ok, transposed; };
+struct WavePlan { int kbn, ppl, ni; bool fullw, ok, transposed, mx; };
 // one orientation: rows of `W` pixels (the lane axis), `H` of them
 static WavePlan wave_plan_1(int Cin, int Cmid, int H, int W, int k, int s, int dtype) {
     WavePlan p{};
@@ -505,6 +673,7 @@ static WavePlan wave_plan_1(int Cin, int Cmid, int H, int W, int k, int s, int d
 #define X(KS, S, KBN, PPL, NI, FW, MW, RSP) if (k == KS && s == S && p.kbn == KBN && p.ppl == PPL && p.ni == NI && p.fullw == FW) p.ok = true;
     if (dtype == COSY_F32) { COSY_WAVE_VARIANTS_F32(X) } else { COSY_WAVE_VARIANTS(X) }
 #undef X
+    p.mx = p.ok && wave_mx(dtype == COSY_F32 ? 4 : 2, k, s, p.ppl, p.fullw);
     return p;
 }
 // The wave walks the map row by row with 16 * PPL lanes-pixels per row; a row that does not fill them wastes lanes (240x320 crops:
@@ -526,12 +695,43 @@ static WavePlan wave_plan(int Cin, int Cmid, int H, int W, int k, int s, int dty
 // Per-chunk parameter blocks of the wave kernel: [chunk][4 + k*k][16] fp32 = s0 * log2(e), b0 * log2(e), s1, b1, then the taps
 // * ln 2 in the order the job walks them (w[kx][ky] for a transposed job).  The products are single-precision, exactly what the
 // kernel used to compute per job.
-size_t wave_params_floats(int Cmid, int k) { return (size_t)(Cmid / 16) * (4 + k * k) * 16; }
+// Taps on the matrix pipe (WavePlan::mx): [chunk][s0 16][b0 16][s1 16][b1 16] fp32 (no log2 e: the expanded values are rounded to the storage
+// type as they are), then 2 k fragments [ky][operand 0 | 1][lane 64][4] of the storage type: the Toeplitz rows of tap row ky for the lane's
+// output pixel i = lane & 3 and channel lane >> 2 -- operand 0 against the pixels 4j .. 4j+3 of the lane quad, operand 1 against 4j-2, 4j-1, 4j+4, 4j+5.
+static inline uint16_t wave_f16_bits(float f) { _Float16 h = (_Float16)(f > 65504.f ? 65504.f : (f < -65504.f ? -65504.f : f)); return __builtin_bit_cast(uint16_t, h); }
+static inline uint16_t wave_bf16_bits(float f) {       // round to nearest even (finite weights)
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static size_t wave_chunk_floats(const WavePlan& p, int k) { return p.mx ? (size_t)64 + 2 * k * 128 : (size_t)(4 + k * k) * 16; }
+size_t wave_params_floats(int Cin, int Cmid, int k, int s, int dtype, int H, int W) {
+    return (size_t)(Cmid / 16) * wave_chunk_floats(wave_plan(Cin, Cmid, H, W, k, s, dtype), k);
+}
 void wave_pack_params(const float* s0, const float* b0, const float* dww, const float* s1, const float* b1, int Cin, int Cmid, int k, int s,
                       int dtype, int H, int W, float* dst) {
     const WavePlan p = wave_plan(Cin, Cmid, H, W, k, s, dtype);
     const float L2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-    const int pf = (4 + k * k) * 16;
+    const size_t pf = wave_chunk_floats(p, k);
+    if (p.mx) {
+        const int lo = (k - 1) / 2;
+        static const int off[2][4] = {{0, 1, 2, 3}, {-2, -1, 4, 5}};
+        for (int ch = 0; ch < Cmid / 16; ++ch) {
+            float* d = dst + (size_t)ch * pf;
+            for (int c = 0; c < 16; ++c) { const int cc = ch * 16 + c; d[c] = s0[cc]; d[16 + c] = b0[cc]; d[32 + c] = s1[cc]; d[48 + c] = b1[cc]; }
+            uint16_t* a = (uint16_t*)(d + 64);
+            for (int ky = 0; ky < k; ++ky)
+                for (int m = 0; m < 2; ++m)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int q = 0; q < 4; ++q) {
+                            const int i = lane & 3, cc = ch * 16 + (lane >> 2), kx = off[m][q] - i + lo;
+                            float w = 0.f;
+                            if (kx >= 0 && kx < k) w = dww[(size_t)(p.transposed ? kx * k + ky : ky * k + kx) * Cmid + cc];
+                            a[(((size_t)ky * 2 + m) * 64 + lane) * 4 + q] = dtype == COSY_BF16 ? wave_bf16_bits(w) : wave_f16_bits(w);
+                        }
+        }
+        return;
+    }
     for (int ch = 0; ch < Cmid / 16; ++ch)
         for (int c = 0; c < 16; ++c) {
             float* d = dst + (size_t)ch * pf + c;
@@ -542,6 +742,10 @@ void wave_pack_params(const float* s0, const float* b0, const float* dww, const 
                 d[(4 + t) * 16] = dww[(size_t)tsrc * Cmid + cc] * LN2;
             }
         }
+}
+bool wave_taps_on_mfma(int Cin, int Cmid, int k, int s, int dtype, int H, int W) {
+    if (H <= 0) return false;
+    return wave_plan(Cin, Cmid, H, W, k, s, dtype).mx;
 }
 bool wave_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W) {
     if (H <= 0) return false;
@@ -565,7 +769,7 @@ void wave_kernel_name(int Cin, int Cmid, int k, int s, int dtype, int H, int W, 
 
 template <typename T, int KS, int S, int KBN, int PPL, int NI, bool FW, int MW, int RSP>
 static int launch_wave_k(WaveKArgs k, int* n_tiles_out, hipStream_t s) {
-    size_t lds = (size_t)4 * ((4 + KS * KS) * 16 * NI * sizeof(float) + (wave_wlds(KBN, MW) ? NI * KBN * 1024 : 0));
+    size_t lds = (size_t)4 * ((wave_mx(sizeof(T), KS, S, PPL, FW) ? 0 : (4 + KS * KS) * 16 * NI * sizeof(float)) + (wave_wlds(KBN, MW) ? NI * KBN * 1024 : 0));
     k.dbg = tune_int("COSY_WAVE_DBG", 0);
     k.stamps = nullptr; k.stamp_stride = 1; k.stamp_slots = 0;
 #ifdef COSY_TUNE

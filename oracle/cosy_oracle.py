@@ -448,7 +448,7 @@ class TorchRef:
     # The same network with every value rounded to the 16-bit storage type exactly where the HIP path stores one:
     # network input, stem output, block inputs / outputs, the depthwise output D, the expanded tensor E of the UNFUSED blocks
     # (the fused fronts keep E in fp32 registers / LDS; the small kernel also folds BN0's scale into its expand weights before
-    # rounding them),
+    # rounding them; front kind 5 rounds E and the depthwise taps: they are the 16-bit operands of its tap MFMAs),
     # the head activation; the 1x1-conv and stem weights; and the
     # squeeze-excite gate where the project GEMM applies it -- to the weight fragments (maps with Ho*Wo % 64 == 0:
     # bf16 round(w * g), fp16 w * half(g) in half arithmetic) or to the activation rows (other maps).  Accumulation, BatchNorm,
@@ -494,9 +494,12 @@ class TorchRef:
             x = sw(t * 0.6931471805599453)
         elif e != 1:
             x = sw(self._bn(self._conv(x, R(sd[p + '_expand_conv.weight']), 1, 1), p + '_bn0'))
-            if not fused:                                        # unfused blocks store the expanded tensor
-                x = R(x)
-        d32 = sw(self._bn(self._conv(x, sd[p + '_depthwise_conv.weight'], k, s, groups=x.shape[1]), p + '_bn1'))
+            if not fused or fused == 5:                          # unfused blocks store the expanded tensor; front kind 5 (wave kernel, taps on the
+                x = R(x)                                         # matrix pipe) rounds it to the storage type as the small MFMA's operand
+        dw_w = sd[p + '_depthwise_conv.weight']
+        if fused == 5:                                           # ... and the taps too (products exact, fp32 accumulation)
+            dw_w = R(dw_w)
+        d32 = sw(self._bn(self._conv(x, dw_w, k, s, groups=x.shape[1]), p + '_bn1'))
         q = d32.mean((2, 3), keepdim=True)
         q = self._conv(sw(self._conv(q, sd[p + '_se_reduce.weight'], 1, 1, bias=sd[p + '_se_reduce.bias'])),
                        sd[p + '_se_expand.weight'], 1, 1, bias=sd[p + '_se_expand.bias'])
@@ -530,7 +533,8 @@ class TorchRef:
 
     def extract_features_emulated(self, x, storage, fused, probes=None, gate_w=None):
         """x (B,6,H,W) fp32; storage 'bf16' | 'fp16'; fused[i] = front kernel of block i as cosy_effnet_b3_block_info reports it
-        (0 unfused: E is stored; 1 wave, 2 small: E never stored; 4: block 0 behind the fused stem, the stem tensor never stored).
+        (0 unfused: E is stored; 1 wave, 2 small: E never stored; 4: block 0 behind the fused stem, the stem tensor never stored; 5 wave with the
+        depthwise taps on the matrix pipe: E and the taps rounded to the storage type, never stored).
         probes: dict filled with {-1: stem, i: block output, 100+i: D of block i, 200+i: gate (B,Cmid), 26: head}.
         NOTE: two evaluations of a 26-block network that round at every layer decorrelate with depth (a value one ulp apart
         perturbs the next layer's roundings), so the END-TO-END distance between this and the device grows to the size of
