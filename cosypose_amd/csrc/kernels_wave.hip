@@ -90,8 +90,8 @@ template <bool SCALED> __device__ __forceinline__ void silu4(float* v) {
 // allocator filling from v0 upwards; profiles/check_wave_isa.py verifies on the built ISA that no compiler-generated
 // instruction touches the reserved range (tests/test_build_isa.py).  (AGPRs would be the natural home, but naming one in
 // inline asm makes hipcc split the budget 128 + 128 and spill through v_accvgpr_write.)
-template <int TOP, int I> __device__ __forceinline__ void xfrag_load(int voff, const char* sbase) {
-    asm volatile("global_load_dwordx4 v[%2:%3], %0, %1 ; XLOAD" :: "v"(voff), "s"(sbase), "n"(TOP - 4 * (I + 1)), "n"(TOP - 4 * I - 1) : "memory");
+template <int TOP, int I, int IMM = 0> __device__ __forceinline__ void xfrag_load(int voff, const char* sbase) {
+    asm volatile("global_load_dwordx4 v[%2:%3], %0, %1 offset:%4 ; XLOAD" :: "v"(voff), "s"(sbase), "n"(TOP - 4 * (I + 1)), "n"(TOP - 4 * I - 1), "n"(IMM) : "memory");
 }
 template <int TOP, int I> __device__ __forceinline__ f32x4 xfrag_read() {
     float x0, x1, x2, x3;
@@ -153,11 +153,14 @@ template <int MINW> __device__ __forceinline__ void xfrag_reserve() {
 //   * a finished output row (lane = (channel, quad): 4 pixels) goes through BatchNorm + SiLU + the squeeze sums where it is, is rounded, permuted
 //     back and TRANSPOSED by one v_mfma_f32_16x16x16 against the identity (A lane (row r, 4 k) -> C lane (column k, 4 rows): exact), which leaves
 //     lane = (pixel, 4 channels): the 8-byte D store of the other form.
+// Rows wider than 16 pixels (PPL > 1) are PPL SEGMENTS of 16 pixels: fragment q holds the pixels 16 q .. 16 q + 15 (the other form gives a lane PPL
+// neighbouring pixels instead), every segment goes through the steps above on its own, and the halo operand of a segment's first / last quad comes
+// from the neighbouring segment's last / first quad (one more quad_perm move and a select) instead of the zero padding.
 // The chunk's parameters arrive as [s0][b0][s1][b1] (16 floats each) + 2 KS ready-made A fragments (wave_pack_params); no LDS parameter block.
 #ifndef COSY_WAVE_MX
 #define COSY_WAVE_MX 1
 #endif
-constexpr bool wave_mx(int esz, int ks, int s, int ppl, bool fullw) { return COSY_WAVE_MX && esz == 2 && s == 1 && ppl == 1 && fullw && (ks == 3 || ks == 5); }
+constexpr bool wave_mx(int esz, int ks, int s, int ppl, bool fullw) { return COSY_WAVE_MX && esz == 2 && s == 1 && ppl >= 1 && fullw && (ks == 3 || ks == 5); }
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 mma4(f16x4 a, f16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x4f16(a, b, c, 0, 0, 0); }
@@ -244,12 +247,23 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     // end are forced to zero after the expansion anyway, and the channel tail of the last k-block meets the zero padding of the
     // packed weights (finite * 0).
     const size_t xrow_bytes = (size_t)a.xs_row;
-    int xoff[PPL][KBN];
+    // Full rows (FULLW: no pixel is clamped): fragment q's lane offsets are fragment 0's plus a wave-uniform step -- added to the row's scalar base --
+    // and k-block kb's are k-block 0's plus 64 kb bytes (the instruction's immediate) except for the last k-block, whose channel tail is clamped:
+    // two offset registers instead of PPL * KBN.
+    constexpr bool XUNI = FULLW;
+    const int qstep = (MX ? 16 : 1) * a.xs_pix;
+    int xoff[XUNI ? 1 : PPL][XUNI ? 2 : KBN];
+    if constexpr (XUNI) {
+        const int px = (MX ? p : p * PPL) * a.xs_pix;
+        xoff[0][0] = px + kg * EPL * (int)sizeof(T);
+        xoff[0][1] = px + min((KBN - 1) * KB + kg * EPL, a.Cin - EPL) * (int)sizeof(T);
+    } else {
 #pragma unroll
-    for (int kb = 0; kb < KBN; ++kb) {
-        const int k = kb * KB + kg * EPL;
+        for (int kb = 0; kb < KBN; ++kb) {
+            const int k = kb * KB + kg * EPL;
 #pragma unroll
-        for (int q = 0; q < PPL; ++q) xoff[q][kb] = min(p * PPL + q, a.W - 1) * a.xs_pix + min(k, a.Cin - EPL) * (int)sizeof(T);
+            for (int q = 0; q < PPL; ++q) xoff[q][kb] = min(p * PPL + q, a.W - 1) * a.xs_pix + min(k, a.Cin - EPL) * (int)sizeof(T);
+        }
     }
     // The input fragments are loaded by inline asm and waited for with a COUNTED s_waitcnt: vmcnt retires loads and stores
     // in order, and hipcc, which cannot count stores across this loop's control flow, waits with vmcnt(0) -- i.e. for the
@@ -267,7 +281,11 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
         const char* rowp = (const char*)X + (size_t)min(iy, a.H - 1) * xrow_bytes;    // rows below the map are never used
         unroll_seq([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            xfrag_load<XTOP, i>(xoff[i / KBN][i % KBN], rowp);
+            if constexpr (XUNI) {
+                constexpr int q = i / KBN, kb = i % KBN;
+                if constexpr (kb == KBN - 1) xfrag_load<XTOP, i>(xoff[0][1], rowp + (size_t)q * qstep);
+                else xfrag_load<XTOP, i, kb * KB * (int)sizeof(T)>(xoff[0][0], rowp + (size_t)q * qstep);
+            } else xfrag_load<XTOP, i>(xoff[i / KBN][i % KBN], rowp);
         }, std::make_integer_sequence<int, PPL * KBN>{});
         xfrag_fence<XTOP, PPL * KBN>();
         st_in_flight = 0;
@@ -363,9 +381,11 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     for (int c = 0; c < NCH; ++c) sum[c] = 0.f;
     // MX: the accumulators are the small MFMA's C operands (lane = (channel lane >> 2, quad lane & 3): 4 pixels); lane permutations to and from
     // the expansion's layout (lane = channel + 16 * quad); the identity fragment of the transposing MFMA
-    f32x4 accx[NOPEN];
+    f32x4 accx[NOPEN][PPL];
 #pragma unroll
-    for (int s = 0; s < NOPEN; ++s) accx[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < NOPEN; ++s)
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) accx[s][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int bp_in = ((lane >> 2) + 16 * (lane & 3)) * 4, bp_out = (4 * (lane & 15) + (lane >> 4)) * 4;
     const int jq = lane & 3;
     t4 ident;
@@ -382,9 +402,9 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     // the 4 MB L2 evicted them quarter by quarter -- 25 % of block 3's time by knock-out timing.)  The project GEMM reads
     // this layout directly (PwArgs::a_chunked).
     static_assert(NI == 1, "chunked D: one 16-channel chunk per job");
-    T* __restrict__ Dlane = (T*)a.D + (size_t)(b * a.nchunks + ch) * a.Ho * a.Wo * 16 + (size_t)(p * TO) * a.ds_pix + kg * 4;   // + uniform row offset
+    T* __restrict__ Dlane = (T*)a.D + (size_t)(b * a.nchunks + ch) * a.Ho * a.Wo * 16 + (size_t)(MX ? p : p * TO) * a.ds_pix + kg * 4;   // + uniform row offset (MX: element t of a row = segment t)
     const size_t drow = (size_t)a.ds_row;
-    const int dpix = a.ds_pix;
+    const int dpix = MX ? 16 * a.ds_pix : a.ds_pix;
     auto flush = [&]() {                     // store the pending output row
         if (oy_pending >= 0 && !COSY_DBG(a.dbg & 1)) {      // dbg 1: no output stores (timing experiments)
             T* o = Dlane + (size_t)(COSY_DBG(a.dbg & 8) ? 0 : oy_pending) * drow;      // dbg 8: every row lands on row 0
@@ -414,32 +434,45 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
             WAVE_STAMP_ROW();
             f32x4 mq[XASM ? PPL : 1];
             wait_row(mq);
-            t4 W1, W2;                       // MX: the row's operands of the tap MFMAs
+            t4 W1[MX ? PPL : 1], W2[MX ? PPL : 1];      // MX: the row's operands of the tap MFMAs, per 16-pixel segment
             if constexpr (MX) {
                 if (IN || iy < a.H) {
-                    f32x4 m = f32x4{0.f, 0.f, 0.f, 0.f};
-                    // operands swapped: rows = pixels -> lane (channel lane & 15, quad lane >> 4) holds 4 pixels
-                    if constexpr (XASM) m = mq[0];
-                    else {
+                    int lo[PPL], hi[PPL];
 #pragma unroll
-                        for (int kb = 0; kb < KBN; ++kb) {
-                            raw_t xv = __builtin_bit_cast(raw_t, xc[0][kb]);
-                            if constexpr (WLDS) mma(m, xv, *(const raw_t*)(Wl + kb * 1024 + lane * 16));
-                            else mma(m, xv, wf[0][kb]);
+                    for (int q = 0; q < PPL; ++q) {
+                        f32x4 m = f32x4{0.f, 0.f, 0.f, 0.f};
+                        // operands swapped: rows = pixels -> lane (channel lane & 15, quad lane >> 4) holds 4 pixels
+                        if constexpr (XASM) m = mq[q];
+                        else {
+#pragma unroll
+                            for (int kb = 0; kb < KBN; ++kb) {
+                                raw_t xv = __builtin_bit_cast(raw_t, xc[q][kb]);
+                                if constexpr (WLDS) mma(m, xv, *(const raw_t*)(Wl + kb * 1024 + lane * 16));
+                                else mma(m, xv, wf[0][kb]);
+                            }
                         }
-                    }
-                    float y4[4];
+                        float y4[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) y4[e] = m[e] * mxp[0] + mxp[1];
-                    if (!COSY_DBG(a.dbg & 512)) silu4<false>(y4);      // dbg 512: no SiLU (timing)
-                    const t4 hv = t4{cvt(y4[0]), cvt(y4[1]), cvt(y4[2]), cvt(y4[3])};      // E in the storage type, as the unfused kernels store it
-                    const i32x2 hh = __builtin_bit_cast(i32x2, hv);
-                    int lo = hh[0], hi = hh[1];
-                    if (!COSY_DBG(a.dbg & 128)) { lo = __builtin_amdgcn_ds_bpermute(bp_in, hh[0]); hi = __builtin_amdgcn_ds_bpermute(bp_in, hh[1]); }   // dbg 128: no lane permutation (timing)
-                    int hp = __builtin_amdgcn_update_dpp(0, hi, 0x90, 0xf, 0xf, false);     // quad_perm [0,0,1,2]: the previous quad's pixels 2, 3
-                    int ln = __builtin_amdgcn_update_dpp(0, lo, 0xF9, 0xf, 0xf, false);     // quad_perm [1,2,3,3]: the next quad's pixels 0, 1
-                    hp = jq == 0 ? 0 : hp; ln = jq == 3 ? 0 : ln;                           // zero padding at the row ends
-                    W1 = __builtin_bit_cast(t4, i32x2{lo, hi}); W2 = __builtin_bit_cast(t4, i32x2{hp, ln});
+                        for (int e = 0; e < 4; ++e) y4[e] = m[e] * mxp[0] + mxp[1];
+                        if (!COSY_DBG(a.dbg & 512)) silu4<false>(y4);      // dbg 512: no SiLU (timing)
+                        const t4 hv = t4{cvt(y4[0]), cvt(y4[1]), cvt(y4[2]), cvt(y4[3])};      // E in the storage type, as the unfused kernels store it
+                        const i32x2 hh = __builtin_bit_cast(i32x2, hv);
+                        lo[q] = hh[0]; hi[q] = hh[1];
+                        if (!COSY_DBG(a.dbg & 128)) { lo[q] = __builtin_amdgcn_ds_bpermute(bp_in, hh[0]); hi[q] = __builtin_amdgcn_ds_bpermute(bp_in, hh[1]); }   // dbg 128: no lane permutation (timing)
+                    }
+#pragma unroll
+                    for (int q = 0; q < PPL; ++q) {
+                        int hp = __builtin_amdgcn_update_dpp(0, hi[q], 0x90, 0xf, 0xf, false);     // quad_perm [0,0,1,2]: the previous quad's pixels 2, 3
+                        int ln = __builtin_amdgcn_update_dpp(0, lo[q], 0xF9, 0xf, 0xf, false);     // quad_perm [1,2,3,3]: the next quad's pixels 0, 1
+                        // a segment's first / last quad: the neighbouring segment's last / first quad, zero padding at the row ends
+                        int hp0 = 0, ln3 = 0;
+                        if constexpr (PPL > 1) {
+                            if (q > 0) hp0 = __builtin_amdgcn_update_dpp(0, hi[q > 0 ? q - 1 : 0], 0x93, 0xf, 0xf, false);             // quad_perm [3,0,1,2]
+                            if (q < PPL - 1) ln3 = __builtin_amdgcn_update_dpp(0, lo[q < PPL - 1 ? q + 1 : 0], 0x39, 0xf, 0xf, false);   // quad_perm [1,2,3,0]
+                        }
+                        hp = jq == 0 ? hp0 : hp; ln = jq == 3 ? ln3 : ln;
+                        W1[q] = __builtin_bit_cast(t4, i32x2{lo[q], hi[q]}); W2[q] = __builtin_bit_cast(t4, i32x2{hp, ln});
+                    }
                 }
             } else
             if (IN || iy < a.H) {
@@ -512,8 +545,10 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
                 if constexpr (!IN) { if (iy + LO - ky < 0 || oy < oy_a || oy >= oy_b) continue; }   // wave-uniform
                 if constexpr (MX) {
                     if ((IN || iy < a.H) && !COSY_DBG(a.dbg & 64)) {       // dbg 64: no tap MFMAs (timing)
-                        accx[os] = mma4(Af[ky][0], W1, accx[os]);
-                        accx[os] = mma4(Af[ky][1], W2, accx[os]);
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q) accx[os][q] = mma4(Af[ky][0], W1[q], accx[os][q]);
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q) accx[os][q] = mma4(Af[ky][1], W2[q], accx[os][q]);
                     }
                 } else
                 if (IN || iy < a.H) {
@@ -530,23 +565,26 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
                 }
                 if constexpr (MX) {
                     if (ky == KS - 1) {
-                        float y4[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) y4[e] = accx[os][e] * mxp[2] + mxp[3];
-                        if (!COSY_DBG(a.dbg & 512)) silu4<false>(y4);      // dbg 512: no SiLU (timing)
+                        for (int q = 0; q < PPL; ++q) {
+                            float y4[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) sum[0] += y4[e];
-                        const t4 hv = t4{cvt(y4[0]), cvt(y4[1]), cvt(y4[2]), cvt(y4[3])};
-                        const i32x2 hh = __builtin_bit_cast(i32x2, hv);
-                        if (COSY_DBG(a.dbg & 256)) {                      // dbg 256: no permutation / transposition of the output row (timing)
-                            ynew[0][0] = hv;
-                        } else {
-                        const int lo = __builtin_amdgcn_ds_bpermute(bp_out, hh[0]), hi = __builtin_amdgcn_ds_bpermute(bp_out, hh[1]);
-                        const f32x4 tr = mma16(__builtin_bit_cast(t4, i32x2{lo, hi}), ident, f32x4{0.f, 0.f, 0.f, 0.f});   // -> lane (pixel, 4 channels), exact
+                            for (int e = 0; e < 4; ++e) y4[e] = accx[os][q][e] * mxp[2] + mxp[3];
+                            if (!COSY_DBG(a.dbg & 512)) silu4<false>(y4);      // dbg 512: no SiLU (timing)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) ynew[0][0][e] = (T)tr[e];
+                            for (int e = 0; e < 4; ++e) sum[0] += y4[e];
+                            const t4 hv = t4{cvt(y4[0]), cvt(y4[1]), cvt(y4[2]), cvt(y4[3])};
+                            const i32x2 hh = __builtin_bit_cast(i32x2, hv);
+                            if (COSY_DBG(a.dbg & 256)) {                      // dbg 256: no permutation / transposition of the output row (timing)
+                                ynew[q][0] = hv;
+                            } else {
+                                const int lo = __builtin_amdgcn_ds_bpermute(bp_out, hh[0]), hi = __builtin_amdgcn_ds_bpermute(bp_out, hh[1]);
+                                const f32x4 tr = mma16(__builtin_bit_cast(t4, i32x2{lo, hi}), ident, f32x4{0.f, 0.f, 0.f, 0.f});   // -> lane (pixel, 4 channels), exact
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) ynew[q][0][e] = (T)tr[e];
+                            }
+                            accx[os][q] = f32x4{0.f, 0.f, 0.f, 0.f};
                         }
-                        accx[os] = f32x4{0.f, 0.f, 0.f, 0.f};
                         done = true; oy_done = oy;
                     }
                 } else
@@ -582,6 +620,9 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) yv[t][ni] = ynew[t][ni];
                 oy_pending = oy_done;
+                // MX: stored right away -- the row finishes behind the next input row's loads in any case (the queue order the counted wait needs),
+                // and PPL register pairs are not held across the next expansion
+                if constexpr (MX) { flush(); oy_pending = -1; }
             }
     };
     // interior rows: iy + LO - (KS-1) >= oy_a * S (every tap row's output row is >= oy_a), iy + LO < oy_b * S (... < oy_b),
