@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libcosyhip.so')
 SOURCES = ['kernels_geom.hip', 'kernels_dist.hip', 'kernels_raster.hip', 'kernels_train.hip', 'kernels_net.hip', 'kernels_small.hip',
-           'kernels_dw.hip', 'kernels_wave.hip', 'kernels_stem.hip', 'effnet.hip']
+           'kernels_dw.hip', 'kernels_wave.hip', 'kernels_stem.hip', 'kernels_smx.hip', 'effnet.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # No packed-fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) anywhere in the library.  Round 4: a wave's packed-fp32 results were WRONG while
 # another wave on its SIMD -- another HIP stream's kernel -- issued 16-bit MFMAs with VGPR accumulators (the wave-autonomous fronts): the rasteriser, whose
@@ -27,7 +27,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-u
 # Per-file flags.  kernels_wave.hip: hipcc's SLP vectoriser pairs the depthwise FMAs of the wave front into v_pk_fma_f32 -- which
 # issues no faster than two v_fma_f32 on gfx950 (profiles/exp/valu_bench.hip: 5.85 vs 2 x 3.1 cycles) -- and pays for the pairing
 # with register shuffles (61 v_mov_b32 per row of the k=5 shape) and un-fused multiply + add tails.  Scalar FMAs, no moves.
-FILE_FLAGS = {'kernels_wave.hip': ['-fno-slp-vectorize'], 'kernels_dw.hip': ['-fno-slp-vectorize'], 'kernels_stem.hip': ['-fno-slp-vectorize']}   # kernels_dw.hip: see its header
+FILE_FLAGS = {'kernels_wave.hip': ['-fno-slp-vectorize'], 'kernels_dw.hip': ['-fno-slp-vectorize'], 'kernels_stem.hip': ['-fno-slp-vectorize'], 'kernels_smx.hip': ['-fno-slp-vectorize']}   # kernels_dw.hip: see its header
 
 
 def _headers():

@@ -61,6 +61,7 @@ struct Block {
     bool skip;
     bool wave;            // front = mbconv_wave_kernel (kernels_wave.hip)
     bool small;           // front = mbconv_small_kernel (whole-image kernel of the late blocks)
+    bool smx;             // ... in its matrix-pipe form (kernels_smx.hip: 8x8 maps, E and the taps in the storage type); params in wave_params
     bool tiled;           // front = mbconv_tile_kernel (LDS-tiled kernel: high-resolution blocks the wave kernel's row mapping does not fit)
     bool fused;           // wave || small || tiled: the expanded tensor never reaches HBM; otherwise pw_gemm_dma -> E -> dwconv
     PwLayer exp, proj;
@@ -189,6 +190,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         // unfused kernels (pw_gemm_dma -> E -> dwconv)
         b.wave = n->fuse && b.d.e != 1 && ((n->wave_mask >> i) & 1) && wave_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
         b.small = !b.wave && n->fuse && b.d.e != 1 && ((n->small_mask >> i) & 1) && small_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
+        b.smx = b.small && small_mx_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
         b.tiled = !b.wave && !b.small && n->fuse && b.d.e != 1 && ((n->tile_mask >> i) & 1) && tile_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype);
         b.fused = b.wave || b.small || b.tiled;
         b.exp_wp_fused = nullptr;
@@ -203,7 +205,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
                 // ride in the depthwise taps (dw_w_fold), BatchNorm 1's bias initialises the depthwise accumulators.
                 // (Measured on the wave kernel too: no gain there -- the freed VALU slots do not shorten its rows, and the MFMA
                 // results then feed inline asm directly, which needs explicit wait states -- so it keeps its BatchNorms.)
-                const PwCfg c48 = b.wave ? PwCfg{1, 1} : PwCfg{3, 1};   // 16-channel tiles for the wave kernel, 48 for the small / tiled kernels
+                const PwCfg c48 = b.wave || b.smx ? PwCfg{1, 1} : PwCfg{3, 1};   // 16-channel tiles for the wave kernel, 48 for the small / tiled kernels
                 const size_t ne = pw_packed_elems(b.d.cin, b.cmid, c48, n->dtype);
                 b.exp_wp_fused = bump.take(ne * n->esz);
                 std::vector<float> b0f(b.cmid, 0.f);
@@ -256,8 +258,21 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
                 if (fill) wave_pack_params(exp_sc.data(), exp_bi.data(), w.data(), sc.data(), bi.data(), b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W, wp.data());
                 b.wave_params = up_f32(wp);
             }
+            if (b.smx) {      // b0f was uploaded as b.b0_fold above; its host copy is rebuilt here (log2 e * BN0 bias)
+                std::vector<char> sp(small_mx_param_bytes(b.cmid, b.d.k), 0);
+                if (fill) {
+                    std::vector<float> sc0, bi0;
+                    const float* pe = p - 4 * b.cmid - (size_t)b.cmid * kk - 4 * b.cmid;      // BatchNorm 0 of the expansion (4 * Cmid floats in front of the depthwise weights)
+                    fold_bn(pe, b.cmid, b.cmid, sc0, bi0);
+                    std::vector<float> b0l(b.cmid);
+                    for (int c = 0; c < b.cmid; ++c) b0l[c] = (float)((double)bi0[c] * 1.4426950408889634);
+                    small_mx_pack_params(b0l.data(), w.data(), sc.data(), bi.data(), b.cmid, b.d.k, n->dtype, sp.data());
+                }
+                b.wave_params = (float*)bump.take(sp.size());
+                if (fill) { hipError_t e2 = hipMemcpy(b.wave_params, sp.data(), sp.size(), hipMemcpyHostToDevice); if (e2 != hipSuccess) *herr = e2; }
+            }
             b.dw_w_fold = nullptr;
-            if (b.small) {
+            if (b.small && !b.smx) {
                 std::vector<float> wf(w.size(), 0.f);
                 const bool xp = small_transposed(b.d.cin, b.cmid, b.H, b.W, b.d.k, b.d.s, n->dtype);
                 if (fill)
@@ -440,14 +455,16 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         } else if (b.fused) {
             FuseArgs f{};
             f.X = in; f.Wp = b.exp_wp_fused;
-            if (b.small) { f.b0 = b.b0_fold; f.dww = b.dw_w_fold; f.b1 = b.dw_bias; }
+            if (b.smx) f.wparams = b.wave_params;
+            else if (b.small) { f.b0 = b.b0_fold; f.dww = b.dw_w_fold; f.b1 = b.dw_bias; }
             else { f.s0 = b.exp.scale; f.b0 = b.exp.bias; f.dww = b.dw_w; f.s1 = b.dw_scale; f.b1 = b.dw_bias; f.wparams = b.wave_params; }
             f.D = Dbuf; f.partial = w.partial; f.zeros = n->zeros;
             f.B = Bc; f.H = b.H; f.W = b.W; f.Cin = b.d.cin; f.Cmid = b.cmid; f.Ho = b.Ho; f.Wo = b.Wo; f.k = b.d.k; f.s = b.d.s; f.pad_lo = b.pad_lo;
             f.x_colmajor = b.in_col; f.d_colmajor = b.out_col;
-            if ((rc = b.wave ? launch_mbconv_wave(f, n->dtype, &se_tiles, s) : b.tiled ? launch_mbconv_tile(f, n->dtype, s) : launch_mbconv_small(f, n->dtype, s))) return rc;
+            if ((rc = b.wave ? launch_mbconv_wave(f, n->dtype, &se_tiles, s) : b.tiled ? launch_mbconv_tile(f, n->dtype, s) : b.smx ? launch_mbconv_small_mx(f, n->dtype, s) : launch_mbconv_small(f, n->dtype, s))) return rc;
             if (b.wave) wave_kernel_name(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W, kn, sizeof(kn));
             else if (b.tiled) tile_kernel_name(b.d.cin, b.d.k, b.d.s, n->dtype, kn, sizeof(kn));
+            else if (b.smx) small_mx_kernel_name(b.d.cin, b.d.k, n->dtype, kn, sizeof(kn));
             else small_kernel_name(b.d.cin, b.d.k, b.d.s, n->dtype, b.H, b.W, kn, sizeof(kn));
             if ((rc = mark(kn, i, ((double)Bc * b.H * b.W * b.d.cin + (double)Bc * b.Ho * b.Wo * b.cmid + (double)b.d.cin * b.cmid) * esz_d,
                            2.0 * Bc * b.H * b.W * b.d.cin * b.cmid + 2.0 * Bc * b.Ho * b.Wo * b.cmid * b.d.k * b.d.k,
@@ -491,7 +508,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         a.res = b.skip ? in : nullptr; a.gate = w.gate; a.se_fused = b.se_fused ? &se : nullptr;
         a.M = Bc * b.Ho * b.Wo; a.K = b.cmid; a.N = b.d.cout; a.HW = b.Ho * b.Wo; a.silu = 0; a.zeros = n->zeros;
         // the wave front (and the row-mapped 8x8 kernel) write D as [sample][Cmid/16][HW][16]
-        a.a_chunked = stem_x != nullptr || b.wave || (b.small && small_writes_chunked(b.d.cin, b.cmid, b.H, b.W, b.Ho, b.Wo, b.d.k, b.d.s, n->dtype));
+        a.a_chunked = stem_x != nullptr || b.wave || b.smx || (b.small && small_writes_chunked(b.d.cin, b.cmid, b.H, b.W, b.Ho, b.Wo, b.d.k, b.d.s, n->dtype));
         if ((rc = probe(100 + i, Dbuf, Bc, b0, b.Ho * b.Wo, b.cmid, a.a_chunked, b.out_col ? b.Ho : 0))) return rc;
         if ((rc = launch_pw_gemm(a, b.proj.cfg, n->dtype, s))) return rc;
         if (n->probe_layer == 200 + i && n->probe_out)      // behind the GEMM: with the squeeze-excite in its prologue that is where the gate is written
@@ -728,7 +745,7 @@ int cosy_effnet_b3_block_info(const cosy_net_t* n, int i, int* dims) {
     // where the project GEMM applies the squeeze-excite gate: to the weight fragments (maps of a multiple of 64 pixels: a wave's 64
     // rows belong to one sample) or to the activation rows
     const int gate_w = (b.Ho * b.Wo) % 64 == 0;
-    const int v[11] = {b.H, b.W, b.Ho, b.Wo, b.d.cin, b.cmid, b.d.cout, i == 0 && n->stem_fused ? 4 : b.wave ? (wave_taps_on_mfma(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W) ? 5 : 1) : b.small ? 2 : b.tiled ? 3 : 0, b.d.k, b.d.s, gate_w};
+    const int v[11] = {b.H, b.W, b.Ho, b.Wo, b.d.cin, b.cmid, b.d.cout, i == 0 && n->stem_fused ? 4 : b.wave ? (wave_taps_on_mfma(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W) ? 5 : 1) : b.smx ? 6 : b.small ? 2 : b.tiled ? 3 : 0, b.d.k, b.d.s, gate_w};
     for (int q = 0; q < 11; ++q) dims[q] = v[q];
     return COSY_OK;
 }

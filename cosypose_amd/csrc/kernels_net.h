@@ -81,6 +81,13 @@ bool small_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W);
 int launch_mbconv_small(const FuseArgs& a, int dtype, hipStream_t s);
 bool small_transposed(int Cin, int Cmid, int H, int W, int k, int s, int dtype);   // taps wanted as w[kx][ky]
 bool small_writes_chunked(int Cin, int Cmid, int H, int W, int Ho, int Wo, int k, int s, int dtype);   // D layout of launch_mbconv_small
+// 8x8 maps with the depthwise taps on the matrix pipe (kernels_smx.hip): Wp packed with PwCfg{1,1} (16-channel tiles) from W * s0 * log2(e), wparams =
+// small_mx_pack_params (log2(e) * BN0 bias, folded BatchNorm 1, Toeplitz tap fragments in the storage type); D chunked; partial has ONE tile per sample
+bool small_mx_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W);
+size_t small_mx_param_bytes(int Cmid, int k);
+void small_mx_pack_params(const float* b0l2e, const float* dww, const float* s1, const float* b1, int Cmid, int k, int dtype, void* dst);
+void small_mx_kernel_name(int Cin, int k, int dtype, char* buf, size_t n);
+int launch_mbconv_small_mx(const FuseArgs& a, int dtype, hipStream_t s);
 // wave-autonomous variant (kernels_wave.hip): expanded rows in registers, no LDS ring / barriers; expand weights packed with
 // PwCfg{1,1} (16-channel tiles, natural row order); partial has ONE tile per sample
 bool wave_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W);

@@ -621,7 +621,8 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
                     for (int ni = 0; ni < NI; ++ni) yv[t][ni] = ynew[t][ni];
                 oy_pending = oy_done;
                 // MX: stored right away -- the row finishes behind the next input row's loads in any case (the queue order the counted wait needs),
-                // and PPL register pairs are not held across the next expansion
+                // and PPL register pairs are not held across the next expansion.  (The fp32-FMA form keeps the parking: with the stores inside its
+                // straight-line tap rows hipcc's schedule spills 70-150 bytes in six variants.)
                 if constexpr (MX) { flush(); oy_pending = -1; }
             }
     };

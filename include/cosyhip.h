@@ -97,7 +97,7 @@ int cosy_effnet_b3_features_nchw(cosy_net_t* net, int B, float* out, cosy_stream
  * (sigmoid(_se_expand(...)), :85-88); layer -2 switches the probe off.
  * cosy_effnet_b3_block_info: dims[11] = {H, W, Ho, Wo, Cin, Cmid, Cout, front kernel (0 unfused, 1 wave, 2 small, 3 tiled, 4 block 0 behind the
  * fused stem: the stem tensor stays fp32 in registers and is never stored -- a forward with probe -1 or per-stage taps runs the unfused kernels,
- * 5 wave with the depthwise taps applied by small MFMAs: the expanded values and the taps are rounded to the storage type), k, s,
+ * 5 wave / 6 small with the depthwise taps applied by small MFMAs: the expanded values and the taps are rounded to the storage type), k, s,
  * SE gate applied to the project weights (1) or to the activation rows (0)}. */
 int cosy_effnet_b3_set_probe(cosy_net_t* net, int layer, float* out);
 int cosy_effnet_b3_block_info(const cosy_net_t* net, int block, int* dims);

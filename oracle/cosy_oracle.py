@@ -481,7 +481,7 @@ class TorchRef:
         k, s, e, cin, cout = B3_BLOCKS[i]
         p = f'backbone._blocks.{i}.'
         inp = x
-        if e != 1 and fused == 2:
+        if e != 1 and fused in (2, 6):
             # small kernel (front kind 2, mbconv_small_kernel): BN0's scale times log2(e) is folded into the expand weights
             # BEFORE they are rounded to the storage type, its bias enters as the MFMA's C operand, the expanded tensor stays fp32
             # (effnet.hip: build_weights).  t = log2(e) * BN0(expand); the device evaluates silu as (t / (1 + 2^-t)) * ln 2.
@@ -492,12 +492,14 @@ class TorchRef:
             We = R((sd[p + '_expand_conv.weight'].double() * (s0 * L2E)[:, None, None, None]).float())
             t = self._conv(x, We, 1, 1) + (b0 * L2E).float()[None, :, None, None]
             x = sw(t * 0.6931471805599453)
+            if fused == 6:                                       # the small kernel's matrix-pipe form (kernels_smx.hip): E rounded to the storage type
+                x = R(x)
         elif e != 1:
             x = sw(self._bn(self._conv(x, R(sd[p + '_expand_conv.weight']), 1, 1), p + '_bn0'))
             if not fused or fused == 5:                          # unfused blocks store the expanded tensor; front kind 5 (wave kernel, taps on the
                 x = R(x)                                         # matrix pipe) rounds it to the storage type as the small MFMA's operand
         dw_w = sd[p + '_depthwise_conv.weight']
-        if fused == 5:                                           # ... and the taps too (products exact, fp32 accumulation)
+        if fused in (5, 6):                                      # ... and the taps too (products exact, fp32 accumulation)
             dw_w = R(dw_w)
         d32 = sw(self._bn(self._conv(x, dw_w, k, s, groups=x.shape[1]), p + '_bn1'))
         q = d32.mean((2, 3), keepdim=True)

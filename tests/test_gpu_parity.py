@@ -241,7 +241,7 @@ def test_fused_kernels_vs_storage_emulation(model, oracle, golden_sd, dtype, hw)
     kinds = [p[7] for p in plan]
     assert (kinds[0] == 4) == (hw[1] in (256, 320)), kinds       # the stem + block-0 front: 256- and 320-pixel-wide crops (kernels_stem.hip), the unfused kernels elsewhere
     if hw in ((256, 256), (240, 320)):     # blocks 2-17 wave (240x320: block 2's 160-pixel rows are walked as 120-pixel columns), 19-25 small
-        assert all(k in (1, 5) for k in kinds[2:18]) and all(k == 2 for k in kinds[19:26]) and kinds[18] == 0, kinds
+        assert all(k in (1, 5) for k in kinds[2:18]) and all(k == (6 if hw == (256, 256) else 2) for k in kinds[19:26]) and kinds[18] == 0, kinds      # 6: the small kernel's matrix-pipe form (8x8 maps)
         # 5 = the wave kernel with its depthwise taps on the matrix pipe (stride-1 blocks whose rows are whole 16-pixel segments: 3, 4, 6, 7, 9-17 at 256x256)
         assert [i for i, k in enumerate(kinds) if k == 5] == ([3, 4, 6, 7] + list(range(9, 18)) if hw == (256, 256) else [3, 4]), kinds      # 240x320: the 80-pixel rows of blocks 3 / 4
     if hw == (224, 224):                   # 56-pixel rows of blocks 3 / 4: no wave variant -> tiled; every other front has a !FULLW wave variant
