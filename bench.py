@@ -59,19 +59,28 @@ GPU_CLOCK_GHZ, N_SIMD = 2.4, 1024
 
 
 def valu_bound(name, k, batch, crop):
-    """Issue-slot floor of a fused-front launch (mbconv_wave_kernel / mbconv_small_kernel): these kernels are bound by the vector
-    ALU beside the matrix cores, not by HBM or MFMA, so the line prices them against THAT roof too.  Model, per 64
+    """Issue-slot floor of a fused-front launch (mbconv_wave_kernel / mbconv_small_kernel / mbconv_small_mx_kernel): these kernels are bound by
+    the vector ALU beside the matrix cores, not by HBM or MFMA, so the line prices them against THAT roof too.  Model, per 64
     elements: BN + SiLU = fma + (exp, rcp) + add + mul = 3 x 3.1 + 2 x 8.7 = 26.7 cycles, once per EXPANDED element (S^2 per
-    output element) and once per output element; k^2 tap FMAs, one packed convert per two outputs and one squeeze add per
-    output element.  floor = instruction-cycles / (1024 SIMDs x 2.4 GHz); `frac` = floor / measured launch time."""
+    output element) and once per output element; one squeeze add and half a packed convert per output element; then either k^2 tap FMAs
+    (fp32-FMA form) or, where the taps run on the matrix pipe (round 5: stride-1 wave variants on full 16-pixel segments, the 8x8-map kernel),
+    what feeds the small MFMAs instead: the expanded value's clamp + half a packed convert, one lane move / select per output, the output's clamp
+    and the conversion back behind the transposing MFMA.  floor = instruction-cycles / (1024 SIMDs x 2.4 GHz); `frac` = floor / measured launch time."""
     import re
     from cosypose_amd import arch
-    m = re.match(r'mbconv_(wave|small)_kernel<[^,]+, (\d), (\d)', name)
-    if not m:
-        return None
-    ks, st = int(m.group(2)), int(m.group(3))
+    m = re.match(r'mbconv_(wave|small)_kernel<([^,]+), (\d), (\d)(?:, \d+, \d+, \d+, (true|false))?', name)
+    mx = False
+    if m:
+        ks, st = int(m.group(3)), int(m.group(4))
+        mx = m.group(1) == 'wave' and st == 1 and m.group(5) == 'true' and m.group(2).strip() != 'float' and ks in (3, 5)
+    else:
+        m = re.match(r'mbconv_small_mx_kernel<[^,]+, (\d)', name)
+        if not m:
+            return None
+        ks, st, mx = int(m.group(1)), 1, True
     silu = 3 * VALU_CYC['fma'] + 2 * VALU_CYC['trans']
-    per_out = st * st * silu + ks * ks * VALU_CYC['fma'] + silu + VALU_CYC['cvt_pk'] / 2 + VALU_CYC['fma']
+    per_out = st * st * silu + silu + VALU_CYC['cvt_pk'] / 2 + VALU_CYC['fma']
+    per_out += (2 * VALU_CYC['fma'] + VALU_CYC['cvt_pk'] + VALU_CYC['fma']) if mx else ks * ks * VALU_CYC['fma']
     h, w = arch.conv_out(crop[0], 3, 2), arch.conv_out(crop[1], 3, 2)
     elems, n_layers = 0.0, 0
     for i, (bk, bs, e, cin, cout) in enumerate(arch.B3_BLOCKS):
@@ -84,7 +93,8 @@ def valu_bound(name, k, batch, crop):
         return None
     floor_us = elems / n_layers / 64.0 * per_out / (N_SIMD * GPU_CLOCK_GHZ * 1e3)
     return dict(floor_us=round(floor_us, 1), frac=round(floor_us / (k['ms'] / k['n'] * 1e3), 3), cycles_per_64_outputs=round(per_out, 1),
-                model='issue cycles of BN+SiLU on the expanded and the output elements, k*k tap FMAs, convert, squeeze add at the measured '
+                taps='matrix pipe' if mx else 'fp32 FMA',
+                model='issue cycles of BN+SiLU on the expanded and the output elements, k*k tap FMAs (or the conversions and lane moves that feed the tap MFMAs), convert, squeeze add at the measured '
                       'per-instruction costs (fma 3.1, exp / rcp 8.7, cvt_pk 4.7 cycles per wave64 instruction), 1024 SIMDs at 2.4 GHz')
 
 
