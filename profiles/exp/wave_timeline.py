@@ -61,6 +61,12 @@ def main():
         return
     ghz = 2.4
     n, t0, t1, tf, te, rsum, rmin, rmax = st.T
+    if os.environ.get('COSY_WAVE_PHASES'):      # phase experiment build (profiles/exp/wave_phases.diff): words 6 / 7 hold three phase sums instead of min / max
+        pa, pb, pc = (rmin.astype(np.uint64) & 0xffffffff).astype(float), (rmin.astype(np.uint64) >> 32).astype(float), (rmax.astype(np.uint64) & 0xffffffff).astype(float)
+        rows = n.astype(float)
+        print(f'phases per row (cycles, mean over the recorded jobs): wait + expansion MFMAs {np.mean(pa / rows):.0f} | BN0 + SiLU + convert + permutation + halo operands {np.mean(pb / rows):.0f} | '
+              f'next loads + tap MFMAs {np.mean(pc / rows):.0f} | row total {np.mean(rsum / (n - 1)):.0f} (the rest: BN1 + SiLU + sums + convert + permutation + transposition + store + loop)')
+        return
     tot, pro, first = te - t0, t1 - t0, tf - t1
     last = te - (tf + rsum)                     # last row start -> job end: the last row, the last store, the squeeze tree
     mean_row = rsum / (n - 1)
