@@ -21,7 +21,8 @@ Storage type.  BASELINE configs[1] names bf16 AND north_star demands <= 1e-4 rel
 `value` is measured in fp16; the same timed loop is repeated in bf16 and fp32 and reported beside it (`other_dtypes`), and
 `pose_deviation` is measured live: the benched dtype's refined poses against the fp32 HIP path (itself held to the reference
 at <= 1e-4 by the parity tests) on this very workload, per parameter group (rotation entries absolute, translation relative
-to each pose's own translation).
+to each pose's own translation), and -- `pose_deviation.vs_oracle`, inside the cpu_baseline leg -- against the CPU ORACLE on the
+first 32 detections of the workload through all five iterations, for every benched storage type.
 
 One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel FAMILY of the backbone (all instantiations of one
 kernel template together; the dominant single instantiation and the next two are reported beside it), timed live with HIP events recorded on
@@ -58,7 +59,7 @@ VALU_CYC = dict(fma=3.1, trans=8.7, cvt_pk=4.7)
 GPU_CLOCK_GHZ, N_SIMD = 2.4, 1024
 
 
-def valu_bound(name, k, batch, crop):
+def valu_bound(name, k, batch, crop, front_kind=None):
     """Issue-slot floor of a fused-front launch (mbconv_wave_kernel / mbconv_small_kernel / mbconv_small_mx_kernel): these kernels are bound by
     the vector ALU beside the matrix cores, not by HBM or MFMA, so the line prices them against THAT roof too.  Model, per 64
     elements: BN + SiLU = fma + (exp, rcp) + add + mul = 3 x 3.1 + 2 x 8.7 = 26.7 cycles, once per EXPANDED element (S^2 per
@@ -68,16 +69,14 @@ def valu_bound(name, k, batch, crop):
     and the conversion back behind the transposing MFMA.  floor = instruction-cycles / (1024 SIMDs x 2.4 GHz); `frac` = floor / measured launch time."""
     import re
     from cosypose_amd import arch
-    m = re.match(r'mbconv_(wave|small)_kernel<([^,]+), (\d), (\d)(?:, \d+, \d+, \d+, (true|false))?', name)
-    mx = False
-    if m:
-        ks, st = int(m.group(3)), int(m.group(4))
-        mx = m.group(1) == 'wave' and st == 1 and m.group(5) == 'true' and m.group(2).strip() != 'float' and ks in (3, 5)
-    else:
-        m = re.match(r'mbconv_small_mx_kernel<[^,]+, (\d)', name)
-        if not m:
-            return None
-        ks, st, mx = int(m.group(1)), 1, True
+    m = re.match(r'mbconv_(wave|small|small_mx)_kernel<([^,]+), (\d)(?:, (\d))?', name)
+    if not m:
+        return None
+    ks, st = int(m.group(3)), (int(m.group(4)) if m.group(1) != 'small_mx' and m.group(4) else 1)
+    # which form of the depthwise the launches ran comes from the engine itself (cosy_effnet_b3_block_info: front kinds 5 / 6 = taps on the matrix
+    # pipe), not from a re-derivation of kernels_wave.hip's predicate on the kernel name
+    kinds = {front_kind.get(l) for l in k['layers']} if front_kind else set()
+    mx = bool(kinds) and kinds <= {5, 6}
     silu = 3 * VALU_CYC['fma'] + 2 * VALU_CYC['trans']
     per_out = st * st * silu + silu + VALU_CYC['cvt_pk'] / 2 + VALU_CYC['fma']
     per_out += (2 * VALU_CYC['fma'] + VALU_CYC['cvt_pk'] + VALU_CYC['fma']) if mx else ks * ks * VALU_CYC['fma']
@@ -144,8 +143,15 @@ def host_cpu():
 
 
 def _cpu_worker(args):
-    """one process of the all-cores CPU baseline: B = 16 detections per call at `threads` threads, `calls` timed calls after a warm-up"""
-    H, W, threads, calls, seed = args
+    """one process of the all-cores CPU baseline: `n_det` detections per call at `threads` threads, pinned to the logical CPUs `cpus` (None: unpinned),
+    `calls` timed calls after a warm-up"""
+    H, W, threads, calls, seed, n_det, cpus = args
+    if cpus:
+        try:
+            os.sched_setaffinity(0, cpus)
+        except (AttributeError, OSError):
+            pass
+    os.environ['OMP_NUM_THREADS'] = str(threads)
     sys.path.insert(0, os.path.join(REPO, 'oracle'))
     import torch
     import cosy_oracle as O
@@ -154,7 +160,6 @@ def _cpu_worker(args):
     tr = O.TorchRef(syn.golden_state_dict(0))
     pts = syn.make_mesh_points(7, 21, 2500)[:, np.random.RandomState(0).choice(2500, 2000, replace=False)]
     h, w = (512, 512) if H == W else (480, 640)
-    n_det = 16
     obj, im, boxes = syn.make_detections(1 + seed, n_det, 2, 21, h, w)
     frames = syn.make_frames(2, 2, h, w)[im]
     K = syn.make_K(n_det, h, w)
@@ -168,18 +173,37 @@ def _cpu_worker(args):
     return t0, time.time(), n_det * calls
 
 
-def cpu_all_cores(crop, threads=16, calls=3):
-    """The CPU port on ALL host cores: stock torch-CPU convolutions stop scaling at ~16 threads, so the cores are filled
-    with cpu_count // 16 independent processes of 16 threads, each running the loop on its own B = 16 detections; rate = detections
-    processed by all of them / the span from the first start to the last end of the timed calls."""
+def cpu_all_cores(crop, budget_s=24.0):
+    """The CPU port on ALL host cores, as the host's BEST (round 5's review: one 16-thread process at B = 1 beat sixteen 16-thread processes at
+    B = 16 -- stock torch-CPU convolutions lose to thread placement on a 256-CPU host, so the figure understated the host).  The cores are filled
+    with independent processes PINNED (sched_setaffinity) to disjoint runs of physical cores -- logical CPUs 0 .. n/2-1 when SMT doubles them --
+    each running the loop on its own few detections; three shapes are tried (threads per process x detections per call: 4 x 1, 8 x 2, 16 x 4) and the best
+    is reported with all of them beside it.  rate = detections processed by all processes / span from the first start to the last end."""
     import multiprocessing as mp
     ncpu = os.cpu_count() or 1
-    procs = max(1, min(ncpu // threads, 16))
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        avail = list(range(ncpu))
+    phys = avail[:max(1, len(avail) // 2)] if len(avail) >= 32 else avail      # SMT siblings are the upper half of the ids on the GPU boxes' EPYC hosts
     ctx = mp.get_context('spawn')
-    with ctx.Pool(procs) as pool:
-        res = pool.map(_cpu_worker, [(crop[0], crop[1], threads, calls, i) for i in range(procs)])
-    t0, t1, n = min(r[0] for r in res), max(r[1] for r in res), sum(r[2] for r in res)
-    return dict(value=round(n / (t1 - t0), 2), processes=procs, threads_per_process=threads, cores=procs * threads)
+    tried = []
+    for threads, n_det, calls in ((4, 1, 6), (8, 2, 4), (16, 4, 3)):
+        procs = max(1, min(len(phys) // threads, 64))
+        if procs * threads > len(phys) and tried:
+            continue
+        jobs = [(crop[0], crop[1], min(threads, len(phys)), calls, i, n_det, phys[i * threads:(i + 1) * threads] or None) for i in range(procs)]
+        t_start = time.time()
+        with ctx.Pool(procs) as pool:
+            res = pool.map(_cpu_worker, jobs)
+        t0, t1, n = min(r[0] for r in res), max(r[1] for r in res), sum(r[2] for r in res)
+        tried.append(dict(value=round(n / (t1 - t0), 2), processes=procs, threads_per_process=min(threads, len(phys)), detections_per_call=n_det,
+                          cores=procs * min(threads, len(phys)), pinned=True))
+        budget_s -= time.time() - t_start
+        if budget_s < 6.0:
+            break
+    best = max(tried, key=lambda d: d['value'])
+    return dict(best, tried=tried)
 
 
 def cpu_baseline(crop, repeats=3):
@@ -226,11 +250,63 @@ def cpu_baseline(crop, repeats=3):
         allc = cpu_all_cores(tuple(crop))
     except Exception as e:      # noqa: BLE001 -- a reported figure, never a reason to lose the line
         allc = dict(value=None, error=f'{type(e).__name__}: {e}')
-    return dict(value=max(table[key][f'B={b}'] for b in (1, 16, 64)), unit='pose-iterations/s', cores=many, kind='port', all_cores=allc,
+    one = max(table[key][f'B={b}'] for b in (1, 16, 64))
+    best_all = allc.get('value') or 0.0
+    # `value` = the host's best: the pinned all-cores run when it beats one process (then `cores` = the cores it used), else one `many`-thread process
+    return dict(value=max(one, best_all), unit='pose-iterations/s', cores=allc.get('cores', many) if best_all > one else many, kind='port', all_cores=allc,
+                value_one_process=one,
                 value_1_thread=table[key]['B=16, 1 thread'], table=table, host=f'{model} ({ncpu} logical CPUs)',
                 sample=f'1 iteration of the loop at B = 1 / 16 / 64 detections, {key} crops (and the other crop size beside it), fp32, torch-CPU '
                        f'backbone + C geometry/roi_align oracle; warm-up then median of {repeats}, {many} threads (and 1 thread at B = 16); '
                        f'host rates on this pool vary by +-40 % between boxes')
+
+
+def oracle_deviation(torch, tc, pd, predictor_cls, coarse, refiner, labels, renders, crop, dtypes, n_sub=32, seed=1):
+    """Part of the cpu_baseline leg (rank 0, N = 1): the first `n_sub` detections of the benched workload (config 1's generator, the bench's own
+    coarse / refiner models and pre-generated renders), coarse 1 + refiner 4, through the HIP path in every benched storage type AND through the CPU
+    oracle (torch-CPU backbone + C geometry / roi_align, fp32) -- the refined poses after all five iterations, per parameter group.  This is the
+    bench line's own oracle comparison (round 5's `pose_deviation` compared with the fp32 HIP path only)."""
+    sys.path.insert(0, os.path.join(REPO, 'oracle'))
+    import cosy_oracle as O
+    from cosypose_amd import synthetic as syn
+    H, W = crop
+    h, w = (512, 512) if H == W else (480, 640)
+    n_obj = len(labels)
+    obj, im, boxes = syn.make_detections(seed + 10, 256, 16, n_obj, h, w)
+    obj, im, boxes = obj[:n_sub], im[:n_sub], boxes[:n_sub]
+    frames, K = syn.make_frames(seed, 16, h, w), syn.make_K(16, h, w)
+    rend_np = [r[:n_sub].cpu().numpy() for r in renders]
+    pts = syn.make_mesh_points(7, n_obj, 2500)[:, np.random.RandomState(0).choice(2500, 2000, replace=False)]
+    nthr = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(nthr); O.set_threads(nthr)
+    t0 = time.time()
+    TCO = O.tco_init_from_boxes(boxes, K[im])
+    c = O.pose_predictor_forward(frames[im], K[im], obj, TCO, pts, None, lambda n, t, k: rend_np[0], 1, (H, W),
+                                 backbone=O.TorchRef(syn.golden_state_dict(0)).net_forward)
+    r = O.pose_predictor_forward(frames[im], K[im], obj, c['iteration=1']['TCO_output'], pts, None, lambda n, t, k: rend_np[(1 + n) % len(rend_np)], 4, (H, W),
+                                 backbone=O.TorchRef(syn.golden_state_dict(1)).net_forward)
+    want = r['iteration=4']['TCO_output']
+    oracle_s = time.time() - t0
+    det = tc.PandasTensorCollection(infos=pd.DataFrame(dict(label=labels[obj], batch_im_id=im, score=1.0)), bboxes=torch.from_numpy(boxes).cuda())
+    fr, Kd = torch.from_numpy(frames).cuda(), torch.from_numpy(K).cuda()
+    out = {}
+    keep = coarse.compute_dtype
+    for dt in dtypes:
+        for m in (coarse, refiner):
+            m.compute_dtype = dt
+            m.renderer.i = 0
+        pred = predictor_cls(coarse_model=coarse, refiner_model=refiner, bsz_objects=n_sub, n_streams=1)
+        final, _ = pred.get_predictions(fr, Kd, detections=det, n_coarse_iterations=1, n_refiner_iterations=4)
+        a = final.poses.double().cpu().numpy().reshape(-1, 4, 4); b = np.asarray(want, np.float64).reshape(-1, 4, 4)
+        rot = float(np.abs(a[:, :3, :3] - b[:, :3, :3]).max())
+        tn = np.maximum(np.abs(b[:, :3, 3]).max(axis=1), 1e-12)
+        tr = float((np.abs(a[:, :3, 3] - b[:, :3, 3]).max(axis=1) / tn).max())
+        out[dt] = dict(rotation_abs=float('%.3g' % rot), translation_rel=float('%.3g' % tr), conforms=bool(max(rot, tr) <= 1e-4))
+    for m in (coarse, refiner):
+        m.compute_dtype = keep
+    return dict(per_dtype=out, bound=1e-4, candidates=n_sub, oracle_seconds=round(oracle_s, 1),
+                vs=f'CPU oracle (fp32, torch-CPU backbone + C geometry / roi_align, {nthr} threads): refined poses after coarse 1 + refiner 4 of the first '
+                   f'{n_sub} detections of this workload, worst candidate')
 
 
 def make_scene(syn, torch, tc, pd, labels, seed, D, n_frames, h, w, n_obj, with_poses=False):
@@ -462,6 +538,12 @@ def main():
                 k['ms'] += r['ms_avg'] * r['n']; k['bytes'] += r['bytes'] * r['n']; k['flops'] += r['flops'] * r['n']; k['n'] += r['n']
                 k['cbytes'] += r['cbytes'] * r['n']; k['layers'].add(r['layer'])
             return out
+        import ctypes
+        front_kind = {}
+        for i_ in range(26):
+            dims_ = (ctypes.c_int * 11)()
+            _lib.check(_lib.lib().cosy_effnet_b3_block_info(nets[0], i_, dims_))
+            front_kind[i_] = int(dims_[7])
         kinds = agg(lambda r: r['name'])
         fams = agg(lambda r: r['name'].split('<')[0].split('+')[0])
         total_ms = sum(k['ms'] for k in kinds.values())
@@ -492,7 +574,7 @@ def main():
             # weights; the depthwise output D and the other block-internal tensors count as 0) -- what `frac` would be if D never left the chip
             d['compulsory_bytes_per_launch'] = round(k['cbytes'] / k['n'])
             d['compulsory_frac'] = round(k['cbytes'] / k['ms'] / 1e6 / HBM_PEAK_GBS, 4)
-            vb = valu_bound(name, k, prof_bsz, (H, W))
+            vb = valu_bound(name, k, prof_bsz, (H, W), front_kind)
             if vb:
                 d['valu_bound'] = vb
             return d
@@ -603,6 +685,19 @@ def main():
             'cpu_baseline': None,
         }
         if world == 1 and not args.no_cpu_baseline:
+            if cfg_i == 1 and args.renderer == 'pregenerated':
+                try:      # the bench line's own comparison with the ORACLE (32-crop subset, all five iterations), every benched storage type
+                    vo = oracle_deviation(torch, tc, pd, CoarseRefinePosePredictor, coarse, refiner, labels, renders, (H, W),
+                                          [dtype] + ([d for d in ('bf16', 'fp16', 'fp32') if d != dtype] if not args.no_other_dtypes else []))
+                    if line_['pose_deviation'] is None:
+                        line_['pose_deviation'] = {}
+                    line_['pose_deviation']['vs_oracle'] = dict(vo, **vo['per_dtype'][dtype])
+                    for od, v in (line_['other_dtypes'] or {}).items():
+                        if od in vo['per_dtype']:
+                            v['pose_deviation_vs_oracle'] = vo['per_dtype'][od]
+                            v['conforms'] = bool(v.get('conforms', True) and vo['per_dtype'][od]['conforms']) if od != 'fp32' else vo['per_dtype'][od]['conforms']
+                except Exception as e:      # noqa: BLE001 -- reported beside the line, never a reason to lose it
+                    line_.setdefault('notes', []).append(f'oracle deviation leg failed: {type(e).__name__}: {e}')
             line_['cpu_baseline'] = cpu_baseline((H, W))
         print(json.dumps(line_), flush=True)
     if world > 1:

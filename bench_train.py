@@ -155,7 +155,7 @@ def main():
     data = types.SimpleNamespace(images=pin(torch.from_numpy(frames)), K=pin(torch.from_numpy(K)), TCO=pin(torch.from_numpy(TCO)),
                                  objects=[dict(name=l) for l in labels[obj]], bboxes=pin(bboxes.cpu()))
     cfg = argparse.Namespace(n_points_loss=2600, loss_disentangled=True, n_pose_dims=9, init_method='v0')
-    opt = train_engine.FlatAdam(model, lr=3e-4, clip_grad_norm=0.5)
+    opt = train_engine.FlatAdam(model, lr=3e-4, clip_grad_norm=0.5, overlap_allreduce=None)     # None: buckets from inside the backward when there is more than one rank
     meters = LazyMeters()          # as train_loop: the loss values are read back without stopping the host (no .item() in the middle of the step)
     ev = lambda: torch.cuda.Event(enable_timing=True)
     split = defaultdict(float)

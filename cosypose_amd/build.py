@@ -155,13 +155,22 @@ def kernel_resources(demangle=True):
     return out
 
 
-def _wave_src_sha():
+def _csrc_sha():
+    """Hash of EVERY source the library is built from (all of csrc/, the public header, the compile flags): the stamp binds the linked
+    library to these, so a .so older than an edited kernels_smx.hip / kernels_stem.hip / ... can never load (round 5's stamp covered
+    kernels_wave.hip and its headers only; the other hand-scheduled files were guarded by mtimes alone)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ['kernels_wave.hip', 'wave_fence.inc', 'net_device.h', 'kernels_net.h', 'cosy_common.h']:
-        h.update(open(os.path.join(CSRC, f), 'rb').read())
-    h.update(' '.join(FLAGS + FILE_FLAGS.get('kernels_wave.hip', [])).encode())
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith(('.hip', '.h', '.inc')):
+            h.update(f.encode())
+            h.update(open(os.path.join(CSRC, f), 'rb').read())
+    h.update(open(os.path.join(HERE, '..', 'include', 'cosyhip.h'), 'rb').read())
+    h.update(' '.join(FLAGS + [f'{k}:{" ".join(v)}' for k, v in sorted(FILE_FLAGS.items())]).encode())
     return h.hexdigest()[:16]
+
+
+_wave_src_sha = _csrc_sha      # (old name, kept for the scripts under profiles/)
 
 
 def read_stamp():
@@ -178,7 +187,7 @@ def stamp_matches(lib_path=None):
     lib_path = lib_path or LIB
     if not st or not st.get('clean') or not os.path.exists(lib_path) or st.get('lib_sha') != _sha16(lib_path):
         return False
-    return not os.path.exists(os.path.join(CSRC, 'kernels_wave.hip')) or st.get('src_sha') == _wave_src_sha()
+    return not os.path.exists(os.path.join(CSRC, 'kernels_wave.hip')) or st.get('src_sha') == _csrc_sha()
 
 
 def check_wave_isa(verbose=False):
@@ -196,7 +205,7 @@ def check_wave_isa(verbose=False):
         print('\n'.join(log)[-3000:], flush=True)
     ver = subprocess.run([HIPCC, '--version'], capture_output=True, text=True).stdout.strip().split('\n')
     clean = not problems
-    json.dump(dict(clean=clean, src_sha=_wave_src_sha(), lib_sha=_sha16(LIB), kernels=n, hipcc=[l for l in ver if l][:2],
+    json.dump(dict(clean=clean, src_sha=_csrc_sha(), lib_sha=_sha16(LIB), kernels=n, hipcc=[l for l in ver if l][:2],
                    checked='device assembly of the compile that produced kernels_wave.o (-save-temps=obj)', summary=log[-1] if clean else problems[0]),
               open(ISA_STAMP, 'w'), indent=1)
     if not clean:

@@ -123,7 +123,11 @@ namespace cosy {
 // simple bump allocator over one hipMalloc'd slab
 struct Bump {
     char* base = nullptr; size_t off = 0;
+    // host mirror of the weight slab (fill pass): every packed tensor is staged at its device offset and the slab goes up in ONE hipMemcpy at the
+    // end of cosy_effnet_b3_create (round 5's profile: ~300 small blocking copies per engine, 19 % of the traced kernel time of a cold start)
+    std::vector<char>* mirror = nullptr;
     void* take(size_t bytes) { off = (off + 255) & ~(size_t)255; void* p = base ? base + off : nullptr; off += bytes; return p; }
+    void stage(void* dev, const void* src, size_t bytes) { memcpy(mirror->data() + ((char*)dev - base), src, bytes); }
 };
 
 static void fold_bn(const float* bn, int C, int Cpad, std::vector<float>& scale, std::vector<float>& bias) {
@@ -141,7 +145,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
     const float* p0 = p;
     auto up_f32 = [&](const std::vector<float>& v) -> float* {
         float* d = (float*)bump.take(v.size() * sizeof(float));
-        if (fill) { hipError_t e = hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice); if (e != hipSuccess) *herr = e; }
+        if (fill) bump.stage(d, v.data(), v.size() * sizeof(float));
         return d;
     };
     auto mk_pw = [&](PwLayer& L, const float* w, int K, int N, const float* bn, int HW, bool gated) {
@@ -153,8 +157,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         if (fill) {
             std::vector<char> tmp(ne * n->esz);
             pw_pack_weights(w, K, N, L.cfg, n->dtype, tmp.data());
-            hipError_t e = hipMemcpy(L.Wp, tmp.data(), tmp.size(), hipMemcpyHostToDevice);
-            if (e != hipSuccess) *herr = e;
+            bump.stage(L.Wp, tmp.data(), tmp.size());
             fold_bn(bn, N, npad, sc, bi);
         } else { sc.assign(npad, 0.f); bi.assign(npad, 0.f); }
         L.scale = up_f32(sc); L.bias = up_f32(bi);
@@ -169,8 +172,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         if (fill) {
             std::vector<char> tmp(ne * n->esz);
             stem_pack_weights(p, n->dtype, tmp.data());
-            hipError_t e2 = hipMemcpy(n->stem_w, tmp.data(), tmp.size(), hipMemcpyHostToDevice);
-            if (e2 != hipSuccess) *herr = e2;
+            bump.stage(n->stem_w, tmp.data(), tmp.size());
         }
         p += STEM_C * IN_C * 9;
         if (fill) fold_bn(p, STEM_C, STEM_C, sc, bi); else { sc.assign(STEM_C, 0.f); bi.assign(STEM_C, 0.f); }
@@ -221,8 +223,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
                     }
                     std::vector<char> tmp(ne * n->esz);
                     pw_pack_weights(ws.data(), b.d.cin, b.cmid, c48, n->dtype, tmp.data());
-                    hipError_t e2 = hipMemcpy(b.exp_wp_fused, tmp.data(), tmp.size(), hipMemcpyHostToDevice);
-                    if (e2 != hipSuccess) *herr = e2;
+                    bump.stage(b.exp_wp_fused, tmp.data(), tmp.size());
                 }
                 b.b0_fold = up_f32(b0f);
                 if (b.wave) { if (fill) fold_bn(p + (size_t)b.cmid * b.d.cin, b.cmid, b.cmid, exp_sc, exp_bi); else { exp_sc.assign(b.cmid, 0.f); exp_bi.assign(b.cmid, 0.f); } }
@@ -246,8 +247,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
                 if (fill) {
                     std::vector<char> tmp(stem_front_weight_elems() * n->esz);
                     stem_front_pack_weights(stem_w_host, n->dtype, tmp.data());
-                    hipError_t e2 = hipMemcpy(n->stemf_w, tmp.data(), tmp.size(), hipMemcpyHostToDevice);
-                    if (e2 != hipSuccess) *herr = e2;
+                    bump.stage(n->stemf_w, tmp.data(), tmp.size());
                     stem_front_pack_params(stem_sc_host.data(), stem_bi_host.data(), w.data(), sc.data(), bi.data(), sp.data());
                 }
                 n->stemf_params = up_f32(sp);
@@ -269,7 +269,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
                     small_mx_pack_params(b0l.data(), w.data(), sc.data(), bi.data(), b.cmid, b.d.k, n->dtype, sp.data());
                 }
                 b.wave_params = (float*)bump.take(sp.size());
-                if (fill) { hipError_t e2 = hipMemcpy(b.wave_params, sp.data(), sp.size(), hipMemcpyHostToDevice); if (e2 != hipSuccess) *herr = e2; }
+                if (fill) bump.stage(b.wave_params, sp.data(), sp.size());
             }
             b.dw_w_fold = nullptr;
             if (b.small && !b.smx) {
@@ -648,7 +648,11 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
         // the largest prologue): fused or not makes no measurable difference (round 5, alternating same-call A/B: backbone 4.551 vs 4.553 ms,
         // profiles/r05_se_fused_ab.txt; round 4's two records disagreed) -> they keep the batched kernels.
         n->se_fuse_mask = (unsigned)tune_int("COSY_SE_FUSE_MASK", 0x3fe0);
-        n->stem_fused = n->fuse && stem_front_supported(dtype, H, W);
+        // the fused stem front reaches the zero page (directly behind X, layout_workspace) by a 32-bit offset from the chunk's X pointer
+        // (launch_stem_front requires it below 2^32 - 2^24): an engine whose input buffer is larger than that (> 2047 crops of 256x256 in a
+        // 16-bit type) keeps the unfused stem + block 0, which has no such limit, instead of failing every forward
+        n->stem_fused = n->fuse && stem_front_supported(dtype, H, W) &&
+                        (size_t)max_batch * H * W * 8 * n->esz + 256 < ((size_t)1 << 32) - ((size_t)1 << 24);
         n->stemf_w = nullptr; n->stemf_params = nullptr;
         n->small_mask = (unsigned)tune_int("COSY_SMALL_MASK", 0x3f80000);
         n->tile_mask = (unsigned)tune_int("COSY_TILE_MASK", 0x13c);         // blocks 2-5 and 8 (measured in round 1: it loses on the k=5 stride-1 blocks 6/7)   // blocks 19-25 (8x8 / 7x10 maps): whole-image kernel
@@ -670,7 +674,13 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
         return COSY_ENOMEM;
     }
     wb.base = (char*)n->wbase; wb.off = 0;
-    build_weights(n, host_params, wb, true, &herr);
+    {
+        std::vector<char> mirror(n->wbytes, 0);
+        wb.mirror = &mirror;
+        build_weights(n, host_params, wb, true, &herr);
+        if (herr == hipSuccess) herr = hipMemcpy(n->wbase, mirror.data(), wb.off, hipMemcpyHostToDevice);      // the whole weight slab, one copy
+        wb.mirror = nullptr;
+    }
     ab.base = (char*)n->abase; ab.off = 0;
     layout_workspace(n, ab);
     if (herr == hipSuccess) herr = hipMemset(n->abase, 0, n->abytes);

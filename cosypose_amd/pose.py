@@ -15,7 +15,7 @@ from torch import nn
 
 from . import lib3d, arch, train_engine
 from ._lib import lib, check, ptr, stream, require_device, ints_to_device, CosyHipError, COSY_F32
-from .efficientnet import EnginePool
+from .efficientnet import EnginePool, packed_cuda
 
 
 class PosePredictor(nn.Module):
@@ -48,8 +48,10 @@ class PosePredictor(nn.Module):
         return state
 
     def __setstate__(self, state):
-        self.__dict__.update(state)
+        super().__setstate__(state)        # torch's back-compat defaults for older pickles (hook dicts), then the state itself
         self.__dict__['_engines'] = EnginePool(self.backbone, self.pose_fc)
+
+    cuda = packed_cuda      # one packed host -> device copy per dtype (efficientnet.packed_cuda)
 
     def enable_debug(self):
         self.debug = True

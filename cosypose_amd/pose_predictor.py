@@ -28,7 +28,9 @@ _ITERATION_FIELDS = (('poses', 'TCO_output'), ('poses_input', 'TCO_input'), ('K_
 _ITERATION_SHAPES = (('poses', (4, 4)), ('poses_input', (4, 4)), ('K_crop', (3, 3)), ('boxes_rend', (4,)), ('boxes_crop', (4,)))
 
 
-_ACCEPTS = {}       # (forward function, keyword) -> bool, see CoarseRefinePosePredictor._accepts
+import weakref
+
+_ACCEPTS = weakref.WeakKeyDictionary()       # forward function -> {keyword: bool}, see CoarseRefinePosePredictor._accepts (weak: closures / instance-level forwards die with their owners)
 
 
 def _iteration_key(n):
@@ -64,15 +66,19 @@ class CoarseRefinePosePredictor(torch.nn.Module):
         fwd = getattr(model, 'forward', None)
         if fwd is None:
             return False
-        key = (getattr(fwd, '__func__', fwd), name)          # per forward FUNCTION: get_predictions asks on every call
-        hit = _ACCEPTS.get(key)
+        fn = getattr(fwd, '__func__', fwd)                   # per forward FUNCTION: get_predictions asks on every call
+        try:
+            table = _ACCEPTS.setdefault(fn, {})
+        except TypeError:                                    # not weak-referenceable (a builtin / C callable): not cached
+            table = {}
+        hit = table.get(name)
         if hit is None:
             try:
                 params = inspect.signature(fwd).parameters
                 hit = name in params or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
             except (TypeError, ValueError):
                 hit = False
-            _ACCEPTS[key] = hit
+            table[name] = hit
         return hit
 
     @staticmethod

@@ -560,7 +560,7 @@ class FlatAdam:
     ONE flat fp32 buffer.  Construction re-homes the parameters (and their .grad) as views of flat buffers, in
     named_parameters() order; the module keeps working as before."""
 
-    def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_grad_norm=0.5, direct_grads=True, overlap_allreduce=None,
+    def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_grad_norm=0.5, direct_grads=True, overlap_allreduce=False,
                  bucket_bytes=8 << 20):
         params = [p for p in model.parameters()]
         dev = params[0].device
@@ -582,14 +582,16 @@ class FlatAdam:
         # wrapper -- its reducer hangs on the per-parameter hooks that never fire then; average with allreduce_gradients(opt) instead
         # (or pass direct_grads=False).
         self.direct_grads = bool(direct_grads)
-        # overlap_allreduce (None = automatic: on when a process group with more than one rank exists): the backward launches the gradient
+        # overlap_allreduce (default False: a backward issues NO collective unless asked -- a process group that exists for sharded inference, a
+        # rank-local gradient check or an uneven number of backwards per rank would otherwise hang on an implicit one; train_loop / bench_train.py
+        # turn it on for their data-parallel steps; None = automatic: on when a group with more than one rank exists): the backward launches the gradient
         # all-reduce itself, bucket by bucket (>= bucket_bytes of finished gradients each: head + late blocks first), beside the rest of the
         # backward; the staged gradients are averaged before they are accumulated, `reduced` tells train_loop / allreduce_gradients that this
         # backward's gradients are already averaged.  Buckets are slices of ONE buffer: elementwise sums, so the result equals the single
         # all-reduce bit for bit at 2 ranks (any order of two addends) and up to the collective's own chunking beyond.
         self.overlap_allreduce = overlap_allreduce
         self.bucket_bytes = int(bucket_bytes)
-        self.reduced = False
+        self.n_backward = self.n_reduced = 0      # direct-path backwards since zero_grad, and how many of them averaged their own gradients
         self._pending, self._hi = [], n
         self.gstage = torch.zeros(n, device=dev)
         self.stage, off = {}, 0
@@ -639,7 +641,7 @@ class FlatAdam:
             work.wait()
         self._pending = []
         self.gstage.div_(dist.get_world_size())
-        self.reduced = True
+        self.n_reduced += 1
 
     def owns(self, params):
         """the given parameters are exactly this optimizer's, still living in its flat buffer"""
@@ -657,10 +659,16 @@ class FlatAdam:
         that were given a foreign .grad tensor are copied in first, exactly as step() treats them."""
         self._collect_stray_gradients()
         self.grad.add_(self.gstage)
+        self.n_backward += 1
+
+    @property
+    def reduced(self):
+        """every backward accumulated since zero_grad averaged its own gradients over the ranks (overlap_allreduce)"""
+        return self.n_backward > 0 and self.n_reduced == self.n_backward
 
     def zero_grad(self):
         self.grad.zero_()
-        self.reduced = False
+        self.n_backward = self.n_reduced = 0
         off = 0
         for p in self.params:       # re-attach views in case something set .grad to None
             if p.grad is None:
@@ -704,8 +712,11 @@ def allreduce_gradients(flat_grad, force=False):
     what is reduced is what the step will use).  force=True runs the collective in a 1-rank group too (RCCL smoke test)."""
     import torch.distributed as dist
     if isinstance(flat_grad, FlatAdam):
-        if flat_grad.reduced and not force:       # the backward launched its own bucketed all-reduce (FlatAdam.overlap_allreduce): already averaged
+        if flat_grad.reduced and not force:       # EVERY backward since zero_grad launched its own bucketed all-reduce (FlatAdam.overlap_allreduce): already averaged
             return flat_grad.grad
+        if flat_grad.n_reduced and not force:
+            raise RuntimeError(f'allreduce_gradients: {flat_grad.n_reduced} of the {flat_grad.n_backward} backwards accumulated since zero_grad averaged their own '
+                               'gradients (overlap_allreduce) and the others did not: the buffer mixes averaged and local gradients')
         flat_grad._collect_stray_gradients()
         flat_grad = flat_grad.grad
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):

@@ -138,6 +138,11 @@ class DevicePrefetcher:
 
     def __iter__(self):
         source = iter(self.batches)
+        # a re-iteration (train_loop keeps ONE prefetcher across epochs) must not inherit the previous pass's slot events: the last step of that pass may
+        # still be reading either slot, so both are gated on everything the consumer has enqueued up to now
+        start = torch.cuda.Event()
+        start.record(torch.cuda.current_stream(self.device))
+        self._free = [start, start]
         try:
             ahead = self._upload(next(source), 0)
         except StopIteration:
@@ -236,7 +241,8 @@ def train_loop(model, mesh_db, cfg, batches, n_epochs, save_dir=None, start_epoc
         # direct_grads (the backward writes straight into FlatAdam's flat buffer and returns None per parameter) must be OFF under a
         # DistributedDataParallel wrapper: DDP averages through per-parameter autograd hooks, which would never fire
         optimizer = train_engine.FlatAdam(model.module if is_ddp else model, lr=cfg.lr, weight_decay=getattr(cfg, 'weight_decay', 0.0),
-                                          clip_grad_norm=cfg.clip_grad_norm, direct_grads=not is_ddp)
+                                          clip_grad_norm=cfg.clip_grad_norm, direct_grads=not is_ddp,
+                                          overlap_allreduce=world > 1 and not is_ddp)      # the data-parallel step: buckets launched from inside the backward
     flat = isinstance(optimizer, train_engine.FlatAdam)
     if flat and is_ddp and optimizer.direct_grads:
         raise ValueError('train_loop: a FlatAdam with direct_grads=True under DistributedDataParallel would skip DDP\'s gradient hooks (the ranks '
