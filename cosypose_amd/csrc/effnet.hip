@@ -649,8 +649,8 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
         // profiles/r05_se_fused_ab.txt; round 4's two records disagreed) -> they keep the batched kernels.
         n->se_fuse_mask = (unsigned)tune_int("COSY_SE_FUSE_MASK", 0x3fe0);
         // the fused stem front reaches the zero page (directly behind X, layout_workspace) by a 32-bit offset from the chunk's X pointer
-        // (launch_stem_front requires it below 2^32 - 2^24): an engine whose input buffer is larger than that (> 2047 crops of 256x256 in a
-        // 16-bit type) keeps the unfused stem + block 0, which has no such limit, instead of failing every forward
+        // (launch_stem_front requires it below 2^32 - 2^24): an engine whose input buffer is larger than that (>= 4080 crops of 256x256 in a
+        // 16-bit type, i.e. a capacity of 4096) keeps the unfused stem + block 0, which has no such limit, instead of failing every forward
         n->stem_fused = n->fuse && stem_front_supported(dtype, H, W) &&
                         (size_t)max_batch * H * W * 8 * n->esz + 256 < ((size_t)1 << 32) - ((size_t)1 << 24);
         n->stemf_w = nullptr; n->stemf_params = nullptr;

@@ -81,6 +81,26 @@ template <bool SCALED> __device__ __forceinline__ void silu4(float* v) {
             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3));
     }
 }
+// the same block WITHOUT volatile (a pure function of its operands): the software-pipelined rows let hipcc place it between the ordered fragment MFMAs
+template <bool SCALED> __device__ __forceinline__ void silu4p(float* v) {
+    float t0, t1, t2, t3;
+    if constexpr (SCALED) {
+        asm(
+            "v_exp_f32 %4, -%0\n v_exp_f32 %5, -%1\n v_exp_f32 %6, -%2\n v_exp_f32 %7, -%3\n"
+            "v_add_f32 %4, 1.0, %4\n v_add_f32 %5, 1.0, %5\n v_add_f32 %6, 1.0, %6\n v_add_f32 %7, 1.0, %7\n"
+            "v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
+            "v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %5\n v_mul_f32 %2, %2, %6\n v_mul_f32 %3, %3, %7\n s_nop 0"
+            : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3));
+    } else {
+        asm(
+            "v_mul_f32 %4, 0xbfb8aa3b, %0\n v_mul_f32 %5, 0xbfb8aa3b, %1\n v_mul_f32 %6, 0xbfb8aa3b, %2\n v_mul_f32 %7, 0xbfb8aa3b, %3\n"
+            "v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n"
+            "v_add_f32 %4, 1.0, %4\n v_add_f32 %5, 1.0, %5\n v_add_f32 %6, 1.0, %6\n v_add_f32 %7, 1.0, %7\n"
+            "v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
+            "v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %5\n v_mul_f32 %2, %2, %6\n v_mul_f32 %3, %3, %7\n s_nop 0"
+            : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3));
+    }
+}
 
 
 // Input fragment i of the wave kernel is loaded into a RESERVED register quad at the top of the kernel's VGPR budget,
@@ -107,6 +127,9 @@ template <int TOP, int I> __device__ __forceinline__ f32x4 xfrag_read() {
 // (hipcc's own code puts s_nop 7 there; two more for margin).  fp32 (parity mode) keeps the copies: its 16x16x4 MFMAs take single registers.
 #ifndef COSY_WAVE_XASM
 #define COSY_WAVE_XASM 1
+#endif
+#ifndef COSY_WAVE_PIPE
+#define COSY_WAVE_PIPE 1
 #endif
 template <typename T, int TOP, int I, bool FIRST, bool XA, typename W> __device__ __forceinline__ void xfrag_mma(f32x4& m, const W& w) {
     constexpr int lo = TOP - 4 * (I + 1), hi = TOP - 4 * I - 1;
@@ -173,6 +196,98 @@ __device__ __forceinline__ f32x4 mma16(bf16x4 a, bf16x4 b, f32x4 c) {
 }
 __device__ __forceinline__ f32x4 mma4(f32x4, f32x4, f32x4 c) { return c; }      // never instantiated for fp32 (wave_mx), only parsed
 __device__ __forceinline__ f32x4 mma16(f32x4, f32x4, f32x4 c) { return c; }
+
+
+// ---- the fused interior row of the matrix-pipe form (round 6): every instruction of the row is issued from `asm volatile` statements in ONE hand-chosen order
+// (volatile statements keep their program order; hipcc only allocates the registers and resolves the sub-registers of the accumulator tuples), so nothing of the row
+// is left to hipcc's scheduler: it kept the two dependent chains of a software-pipelined row apart (profiles/r05_wave_occupancy.txt).  Wait states and counted waits
+// are written out by hand (hipcc pads nothing inside or between asm statements): see the hazard notes at row_px below.
+template <typename T> struct PxT;
+template <> struct PxT<f16_t> { static constexpr bool F16 = true; };
+template <> struct PxT<bf16_t> { static constexpr bool F16 = false; };
+template <> struct PxT<float> { static constexpr bool F16 = false; };
+template <typename T, typename V4> __device__ __forceinline__ void px_tap(f32x4& acc, const V4& A, const V4& W) {     // acc += A * W (16 channel blocks of 4x4x4)
+    if constexpr (PxT<T>::F16) asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %0 ; PX" : "+v"(acc) : "v"(A), "v"(W));
+    else asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0 ; PX" : "+v"(acc) : "v"(A), "v"(W));
+}
+template <typename T, typename V4> __device__ __forceinline__ void px_tap0(f32x4& acc, const V4& A, const V4& W) {    // acc = A * W: the first tap row of a new output row
+    if constexpr (PxT<T>::F16) asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, 0 ; PX" : "=&v"(acc) : "v"(A), "v"(W));
+    else asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, 0 ; PX" : "=&v"(acc) : "v"(A), "v"(W));
+}
+// expansion MFMA on the reserved fragment quad I (pixels as the MFMA's rows), no wait states of its own
+template <typename T, int TOP, int I, bool FIRST, typename W> __device__ __forceinline__ void px_mma(f32x4& m, const W& w) {
+    constexpr int lo = TOP - 4 * (I + 1), hi = TOP - 4 * I - 1;
+    if constexpr (PxT<T>::F16) {
+        if constexpr (FIRST) asm volatile("v_mfma_f32_16x16x32_f16 %0, v[%2:%3], %1, 0 ; XMMA" : "=&v"(m) : "v"(w), "n"(lo), "n"(hi));
+        else asm volatile("v_mfma_f32_16x16x32_f16 %0, v[%2:%3], %1, %0 ; XMMA" : "+v"(m) : "v"(w), "n"(lo), "n"(hi));
+    } else {
+        if constexpr (FIRST) asm volatile("v_mfma_f32_16x16x32_bf16 %0, v[%2:%3], %1, 0 ; XMMA" : "=&v"(m) : "v"(w), "n"(lo), "n"(hi));
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, v[%2:%3], %1, %0 ; XMMA" : "+v"(m) : "v"(w), "n"(lo), "n"(hi));
+    }
+}
+template <int OFF, typename R> __device__ __forceinline__ void px_wread(R& w, unsigned addr) {      // parked weight fragment -> registers (in flight behind the statement)
+    asm volatile("ds_read_b128 %0, %1 offset:%2 ; PX" : "=v"(w) : "v"(addr), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void px_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0) ; PX" :: "n"(N)); }
+template <int N> __device__ __forceinline__ void px_nop() { asm volatile("s_nop %0 ; PX" :: "n"(N)); }
+// y[e] = s * m[e] + b   (the BatchNorm of an MFMA result: reads the tuple's sub-registers)
+__device__ __forceinline__ void px_bn(float* y, const f32x4& m, float s, float b) {
+    asm volatile("v_fma_f32 %0, %8, %4, %9\n v_fma_f32 %1, %8, %5, %9\n v_fma_f32 %2, %8, %6, %9\n v_fma_f32 %3, %8, %7, %9 ; PX"
+                 : "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]) : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(s), "v"(b));
+}
+// SiLU in five statements (the arithmetic of silu4<false>, value for value): t = -log2(e) * y | t = 2^t | t = 1 + t | t = 1 / t | y = y * t
+__device__ __forceinline__ void px_silu_a(const float* y, float* t) {
+    asm volatile("v_mul_f32 %0, 0xbfb8aa3b, %4\n v_mul_f32 %1, 0xbfb8aa3b, %5\n v_mul_f32 %2, 0xbfb8aa3b, %6\n v_mul_f32 %3, 0xbfb8aa3b, %7 ; PX"
+                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]));
+}
+__device__ __forceinline__ void px_silu_b(float* t) {
+    asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3 ; PX" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+}
+__device__ __forceinline__ void px_silu_c(float* t) {
+    asm volatile("v_add_f32 %0, 1.0, %0\n v_add_f32 %1, 1.0, %1\n v_add_f32 %2, 1.0, %2\n v_add_f32 %3, 1.0, %3 ; PX" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+}
+__device__ __forceinline__ void px_silu_d(float* t) {
+    asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3 ; PX" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+}
+__device__ __forceinline__ void px_silu_e(float* y, const float* t) {
+    asm volatile("v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %5\n v_mul_f32 %2, %2, %6\n v_mul_f32 %3, %3, %7 ; PX"
+                 : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]) : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]));
+}
+__device__ __forceinline__ void px_sum(float& s, const float* y) {      // ((((s + y0) + y1) + y2) + y3): the order of the unfused form
+    asm volatile("v_add_f32 %0, %1, %0\n v_add_f32 %0, %2, %0\n v_add_f32 %0, %3, %0\n v_add_f32 %0, %4, %0 ; PX" : "+v"(s) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]));
+}
+// round four values to the storage type: (y0, y1) -> lo, (y2, y3) -> hi; fp16 saturates (v_med3 against +-65504, as cvt())
+template <typename T> __device__ __forceinline__ void px_cvt(int& lo, int& hi, float* y, float nclamp, float pclamp) {
+    if constexpr (PxT<T>::F16)
+        asm volatile("v_med3_f32 %2, %2, %6, %7\n v_med3_f32 %3, %3, %6, %7\n v_med3_f32 %4, %4, %6, %7\n v_med3_f32 %5, %5, %6, %7\n"
+                     "v_cvt_pk_f16_f32 %1, %4, %5\n v_cvt_pk_f16_f32 %0, %2, %3 ; PX"
+                     : "=&v"(lo), "=&v"(hi), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]) : "s"(nclamp), "v"(pclamp));
+    else
+        asm volatile("v_cvt_pk_bf16_f32 %1, %4, %5\n v_cvt_pk_bf16_f32 %0, %2, %3 ; PX" : "=&v"(lo), "=&v"(hi) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]));
+}
+__device__ __forceinline__ void px_bperm2(int& lo, int& hi, int addr, int a, int b) {      // both results in flight behind the statement
+    asm volatile("ds_bpermute_b32 %0, %2, %3\n ds_bpermute_b32 %1, %2, %4 ; PX" : "=&v"(lo), "=&v"(hi) : "v"(addr), "v"(a), "v"(b));
+}
+// the halo operand of a 16-pixel row's tap MFMAs: (previous quad's pixels 2, 3 | next quad's pixels 0, 1), zero at the row ends
+__device__ __forceinline__ void px_halo(int& hp, int& ln, int lo, int hi, unsigned long long first_quad, unsigned long long last_quad) {
+    asm volatile("v_mov_b32_dpp %0, %3 quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 quad_perm:[1,2,3,3] row_mask:0xf bank_mask:0xf\n"
+                 "v_cndmask_b32_e64 %0, %0, 0, %4\n v_cndmask_b32_e64 %1, %1, 0, %5 ; PX"
+                 : "=&v"(hp), "=&v"(ln) : "v"(lo), "v"(hi), "s"(first_quad), "s"(last_quad));
+}
+template <typename T, typename V4> __device__ __forceinline__ void px_transpose(f32x4& tr, const V4& a, const V4& ident) {
+    if constexpr (PxT<T>::F16) asm volatile("v_mfma_f32_16x16x16_f16 %0, %1, %2, 0 ; PX" : "=&v"(tr) : "v"(a), "v"(ident));
+    else asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, 0 ; PX" : "=&v"(tr) : "v"(a), "v"(ident));
+}
+template <typename T> __device__ __forceinline__ void px_cvt_store(const f32x4& tr, unsigned voff, const void* srow) {      // exact values: plain converts, 8-byte store
+    int o0, o1;
+    if constexpr (PxT<T>::F16)
+        asm volatile("v_cvt_pk_f16_f32 %0, %2, %3\n v_cvt_pk_f16_f32 %1, %4, %5\n" : "=&v"(o0), "=&v"(o1) : "v"(tr[0]), "v"(tr[1]), "v"(tr[2]), "v"(tr[3]));
+    else
+        asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n v_cvt_pk_bf16_f32 %1, %4, %5\n" : "=&v"(o0), "=&v"(o1) : "v"(tr[0]), "v"(tr[1]), "v"(tr[2]), "v"(tr[3]));
+    typedef int i2_t __attribute__((ext_vector_type(2)));
+    const i2_t d = i2_t{o0, o1};
+    asm volatile("global_store_dwordx2 %0, %1, %2 ; PX" :: "v"(voff), "v"(d), "s"(srow) : "memory");
+}
 
 template <typename F, int... Us>
 __device__ __forceinline__ void unroll_seq(F&& f, std::integer_sequence<int, Us...>) { (f(std::integral_constant<int, Us>{}), ...); }
@@ -274,6 +389,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     static_assert(MINW >= 2 && MINW <= 5);
     xfrag_reserve<MINW>();
     constexpr bool XASM = COSY_WAVE_XASM && sizeof(T) == 2;   // the MFMAs read the fragments in place (xfrag_mma)
+    constexpr bool PIPE = COSY_WAVE_PIPE && MX && XASM && PPL == 1;       // matrix-pipe form: row iy's expansion side and row iy - 1's tap / output side in one iteration (row_mx)
     raw_t wf[NI][KBN];                       // the chunk's expand-weight fragments (WLDS: parked in LDS instead)
     f32x4 xc[XASM ? 1 : PPL][XASM ? 1 : KBN];
     int st_in_flight = 0;                    // stores issued behind the newest loads (wave-uniform)
@@ -388,6 +504,10 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
         for (int q = 0; q < PPL; ++q) accx[s][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int bp_in = ((lane >> 2) + 16 * (lane & 3)) * 4, bp_out = (4 * (lane & 15) + (lane >> 4)) * 4;
     const int jq = lane & 3;
+    // fused interior iteration (row_px): lane masks of a row's first / last quad, the parked weight fragments' LDS address, the output row's store as
+    // (uniform row pointer, per-lane byte offset)
+    const unsigned long long first_quad = __builtin_amdgcn_ballot_w64(jq == 0), last_quad = __builtin_amdgcn_ballot_w64(jq == 3);
+    const unsigned wl_addr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)(Wl + lane * 16);
     t4 ident;
 #pragma unroll
     for (int e = 0; e < 4; ++e) ident[e] = (T)(4 * kg + e == p ? 1.f : 0.f);
@@ -404,6 +524,8 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     static_assert(NI == 1, "chunked D: one 16-channel chunk per job");
     T* __restrict__ Dlane = (T*)a.D + (size_t)(b * a.nchunks + ch) * a.Ho * a.Wo * 16 + (size_t)(MX ? p : p * TO) * a.ds_pix + kg * 4;   // + uniform row offset (MX: element t of a row = segment t)
     const size_t drow = (size_t)a.ds_row;
+    const T* D_chunk = (const T*)a.D + (size_t)(b * a.nchunks + ch) * a.Ho * a.Wo * 16;
+    const unsigned d_voff = (unsigned)(((size_t)(MX ? p : p * TO) * a.ds_pix + kg * 4) * sizeof(T));
     const int dpix = MX ? 16 * a.ds_pix : a.ds_pix;
     auto flush = [&]() {                     // store the pending output row
         if (oy_pending >= 0 && !COSY_DBG(a.dbg & 1)) {      // dbg 1: no output stores (timing experiments)
@@ -626,6 +748,225 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
                 if constexpr (MX) { flush(); oy_pending = -1; }
             }
     };
+    // ---- matrix-pipe form of the 16-pixel-row shapes (PPL = 1: blocks 9-17 at 256x256), SOFTWARE-PIPELINED over the rows (round 6).  A wave's row is a chain of
+    // dependent steps -- wait, expansion MFMAs, BN, SiLU, convert, lane permutation, tap MFMAs, BN, SiLU, convert, permutation, transposition, store: 1300-1600 cycles
+    // for ~130 instructions when a wave has its SIMD to itself (profiles/r05_wave_occupancy.txt).  One ITERATION here does the tap / output side of row iy - 1
+    // (operands W1p / W2p kept from the previous iteration) and the expansion side of row iy: two independent chains.  row_mx is the plain form of an iteration
+    // (hipcc's schedule; rows at the job's and the map's edges: every part behind a wave-uniform condition); row_px below is the interior form, every instruction
+    // of it placed by hand.  Measured (profiles/r06_wave_rows.txt): row to row alone on a SIMD 1581 -> 1102 cycles (blocks 14-17) / 1333 -> 1004 (block 13), at four
+    // waves per SIMD 2323 -> 1931; results bit-identical to the unpipelined form (profiles/exp/ab_bits.py).
+    t4 W1p[PIPE ? PPL : 1], W2p[PIPE ? PPL : 1];
+    bool prev_fused = false;      // the previous iteration was the fused form (row_px)
+    auto row_mx = [&](auto uc, auto inc, const int base) {
+        if constexpr (PIPE) {
+            constexpr int u = decltype(uc)::value, up = (u + U - 1) % U;      // accumulator-slot arithmetic of row iy - 1
+            constexpr bool IN = decltype(inc)::value;
+            const int iy = base + u, ip = iy - 1;
+            const bool doA = IN || (iy >= iy_first && iy <= iy_last), doB = IN || (ip >= iy_first && ip <= iy_last);
+            if constexpr (!IN) { if (!doA && !doB) return; }
+            t4 W1n[PPL], W2n[PPL];
+            if constexpr (!IN) {
+                // behind a fused iteration (row_px, which starts a new output row with SrcC = 0 and never resets): the accumulator slot this iteration's first tap row
+                // adds into still holds the output row the fused iteration finished
+                if (prev_fused) { constexpr int os0 = ((up + LO) % NOPEN + NOPEN) % NOPEN; accx[os0][0] = f32x4{0.f, 0.f, 0.f, 0.f}; prev_fused = false; }
+            }
+            // ---- A1: row iy's expansion chain issued, the next row's loads behind it
+            f32x4 mq[PPL];
+            if (doA) {
+                WAVE_STAMP_ROW();
+                wait_row(mq);
+                if ((IN || iy + 1 <= iy_last) && !COSY_DBG(a.dbg & 2)) load_row(iy + 1);
+            }
+            // ---- B: row iy - 1 scattered into the output rows it feeds, the finished output row stored
+            if (doB) {
+                bool done = false;
+                int oy_done = -1;
+                out_t ynew[TO][NI];
+#pragma unroll
+                for (int ky = 0; ky < KS; ++ky) {
+                    constexpr int os_dummy = 0; (void)os_dummy;
+                    const int os = ((up + LO - ky) % NOPEN + NOPEN) % NOPEN;     // compile-time after unrolling (S = 1)
+                    const int oy = ip + LO - ky;
+                    if constexpr (!IN) { if (oy < 0 || oy < oy_a || oy >= oy_b) continue; }
+                    if ((IN || ip < a.H) && !COSY_DBG(a.dbg & 64)) {
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q) accx[os][q] = mma4(Af[ky][0], W1p[q], accx[os][q]);
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q) accx[os][q] = mma4(Af[ky][1], W2p[q], accx[os][q]);
+                    }
+                    if (ky == KS - 1) {
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q) {
+                            float y4[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y4[e] = accx[os][q][e] * mxp[2] + mxp[3];
+                            if (!COSY_DBG(a.dbg & 512)) silu4p<false>(y4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) sum[0] += y4[e];
+                            const t4 hv = t4{cvt(y4[0]), cvt(y4[1]), cvt(y4[2]), cvt(y4[3])};
+                            const i32x2 hh = __builtin_bit_cast(i32x2, hv);
+                            if (COSY_DBG(a.dbg & 256)) {
+                                ynew[q][0] = hv;
+                            } else {
+                                const int lo = __builtin_amdgcn_ds_bpermute(bp_out, hh[0]), hi = __builtin_amdgcn_ds_bpermute(bp_out, hh[1]);
+                                const f32x4 tr = mma16(__builtin_bit_cast(t4, i32x2{lo, hi}), ident, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) ynew[q][0][e] = (T)tr[e];
+                            }
+                            accx[os][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                        done = true; oy_done = oy;
+                    }
+                }
+                if (done) {
+#pragma unroll
+                    for (int t = 0; t < TO; ++t) yv[t][0] = ynew[t][0];
+                    oy_pending = oy_done;
+                    flush(); oy_pending = -1;
+                }
+            }
+            // ---- A2: row iy's expanded values -> its tap operands (independent of B: hipcc interleaves the two)
+            if (doA) {
+                if (IN || iy < a.H) {
+                    int lo[PPL], hi[PPL];
+#pragma unroll
+                    for (int q = 0; q < PPL; ++q) {
+                        float y4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y4[e] = mq[q][e] * mxp[0] + mxp[1];
+                        if (!COSY_DBG(a.dbg & 512)) silu4p<false>(y4);
+                        const t4 hv = t4{cvt(y4[0]), cvt(y4[1]), cvt(y4[2]), cvt(y4[3])};
+                        const i32x2 hh = __builtin_bit_cast(i32x2, hv);
+                        lo[q] = hh[0]; hi[q] = hh[1];
+                        if (!COSY_DBG(a.dbg & 128)) { lo[q] = __builtin_amdgcn_ds_bpermute(bp_in, hh[0]); hi[q] = __builtin_amdgcn_ds_bpermute(bp_in, hh[1]); }
+                    }
+#pragma unroll
+                    for (int q = 0; q < PPL; ++q) {
+                        int hp = __builtin_amdgcn_update_dpp(0, hi[q], 0x90, 0xf, 0xf, false);     // quad_perm [0,0,1,2]
+                        int ln = __builtin_amdgcn_update_dpp(0, lo[q], 0xF9, 0xf, 0xf, false);     // quad_perm [1,2,3,3]
+                        int hp0 = 0, ln3 = 0;
+                        if constexpr (PPL > 1) {
+                            if (q > 0) hp0 = __builtin_amdgcn_update_dpp(0, hi[q > 0 ? q - 1 : 0], 0x93, 0xf, 0xf, false);             // quad_perm [3,0,1,2]
+                            if (q < PPL - 1) ln3 = __builtin_amdgcn_update_dpp(0, lo[q < PPL - 1 ? q + 1 : 0], 0x39, 0xf, 0xf, false);   // quad_perm [1,2,3,0]
+                        }
+                        hp = jq == 0 ? hp0 : hp; ln = jq == 3 ? ln3 : ln;
+                        W1n[q] = __builtin_bit_cast(t4, i32x2{lo[q], hi[q]}); W2n[q] = __builtin_bit_cast(t4, i32x2{hp, ln});
+                    }
+                }
+            }
+            if (doA) {
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) { W1p[q] = W1n[q]; W2p[q] = W2n[q]; }
+            }
+        }
+    };
+
+    // ---- the FUSED interior iteration (round 6): the tap / output side of row iy - 1 and the expansion side of row iy as ONE hand-ordered instruction stream.
+    // Order (every line an asm volatile statement, nothing for hipcc to schedule):
+    //   [parked weight fragments 0..2 -> registers]  taps of row iy - 1 (first operands of all KS output rows, then the halo operands: a dependent pair is KS - 1 MFMAs apart)
+    //   wait for row iy's fragments (counted: the previous output row's store stays in flight)
+    //   expansion chain m1 .. mKBN, one group of four output-side VALU instructions (BatchNorm 1, SiLU's five steps) behind each link: the chain's 16-cycle links cover them
+    //   row iy + 1's loads, BatchNorm 0 of the expanded row, then the two sides interleaved: squeeze adds | SiLU steps | converts | both lane permutations
+    //   transposing MFMA of the output row; under its latency the halo operands of the next taps; convert, store.
+    // Hazards written out by hand (hipcc pads nothing here; padding it would insert: 4x4x4 result -> VALU / VMEM read 5 wait states, -> the next MFMA's SrcC 2;
+    // 16x16x16 / 16x16x32 result -> VALU read 8; transcendental -> VALU read 1; VALU write -> MFMA A / B read 2 -- read off hipcc's own padding of
+    // profiles/exp/mfma_hazards.hip): every such pair below has at least that many instructions of the other chain between its two ends, or an s_nop.
+    auto row_px = [&](auto uc, const int base) {
+        if constexpr (PIPE) {
+            constexpr int u = decltype(uc)::value, up = (u + U - 1) % U;
+            constexpr int od = ((up + LO - (KS - 1)) % NOPEN + NOPEN) % NOPEN;       // the output row that row iy - 1 completes
+            const int iy = base + u, ip = iy - 1, oy = ip - LO;
+            WAVE_STAMP_ROW();
+            if (!st_in_flight) asm volatile("s_waitcnt vmcnt(0) ; XWAIT" ::: "memory");       // (first fused iteration of a job only: nothing was stored behind its loads)
+            px_lgkm<0>();
+            raw_t wb[3];
+            if constexpr (WLDS) { px_wread<0>(wb[0], wl_addr); px_wread<1024>(wb[1], wl_addr); px_wread<2048>(wb[2], wl_addr); }
+            // ---- taps of row iy - 1: tap row ky feeds output row ip + LO - ky (accumulator slot compile-time); ky = KS - 1 first: that row is complete behind its pair
+            unroll_seq([&](auto kc) {
+                constexpr int ky = KS - 1 - decltype(kc)::value, os = ((up + LO - ky) % NOPEN + NOPEN) % NOPEN;
+                if constexpr (ky == 0) px_tap0<T>(accx[os][0], Af[ky][0], W1p[0]); else px_tap<T>(accx[os][0], Af[ky][0], W1p[0]);
+            }, std::make_integer_sequence<int, KS>{});
+            unroll_seq([&](auto kc) {
+                constexpr int ky = KS - 1 - decltype(kc)::value, os = ((up + LO - ky) % NOPEN + NOPEN) % NOPEN;
+                px_tap<T>(accx[os][0], Af[ky][1], W2p[0]);
+            }, std::make_integer_sequence<int, KS>{});
+            xfrag_fence<XTOP, PPL * KBN>();
+            asm volatile("s_waitcnt vmcnt(1) ; XWAIT" ::: "memory");
+            // ---- expansion chain with the output side's first steps in its shadow
+            f32x4 macc;
+            float yo[4], to[4], ye[4], te[4];
+            unroll_seq([&](auto kc) {
+                constexpr int kb = decltype(kc)::value;
+                if constexpr (WLDS) {
+                    // fragments in flight at this point: kb .. min(kb + 2, KBN - 1)
+                    px_lgkm<(kb + 2 < KBN ? 2 : KBN - 1 - kb)>();
+                    px_mma<T, XTOP, kb, kb == 0>(macc, wb[kb % 3]);
+                    if constexpr (kb + 3 < KBN) px_wread<(kb + 3) * 1024>(wb[kb % 3], wl_addr);
+                } else px_mma<T, XTOP, kb, kb == 0>(macc, wf[0][kb]);
+                if constexpr (kb == 0) { if constexpr (KS == 3) px_nop<1>(); px_bn(yo, accx[od][0], mxp[2], mxp[3]); }
+                if constexpr (kb == 1) px_silu_a(yo, to);
+                if constexpr (kb == 2) px_silu_b(to);
+                if constexpr (kb == 3) px_silu_c(to);
+            }, std::make_integer_sequence<int, KBN>{});
+            if constexpr (KBN <= 3) px_silu_c(to);
+            px_silu_d(to);
+            load_row(iy + 1);                        // row iy's fragments are consumed: the next row's loads (they return long after the last link has read its operands)
+            px_silu_e(yo, to);
+            // ---- both sides interleaved
+            px_bn(ye, macc, mxp[0], mxp[1]);         // >= 8 instructions behind the last link
+            px_sum(sum[0], yo);
+            px_silu_a(ye, te);
+            int po0, po1, qo0, qo1;
+            px_cvt<T>(po0, po1, yo, -65504.f, 65504.f);
+            px_silu_b(te);
+            px_bperm2(qo0, qo1, bp_out, po0, po1);
+            px_silu_c(te);
+            px_silu_d(te);
+            px_silu_e(ye, te);                   // (the first reciprocal is three instructions old)
+            int pe0, pe1, w1lo, w1hi;
+            px_cvt<T>(pe0, pe1, ye, -65504.f, 65504.f);
+            px_bperm2(w1lo, w1hi, bp_in, pe0, pe1);
+            // ---- the output row: transposed back to (pixel, 4 channels), stored; the next taps' operands under the transposition's latency
+            px_lgkm<2>();
+            f32x4 tr;
+            px_transpose<T>(tr, __builtin_bit_cast(t4, i32x2{qo0, qo1}), ident);
+            px_lgkm<0>();
+            int hp, ln;
+            px_halo(hp, ln, w1lo, w1hi, first_quad, last_quad);
+            px_nop<3>();
+            px_cvt_store<T>(tr, d_voff, (const T*)D_chunk + (size_t)oy * drow);
+            st_in_flight = 1;
+            W1p[0] = __builtin_bit_cast(t4, i32x2{w1lo, w1hi}); W2p[0] = __builtin_bit_cast(t4, i32x2{hp, ln});
+            prev_fused = true;
+        }
+    };
+    if constexpr (PIPE) {
+        // interior iterations: row iy - 1 feeds only output rows of this job and lies inside the map; row iy lies inside the map and has a successor
+        const int in_lo2 = oy_a + KS - LO, in_hi2 = min(min(oy_b - LO, a.H - 1), iy_last - 1);
+        for (int base = (iy_first / U) * U; base <= iy_last + 1; base += U) {
+            unroll_seq([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                int iy = base + u;
+                // Whole groups of U fused iterations as ONE straight-line loop body (entered from the instance whose u is the first fused row's: band 0, i.e. every
+                // launch of the shipped row-band counts of these shapes): between two fused iterations there is then no merge with the plain form, so hipcc renames the
+                // accumulator slots from iteration to iteration instead of copying them at every merge (8 v_mov_b64 per row of the k = 5 shape otherwise).
+                if constexpr (u == (KS - LO) % U) {
+                    if (iy == in_lo2 && oy_a == 0 && !COSY_DBG(a.dbg & 16)) {
+                        for (int g = (in_hi2 - in_lo2 + 1) / U; g > 0; --g) {
+                            unroll_seq([&](auto jc) {
+                                constexpr int j = decltype(jc)::value;
+                                row_px(std::integral_constant<int, (u + j) % U>{}, base + ((u + j) / U) * U);
+                            }, std::make_integer_sequence<int, U>{});
+                            base += U;
+                        }
+                        iy = base + u;
+                    }
+                }
+                if (iy >= in_lo2 && iy <= in_hi2 && !COSY_DBG(a.dbg & 16)) { row_px(uc, base); return; }
+                row_mx(uc, std::false_type{}, base);
+            }, std::make_integer_sequence<int, U>{});
+        }
+    } else {
     // interior rows: iy + LO - (KS-1) >= oy_a * S (every tap row's output row is >= oy_a), iy + LO < oy_b * S (... < oy_b),
     // iy < H, iy + 1 <= iy_last
     const int in_lo = oy_a * S + KS - 1 - LO, in_hi = min(min(oy_b * S - 1 - LO, a.H - 1), iy_last - 1);
@@ -637,6 +978,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
             }
             row(uc, std::false_type{}, base);
         }, std::make_integer_sequence<int, U>{});
+    }
     }
     flush();
     // ---- squeeze sums: fixed-order tree over the 16 lanes of a row (one channel quad per row), lane 15 writes
@@ -679,7 +1021,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
 // across batch sizes.
 #define COSY_WAVE_VARIANTS(X)                                                                                      \
     X(3, 2, 1, 8, 1, true, 2, 4) X(3, 1, 1, 4, 1, true, 3, 2) X(5, 2, 1, 4, 1, true, 3, 1) X(5, 1, 2, 2, 1, true, 3, 2)      \
-    X(3, 2, 2, 2, 1, true, 4, 2) X(3, 1, 3, 1, 1, true, 5, 1) X(5, 1, 3, 1, 1, true, 4, 1) X(5, 1, 5, 1, 1, true, 4, 1)      \
+    X(3, 2, 2, 2, 1, true, 4, 2) X(3, 1, 3, 1, 1, true, 4, 1) X(5, 1, 3, 1, 1, true, 4, 1) X(5, 1, 5, 1, 1, true, 4, 1)      \
     X(3, 1, 1, 5, 1, true, 2, 2) X(5, 2, 1, 6, 1, false, 2, 1) X(5, 1, 2, 3, 1, false, 2, 2) X(3, 2, 2, 4, 1, false, 3, 1)   \
     X(3, 1, 3, 2, 1, false, 3, 1) X(5, 1, 3, 2, 1, false, 2, 1) X(5, 1, 5, 2, 1, false, 2, 1)                                \
     /* rows that do not fill their 16 * PPL lanes, reached by walking the map's COLUMNS (wave_plan: transposed): 240x320 crops */ \
@@ -826,6 +1168,9 @@ static int launch_wave_k(WaveKArgs k, int* n_tiles_out, hipStream_t s) {
         }
     }
 #endif
+#ifdef COSY_TUNE
+    lds += (size_t)tune_int("COSY_WAVE_LDS_PAD", 0);      // experiment: fewer resident workgroups per CU
+#endif
     k.rsplit = tune_int("COSY_WAVE_RSPLIT", RSP);
     if (k.rsplit < 1) k.rsplit = 1;
     if (k.rsplit > WAVE_MAX_RSPLIT) k.rsplit = WAVE_MAX_RSPLIT;
@@ -834,6 +1179,9 @@ static int launch_wave_k(WaveKArgs k, int* n_tiles_out, hipStream_t s) {
     *n_tiles_out = k.rsplit;
     const long jobs_per_xcd = (long)cdiv(k.B, 8) * k.nchunks * k.rsplit;
     const dim3 grid((unsigned)(cdiv(jobs_per_xcd, 4) * 8)), block(256);
+#ifdef COSY_TUNE
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)mbconv_wave_kernel<T, KS, S, KBN, PPL, NI, FW, MW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
     hipLaunchKernelGGL((mbconv_wave_kernel<T, KS, S, KBN, PPL, NI, FW, MW>), grid, block, lds, s, k);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;

@@ -463,6 +463,21 @@ class TorchRef:
             return t.clamp(-65504.0, 65504.0).half().float()
         return t
 
+    # bf16 (round 6): the 1x1-conv WEIGHTS are error-compensated pairs -- hi = bf16(w), lo = bf16(w - hi), two MFMAs per fragment against the same
+    # activation fragment, fp32 accumulation -- so what multiplies the activations is hi + lo (16 significant bits); the depthwise taps and the expanded
+    # values of the matrix-pipe fronts (kinds 5 / 6) are fp16 operands in EVERY 16-bit mode (the small MFMA's operands are a register format, not storage).
+    hilo = False         # True: bf16 weights as hi + lo pairs (set together with the kernels that implement them)
+
+    def _rndw(self, t, storage):
+        if storage == 'bf16' and self.hilo:
+            hi = t.bfloat16().float()
+            return hi + (t - hi).bfloat16().float()
+        return self._rnd(t, storage)
+
+    def _rnd_mx(self, t, storage):
+        """operand format of the depthwise MFMAs (front kinds 5 / 6): fp16, saturating, for both 16-bit storage types"""
+        return self._rnd(t, 'fp16' if (storage == 'bf16' and self.hilo) else storage)
+
     def stem_emulated(self, x, storage, round_output=True):
         """x (B,6,H,W) fp32 (rounded to the storage type here, as the crop kernel does) -> stem output.  round_output=False: the stem tensor as
         the fused stem + block-0 front holds it (kernels_stem.hip: fp32 rows in registers, never stored)"""
@@ -489,25 +504,27 @@ class TorchRef:
             s0 = g64.float().double()
             b0 = (sd[p + '_bn0.bias'].double() - sd[p + '_bn0.running_mean'].double() * g64).float().double()
             L2E = 1.4426950408889634
-            We = R((sd[p + '_expand_conv.weight'].double() * (s0 * L2E)[:, None, None, None]).float())
+            We = self._rndw((sd[p + '_expand_conv.weight'].double() * (s0 * L2E)[:, None, None, None]).float(), storage)
             t = self._conv(x, We, 1, 1) + (b0 * L2E).float()[None, :, None, None]
             x = sw(t * 0.6931471805599453)
-            if fused == 6:                                       # the small kernel's matrix-pipe form (kernels_smx.hip): E rounded to the storage type
-                x = R(x)
+            if fused == 6:                                       # the small kernel's matrix-pipe form (kernels_smx.hip): E rounded to the tap MFMAs' operand type
+                x = self._rnd_mx(x, storage)
         elif e != 1:
-            x = sw(self._bn(self._conv(x, R(sd[p + '_expand_conv.weight']), 1, 1), p + '_bn0'))
-            if not fused or fused == 5:                          # unfused blocks store the expanded tensor; front kind 5 (wave kernel, taps on the
-                x = R(x)                                         # matrix pipe) rounds it to the storage type as the small MFMA's operand
+            x = sw(self._bn(self._conv(x, self._rndw(sd[p + '_expand_conv.weight'], storage), 1, 1), p + '_bn0'))
+            if not fused:                                        # unfused blocks store the expanded tensor
+                x = R(x)
+            elif fused == 5:                                     # front kind 5 (wave kernel, taps on the matrix pipe): the small MFMA's operand
+                x = self._rnd_mx(x, storage)
         dw_w = sd[p + '_depthwise_conv.weight']
         if fused in (5, 6):                                      # ... and the taps too (products exact, fp32 accumulation)
-            dw_w = R(dw_w)
+            dw_w = self._rnd_mx(dw_w, storage)
         d32 = sw(self._bn(self._conv(x, dw_w, k, s, groups=x.shape[1]), p + '_bn1'))
         q = d32.mean((2, 3), keepdim=True)
         q = self._conv(sw(self._conv(q, sd[p + '_se_reduce.weight'], 1, 1, bias=sd[p + '_se_reduce.bias'])),
                        sd[p + '_se_expand.weight'], 1, 1, bias=sd[p + '_se_expand.bias'])
         g = torch.sigmoid(q)[:, :, 0, 0]                       # (B, Cmid)
         D = R(d32)
-        W = R(sd[p + '_project_conv.weight'])[:, :, 0, 0]        # (Cout, Cmid)
+        W = self._rndw(sd[p + '_project_conv.weight'], storage)[:, :, 0, 0]        # (Cout, Cmid)
         hw = D.shape[2] * D.shape[3]
         if gate_on_weights is None:
             gate_on_weights = hw % 64 == 0
@@ -515,7 +532,7 @@ class TorchRef:
             if storage == 'fp16':
                 Wg = (W.half()[None] * g.half()[:, None, :]).float()
             else:
-                Wg = R(W[None] * g[:, None, :])
+                Wg = self._rndw(W[None] * g[:, None, :], storage)      # bf16: (hi + lo) * g in fp32, re-split into a pair
             y = torch.einsum('bnk,bkhw->bnhw', Wg, D)
         else:                                                    # gate applied to the activation rows
             if storage == 'fp16':
@@ -531,7 +548,7 @@ class TorchRef:
     def head_emulated(self, x, storage):
         R = lambda t: self._rnd(t, storage)
         sw = lambda t: t * self.torch.sigmoid(t)
-        return R(sw(self._bn(self._conv(x, R(self.sd['backbone._conv_head.weight']), 1, 1), 'backbone._bn1')))
+        return R(sw(self._bn(self._conv(x, self._rndw(self.sd['backbone._conv_head.weight'], storage), 1, 1), 'backbone._bn1')))
 
     def extract_features_emulated(self, x, storage, fused, probes=None, gate_w=None):
         """x (B,6,H,W) fp32; storage 'bf16' | 'fp16'; fused[i] = front kernel of block i as cosy_effnet_b3_block_info reports it

@@ -1865,7 +1865,7 @@ def test_io_formats_round_trip_on_device(model, labels21, tmp_path):
 
 
 def test_engine_capacity_beyond_the_stem_front_offset_limit(model, golden_sd):
-    """An engine whose input buffer exceeds the 32-bit offset the fused stem front reaches its zero page by (> 2047 crops of 256x256 in a 16-bit
+    """An engine whose input buffer exceeds the 32-bit offset the fused stem front reaches its zero page by (>= 4080 crops of 256x256 in a 16-bit
     type; EnginePool rounds capacities up to powers of two, so one 2049-crop call asks for 4096) must still run: it keeps the unfused stem + block 0
     (block kind != 4) and gives the results of a small engine within the 16-bit kernels' tolerance (round 5's advisor: such calls FAILED at forward)."""
     import ctypes
@@ -1874,7 +1874,7 @@ def test_engine_capacity_beyond_the_stem_front_offset_limit(model, golden_sd):
     blob, _ = flat_params(model.backbone, model.pose_fc)
     x = dev(np.concatenate([syn.make_renders(77, 4, 256, 256), syn.make_renders(78, 4, 256, 256)], 1))
     outs, kinds = [], []
-    for cap in (16, 2100):
+    for cap in (16, 4100):          # 4100 crops x 256 x 256 x 16 bytes = 4.3 GB of input buffer (the whole engine: ~45 GB of the 288)
         h = ctypes.c_void_p()
         check(lib().cosy_effnet_b3_create(blob.data_ptr(), blob.numel(), COSY_F16, 256, 256, cap, ctypes.byref(h)))
         try:
