@@ -149,7 +149,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         return d;
     };
     auto mk_pw = [&](PwLayer& L, const float* w, int K, int N, const float* bn, int HW, bool gated) {
-        L.K = K; L.N = N; L.cfg = n->esz == 2 ? pw_choose_cfg_late(K, N, HW, gated) : pw_choose_cfg(N);
+        L.K = K; L.N = N; L.cfg = n->esz == 2 ? pw_choose_cfg_late(K, N, HW, gated, n->dtype) : pw_choose_cfg(N);
         const size_t ne = pw_packed_elems(K, N, L.cfg, n->dtype);
         L.Wp = bump.take(ne * n->esz);
         const int npad = cdiv(N, pw_bn(L.cfg)) * pw_bn(L.cfg);
@@ -317,7 +317,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         // tile computes two gates: at 240x320 crops -- maps of 1200 / 300 pixels under 128-row tiles -- the project GEMMs of blocks 13-17
         // went 64 -> 148 us for 13 us of squeeze-excite kernels saved; those sizes keep the kernels)
         b.se_fused = ((n->se_fuse_mask >> i) & 1) && (size_t)b.cse * b.cmid * 8 <= ((size_t)256 << 10) && b.cse <= 128 &&
-                     (b.Ho * b.Wo) % pw_bm(b.proj.cfg) == 0 && b.proj.cfg.WV == 4 && b.proj.cfg.NI >= 3 && b.cmid > 2 * pw_kb(n->dtype);   // (the 3-stage 4-wave tiles carry the prologue)
+                     (b.Ho * b.Wo) % pw_bm(b.proj.cfg) == 0 && b.proj.cfg.WV == 4 && b.proj.cfg.NI >= 3 && b.cmid > 2 * pw_kb(n->dtype) && pw_ring_stages(b.cmid, b.proj.cfg, n->dtype) == 3;   // (the 3-stage 4-wave tiles carry the prologue)
         p += (size_t)b.d.cout * b.cmid + 4 * b.d.cout;
         h = b.Ho; w_ = b.Wo;
     }
@@ -654,8 +654,11 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
         n->stem_fused = n->fuse && stem_front_supported(dtype, H, W) &&
                         (size_t)max_batch * H * W * 8 * n->esz + 256 < ((size_t)1 << 32) - ((size_t)1 << 24);
         n->stemf_w = nullptr; n->stemf_params = nullptr;
-        n->small_mask = (unsigned)tune_int("COSY_SMALL_MASK", 0x3f80000);
-        n->tile_mask = (unsigned)tune_int("COSY_TILE_MASK", 0x13c);         // blocks 2-5 and 8 (measured in round 1: it loses on the k=5 stride-1 blocks 6/7)   // blocks 19-25 (8x8 / 7x10 maps): whole-image kernel
+        // bf16 (round 6: hi + lo weight pairs in the GEMM and the wave fronts): the whole-image fronts of the 8x8 / 7x10 maps and the LDS-tiled front do not carry the
+        // pairs -- their blocks run the unfused kernels (pw_gemm_dma -> E -> dwconv), which do
+        const bool pairs = dtype == COSY_BF16;
+        n->small_mask = pairs ? 0u : (unsigned)tune_int("COSY_SMALL_MASK", 0x3f80000);
+        n->tile_mask = pairs ? 0u : (unsigned)tune_int("COSY_TILE_MASK", 0x13c);         // blocks 2-5 and 8 (measured in round 1: it loses on the k=5 stride-1 blocks 6/7)   // blocks 19-25 (8x8 / 7x10 maps): whole-image kernel
         n->wave_mask = (unsigned)tune_int("COSY_WAVE_MASK", 0x3fffc);   // blocks 2-17: maps 16..128 pixels wide, stride per shape table
         n->nstreams = tune_int("COSY_STREAMS", 1) == 2 && max_batch >= 32 ? 2 : 1;   // measured: 2 streams x half batches is ~10 % slower
     }
@@ -754,7 +757,7 @@ int cosy_effnet_b3_block_info(const cosy_net_t* n, int i, int* dims) {
     const Block& b = n->blk[i];
     // where the project GEMM applies the squeeze-excite gate: to the weight fragments (maps of a multiple of 64 pixels: a wave's 64
     // rows belong to one sample) or to the activation rows
-    const int gate_w = (b.Ho * b.Wo) % 64 == 0;
+    const int gate_w = pw_gate_on_weights(b.Ho * b.Wo, n->dtype);
     const int v[11] = {b.H, b.W, b.Ho, b.Wo, b.d.cin, b.cmid, b.d.cout, i == 0 && n->stem_fused ? 4 : b.wave ? (wave_taps_on_mfma(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W) ? 5 : 1) : b.smx ? 6 : b.small ? 2 : b.tiled ? 3 : 0, b.d.k, b.d.s, gate_w};
     for (int q = 0; q < 11; ++q) dims[q] = v[q];
     return COSY_OK;

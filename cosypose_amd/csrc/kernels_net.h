@@ -13,11 +13,14 @@ struct PwCfg { int NI, WN, WV = 4, KG = 1; };
 static inline int pw_bn(PwCfg c) { return 16 * c.NI * c.WN; }
 static inline int pw_bm(PwCfg c) { return 64 * (c.WV / c.KG / c.WN); }
 PwCfg pw_choose_cfg(int N);
-PwCfg pw_choose_cfg_late(int K, int N, int HW, bool gated);
+PwCfg pw_choose_cfg_late(int K, int N, int HW, bool gated, int dtype);
+int pw_ring_stages(int K, PwCfg c, int dtype);   // LDS ring depth of the 4-wave GEMM tile for this layer (the squeeze-excite prologue exists for 3 stages only)
+int pw_hl(int dtype);                     // weight fragment blocks per k-block: 2 for bf16 (hi + lo pairs), else 1
+bool pw_gate_on_weights(int HW, int dtype);   // project GEMM: squeeze-excite gate folded into the weight fragments (else: multiplied into the activation rows)
 int pw_kb(int dtype);                     // k elements per fragment block: 32 (bf16) / 16 (f32)
-size_t pw_packed_elems(int K, int N, PwCfg c, int dtype);
+size_t pw_packed_elems(int K, int N, PwCfg c, int dtype, int hl = -1);      // hl: weight fragment blocks per k-block (< 0: pw_hl(dtype); 1: single values)
 // host-side packing of a (N,K) fp32 weight into the kernel's fragment-block order (dst has elem size of dtype)
-void pw_pack_weights(const float* w, int K, int N, PwCfg c, int dtype, void* dst);
+void pw_pack_weights(const float* w, int K, int N, PwCfg c, int dtype, void* dst, int hl = -1);
 
 struct PwArgs {
     const void* A;       // (M,K) activations, NHWC rows

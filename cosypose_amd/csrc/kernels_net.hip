@@ -47,7 +47,7 @@ PwCfg pw_choose_cfg(int N) {
 // (b14-17 project), 51 -> 41 us (b13).  Wider tiles lose: BN = 256 (NI8,WN2; 84 KB of LDS, one workgroup per CU) 58 -> 86
 // us (82 us with a 2-stage ring that restores two workgroups per CU), 256 x 128 (NI8,WN1) 66 -> 107 us, 2 x 192 for N = 384
 // 61 -> 70 us.
-PwCfg pw_choose_cfg_late(int K, int N, int HW, bool gated) {
+PwCfg pw_choose_cfg_late(int K, int N, int HW, bool gated, int dtype) {
     // 8-wave tiles (128 x 128 as 2 x 4 waves of 64 x 32): each wave issues half the LDS-DMAs, gate multiplies and MFMAs of a
     // k-step and two waves share a SIMD, so one wave's gate arithmetic / fragment reads overlap the other's MFMAs (the
     // 4-wave tile runs them back to back).  Measured at 256 crops: N = 232 project 44 -> 36 us, N = 816 expand 55 -> 44 us,
@@ -64,18 +64,27 @@ PwCfg pw_choose_cfg_late(int K, int N, int HW, bool gated) {
     // profiles/r04_rowgate_tiles.txt): the split-K tile loses (blocks 19-23 51 -> 58 us, 24 / 25 51 / 79 -> 74 / 109); the 8-wave tile wins for
     // N = 384 (blocks 24 / 25: 51 / 79 -> 47 / 74 us); N <= 256 goes to the 4-wave tile with 32 rows per wave (pw_mi below), which wins more.
     static const int pw16_rg = tune_int("COSY_PW16_RG", 0), pw8_rg = tune_int("COSY_PW8_RG", 1);
-    if (pw16 && gated && K >= 1024 && (HW % 64 == 0 || pw16_rg) && N >= 192) return N > 256 && N <= 384 ? PwCfg{3, 4, 16, 2} : PwCfg{2, 4, 16, 2};
+    // bf16 (round 6): every weight fragment is a hi + lo pair (pw_hl), so a ring stage carries twice the weight blocks: the 16-wave split-K tile runs a TWO-stage ring
+    // there (2 x (8 + 16..24) KB x 2 stages + the gate rows <= 158 KB; three stages do not fit)
+    // (bf16: 128-column tiles for N = 384 too -- the 192-column one does not fit 128 registers with the weight pairs)
+    if (pw16 && gated && K >= 1024 && (HW % 64 == 0 || pw16_rg) && N >= 192) return N > 256 && N <= 384 && dtype != COSY_BF16 ? PwCfg{3, 4, 16, 2} : PwCfg{2, 4, 16, 2};
     if (pw8 && K >= 128 && N >= 192 && (!gated || HW % 64 == 0 || (pw8_rg && N > 256))) return PwCfg{2, 4, 8};
     static const int wide = tune_int("COSY_PW_WIDE", 1);
     if (wide && K >= 96 && HW >= 64 && N > 128 && N <= 160) return PwCfg{5, 2};
     return pw_choose_cfg(N);
 }
 int pw_kb(int dtype) { return dtype == COSY_F32 ? 16 : 32; }
+// where the project GEMM applies the squeeze-excite gate for a map of HW pixels: to the weight fragments, or to the activation rows
+bool pw_gate_on_weights(int HW, int dtype) { return HW % 64 == 0 && dtype != COSY_BF16; }
+// bf16 weights are ERROR-COMPENSATED PAIRS (round 6): hi = bf16(w), lo = bf16(w - hi), stored as two consecutive fragment blocks per k-block; every MFMA kernel
+// multiplies the same activation fragment with both (fp32 accumulation), so what meets the activations is hi + lo = w to 16 significant bits.  bf16's 8-bit
+// weights were what kept the type BASELINE configs[1] names outside north_star's 1e-4 pose bound (1.7e-4; with the pairs 3e-5, below fp16's: profiles/r06_bf16.txt).
+int pw_hl(int dtype) { return dtype == COSY_BF16 ? 2 : 1; }
 static inline uint16_t f32_to_f16_host(float f) { _Float16 h = (_Float16)(f > 65504.f ? 65504.f : (f < -65504.f ? -65504.f : f)); uint16_t u; memcpy(&u, &h, 2); return u; }
 static int pw_nkb_total(int K, int dtype) { int n = cdiv(K, pw_kb(dtype)); return (n + 1) & ~1; }
-size_t pw_packed_elems(int K, int N, PwCfg c, int dtype) {
+size_t pw_packed_elems(int K, int N, PwCfg c, int dtype, int hl) {      // hl: fragment blocks per k-block; < 0 = the type's own (pw_hl), 1 = single values (the stem kernels)
     const int epl = dtype == COSY_F32 ? 4 : 8;
-    return (size_t)cdiv(N, pw_bn(c)) * c.NI * c.WN * pw_nkb_total(K, dtype) * 64 * epl;
+    return (size_t)cdiv(N, pw_bn(c)) * c.NI * c.WN * pw_nkb_total(K, dtype) * (hl < 0 ? pw_hl(dtype) : hl) * 64 * epl;
 }
 static inline uint16_t f32_to_bf16_host(float f) {
     uint32_t u; memcpy(&u, &f, 4);
@@ -83,21 +92,28 @@ static inline uint16_t f32_to_bf16_host(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
-void pw_pack_weights(const float* w, int K, int N, PwCfg c, int dtype, void* dst) {
-    const int epl = dtype == COSY_F32 ? 4 : 8, kb = pw_kb(dtype), nkb = pw_nkb_total(K, dtype);
+static inline float bf16_bits_to_f32(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+void pw_pack_weights(const float* w, int K, int N, PwCfg c, int dtype, void* dst, int hl_) {
+    const int epl = dtype == COSY_F32 ? 4 : 8, kb = pw_kb(dtype), nkb = pw_nkb_total(K, dtype), hl = hl_ < 0 ? pw_hl(dtype) : hl_;
     const int NW = c.NI * c.WN, BN = pw_bn(c), NT = cdiv(N, BN);
     size_t idx = 0;
     for (int nt = 0; nt < NT; ++nt)
         for (int nb = 0; nb < NW; ++nb)
             for (int kbi = 0; kbi < nkb; ++kbi)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int e = 0; e < epl; ++e, ++idx) {
-                        const int i = lane & 15, kg = lane >> 4, wn = nb / c.NI, ni = nb % c.NI;
-                        const int n = nt * BN + wn * 16 * c.NI + (i >> 2) * 4 * c.NI + ni * 4 + (i & 3);
-                        const int k = kbi * kb + kg * epl + e;
-                        const float v = (n < N && k < K) ? w[(size_t)n * K + k] : 0.f;
-                        if (dtype == COSY_F32) ((float*)dst)[idx] = v; else ((uint16_t*)dst)[idx] = dtype == COSY_BF16 ? f32_to_bf16_host(v) : f32_to_f16_host(v);
-                    }
+                for (int h = 0; h < hl; ++h)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < epl; ++e, ++idx) {
+                            const int i = lane & 15, kg = lane >> 4, wn = nb / c.NI, ni = nb % c.NI;
+                            const int n = nt * BN + wn * 16 * c.NI + (i >> 2) * 4 * c.NI + ni * 4 + (i & 3);
+                            const int k = kbi * kb + kg * epl + e;
+                            const float v = (n < N && k < K) ? w[(size_t)n * K + k] : 0.f;
+                            if (dtype == COSY_F32) ((float*)dst)[idx] = v;
+                            else if (dtype == COSY_F16) ((uint16_t*)dst)[idx] = f32_to_f16_host(v);
+                            else {
+                                const uint16_t hi = f32_to_bf16_host(v);
+                                ((uint16_t*)dst)[idx] = h == 0 ? hi : f32_to_bf16_host(v - bf16_bits_to_f32(hi));
+                            }
+                        }
 }
 
 // samples an m-tile of bm rows can touch when a sample has hw rows
@@ -152,7 +168,8 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
     constexpr int EPL = D::EPL, KB = D::KB;
     constexpr int GW = NWV / KG;              // waves of one K-group
     constexpr int WM = GW / WN, BM = 16 * MI * WM, BN = 16 * NI * WN;
-    constexpr int NA = BM / 16, NW = NI * WN, NB = NA + NW;
+    constexpr int HL = __is_same(T, bf16_t) ? 2 : 1;        // bf16: weight fragments are hi + lo pairs (pw_hl), two consecutive blocks
+    constexpr int NA = BM / 16, NW = NI * WN, NB = NA + NW * HL;
     constexpr int SB = KG * NB;               // 1 KiB blocks of one ring stage (KG k-blocks)
     constexpr int L = (SB + NWV - 1) / NWV;   // DMA instructions per wave per stage
     static_assert(GW * KG == NWV && WM * WN == GW, "wave grid");
@@ -196,7 +213,7 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
                     const int m = m0 + blk * 16 + row, k = kb * KB + kg * EPL;
                     if (m < M && k < K) src = a.a_chunked ? A + (size_t)(achunk[i] + (unsigned)(k >> 4) * (unsigned)a.HW) * 16 + (k & 15) : A + (size_t)m * K + k;
                 } else {
-                    src = Wp + ((size_t)(nt * NW + (blk - NA)) * a.nkb_total + kb) * 64 * EPL + lane * EPL;
+                    src = Wp + (((size_t)(nt * NW + (blk - NA) / HL) * a.nkb_total + kb) * HL + (blk - NA) % HL) * 64 * EPL + lane * EPL;
                 }
             }
             if (a.a_nt && blk < NA)     // wave-uniform
@@ -358,9 +375,12 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
         const int kb = ks * KG + kgp;                                          // this K-group's k-block of the stage
         if (KG > 1 && kb >= a.nkb_valid) continue;                             // odd number of k-blocks: the last stage is half full (wave-uniform)
         const char* st = lds + ((ks % NS) * SB + kgp * NB) * 1024;
-        raw_t fw[NI], fa[MI];
+        raw_t fw[NI], fa[MI], fwl[HL == 2 ? NI : 1];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) fw[ni] = *(const raw_t*)(st + (NA + wn * NI + ni) * 1024 + lane * 16);
+        for (int ni = 0; ni < NI; ++ni) {
+            fw[ni] = *(const raw_t*)(st + (NA + (wn * NI + ni) * HL) * 1024 + lane * 16);
+            if constexpr (HL == 2) fwl[ni] = *(const raw_t*)(st + (NA + (wn * NI + ni) * HL + 1) * 1024 + lane * 16);
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) fa[mi] = *(const raw_t*)(st + (wm * MI + mi) * 1024 + lane * 16);
         if (GATE && a.rowgate) {
@@ -394,7 +414,7 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
                 w8 = w8 * g8;
                 fw[ni] = __builtin_bit_cast(raw_t, w8);
             }
-        } else if constexpr (GATE) {
+        } else if constexpr (GATE && HL == 1) {      // (fp32; bf16 always takes the row-side gate: a folded weight would have to be re-split into a pair)
             float g[EPL];
             const float* gp = gl + gsel * Kpad + kb * KB + kg * EPL;
 #pragma unroll
@@ -411,7 +431,10 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) mma(acc[mi][ni], fw[ni], fa[mi]);
+            for (int ni = 0; ni < NI; ++ni) {
+                mma(acc[mi][ni], fw[ni], fa[mi]);
+                if constexpr (HL == 2) mma(acc[mi][ni], fwl[ni], fa[mi]);
+            }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (KG > 1) {
@@ -488,10 +511,10 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
 template <typename T, int NI, int WN, bool GATE, int NS, int MI, int NWV = 4, int KG = 1, bool SEF = false>
 static int launch_pw_dma_mi(PwKArgs k, hipStream_t s) {
     if constexpr (!SEF) COSY_REQUIRE(!k.se_wr, "pw_gemm_dma: this tile shape has no squeeze-excite prologue (NI=%d WN=%d)", NI, WN);
-    constexpr int WM = NWV / KG / WN, NB = KG * (MI * WM + NI * WN);
+    constexpr int WM = NWV / KG / WN, NB = KG * (MI * WM + NI * WN * (__is_same(T, bf16_t) ? 2 : 1));
     k.MT = cdiv(k.M, 16 * MI * WM);
     const int grid = cdiv(k.MT, 8) * 8 * k.NT;
-    k.rowgate = GATE && (k.HW % 64 != 0);
+    k.rowgate = GATE && (k.HW % 64 != 0 || __is_same(T, bf16_t));      // bf16: the gate always multiplies the activation rows (pw_gate_on_weights)
     k.nsamp = k.rowgate ? pw_gate_nsamp(16 * MI * WM, k.HW) : 2;
     const size_t lds = (size_t)NS * NB * 1024 + 3072 + (GATE ? (size_t)k.nsamp * k.nkb_total * DT<T>::KB * 4 : 0) +
                        (GATE && k.se_wr ? ((size_t)k.nkb_total * DT<T>::KB + 128) * 4 : 0);       // + pooled[Kpad], redv[<= 128]
@@ -527,14 +550,21 @@ static int launch_pw_dma_ns(const PwKArgs& k, int grid, hipStream_t s) {
     }
     return launch_pw_dma_mi<T, NI, WN, GATE, NS, 4>(k, s);
 }
+// Ring depth of the 4-wave tiles.  Short k-loops (<= 2 k-blocks: the streaming 1x1 convs of the high-resolution blocks) need no deep ring: 2 stages keep the
+// LDS footprint small so that more workgroups are resident per CU.  bf16 (hi + lo weight blocks, pw_hl): a 3-stage ring of the 160-column tile is 84 KB -- ONE
+// workgroup per CU instead of two (blocks 13-17's project GEMMs: 41 -> 85 us, profiles/r06_bf16.txt); two stages keep the second workgroup.
+int pw_ring_stages(int K, PwCfg c, int dtype) {
+    static const int ns2 = tune_int("COSY_PW_NS2_MAXKB", 2), deep = tune_int("COSY_PW_NS", 3);
+    const int nkb = cdiv(K, pw_kb(dtype));
+    if (nkb <= ns2) return 2;
+    if (c.WV <= 4 && (16 / c.WN + c.NI * c.WN * pw_hl(dtype)) * 3 > 80) return 2;
+    return deep >= 4 && nkb >= 8 ? 4 : 3;
+}
 template <typename T, int NI, int WN, bool GATE>
 static int launch_pw_dma_cfg(const PwKArgs& k, int grid, hipStream_t s) {
-    // short k-loops (<= 2 k-blocks: the streaming 1x1 convs of the high-resolution blocks) need no deep ring:
-    // 2 stages keep the LDS footprint small so that more workgroups are resident per CU
-    static const int ns2 = tune_int("COSY_PW_NS2_MAXKB", 2);
-    if (k.nkb_valid <= ns2) return launch_pw_dma_ns<T, NI, WN, GATE, 2>(k, grid, s);
-    static const int deep = tune_int("COSY_PW_NS", 3);
-    if (deep >= 4 && k.nkb_valid >= 8) return launch_pw_dma_ns<T, NI, WN, GATE, 4>(k, grid, s);
+    const int ns = pw_ring_stages(k.K, PwCfg{NI, WN}, sizeof(T) == 4 ? COSY_F32 : __is_same(T, bf16_t) ? COSY_BF16 : COSY_F16);
+    if (ns == 2) return launch_pw_dma_ns<T, NI, WN, GATE, 2>(k, grid, s);
+    if (ns == 4) return launch_pw_dma_ns<T, NI, WN, GATE, 4>(k, grid, s);
     return launch_pw_dma_ns<T, NI, WN, GATE, 3>(k, grid, s);
 }
 template <typename T, bool GATE>
@@ -542,9 +572,10 @@ static int launch_pw_dma(const PwKArgs& k, PwCfg c, int grid, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {   // 8-wave tiles of the late layers: 2 waves per SIMD take turns on the matrix pipe
         if (c.WV == 16) {        // in-workgroup split-K (KG = 2): the K >= 1024 project convs of the 8x8 maps
             if constexpr (GATE) {
+                constexpr int NS16 = __is_same(T, bf16_t) ? 2 : 3;      // bf16: hi + lo weight blocks, two ring stages (pw_choose_cfg_late)
                 if (k.nkb_valid > 4 && (k.HW % 64 == 0 || tune_int("COSY_PW16_RG", 0)) && c.KG == 2 && c.WN == 4) {
-                    if (c.NI == 2) return launch_pw_dma_mi<T, 2, 4, GATE, 3, 4, 16, 2>(k, s);
-                    if (c.NI == 3) return launch_pw_dma_mi<T, 3, 4, GATE, 3, 4, 16, 2>(k, s);
+                    if (c.NI == 2) return launch_pw_dma_mi<T, 2, 4, GATE, NS16, 4, 16, 2>(k, s);
+                    if constexpr (!__is_same(T, bf16_t)) { if (c.NI == 3) return launch_pw_dma_mi<T, 3, 4, GATE, NS16, 4, 16, 2>(k, s); }
                 }
             }
             set_error("pw_gemm_dma: 16-wave split-K tile NI=%d WN=%d KG=%d not built for this layer", c.NI, c.WN, c.KG);
@@ -603,12 +634,10 @@ static const char* tname(int dtype) { return dtype == COSY_F32 ? "float" : dtype
 // the kernel symbol (as rocprofv3 demangles it) that launch_pw_gemm will run for these arguments
 void pw_kernel_name(const PwArgs& a, PwCfg c, int dtype, char* buf, size_t n) {
     const int nkb = cdiv(a.K, pw_kb(dtype));
-    static const int deep = tune_int("COSY_PW_NS", 3);
     const int mi = pw_mi_for(a.gate != nullptr, a.HW, nkb, a.N, dtype == COSY_F32 ? 4 : 2);
-    if (c.WV == 16) snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, 3, %s, 4, 16, %d>", tname(dtype), c.NI, c.WN, a.gate ? "true" : "false", c.KG);
+    if (c.WV == 16) snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, %d, %s, 4, 16, %d>", tname(dtype), c.NI, c.WN, dtype == COSY_BF16 ? 2 : 3, a.gate ? "true" : "false", c.KG);
     else if (c.WV == 8) snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, 3, %s, 4, 8>", tname(dtype), c.NI, c.WN, a.gate ? "true" : "false");
-    else snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, %d, %s, %d>", tname(dtype), c.NI, c.WN,
-                  nkb <= 2 ? 2 : (deep >= 4 && nkb >= 8 ? 4 : 3), a.gate ? "true" : "false", mi);
+    else snprintf(buf, n, "pw_gemm_dma_kernel<%s, %d, %d, %d, %s, %d>", tname(dtype), c.NI, c.WN, pw_ring_stages(a.K, c, dtype), a.gate ? "true" : "false", mi);
 }
 void small_kernel_name(int Cin, int k, int s, int dtype, int H, int W, char* buf, size_t n) {
     const int mbr = cdiv(H * W, 16), mpw = cdiv(mbr, (mbr <= 4 ? 256 : 512) / 64);

@@ -303,7 +303,7 @@ void stem_front_pack_weights(const float* w, int dtype, void* dst) {
     for (int n = 0; n < 40; ++n)
         for (int ci = 0; ci < 6; ++ci)
             for (int tap = 0; tap < 9; ++tap) m[(size_t)n * 72 + tap * 8 + ci] = w[((size_t)n * 6 + ci) * 9 + tap];
-    pw_pack_weights(m.data(), 72, 48, PwCfg{1, 1}, dtype, dst);        // [n-tile 3][k-block 4 (72 -> 3, padded to an even count)][lane][8]
+    pw_pack_weights(m.data(), 72, 48, PwCfg{1, 1}, dtype, dst, 1);        // [n-tile 3][k-block 4 (72 -> 3, padded to an even count)][lane][8]
 }
 // s0 / b0: folded stem BatchNorm (40); dww: block 0's depthwise taps [tap][40]; s1 / b1: its folded BatchNorm 1 (40)
 void stem_front_pack_params(const float* s0, const float* b0, const float* dww, const float* s1, const float* b1, float* dst) {

@@ -299,7 +299,9 @@ constexpr bool wave_interior_form(int ks, int s, int kbn, int ppl, int minw) { r
 #ifndef COSY_WAVE_WLDS
 #define COSY_WAVE_WLDS 1
 #endif
-constexpr bool wave_wlds(int kbn, int minw) { return (COSY_WAVE_WLDS && kbn >= 5 && minw >= 4) || kbn >= 9; }
+// (the argument counts weight FRAGMENTS per pixel fragment: k-blocks, x 2 for bf16's hi + lo pairs; 4 fragments at three waves per SIMD only exist there --
+// blocks 6 / 7 in bf16 spill with 16 weight registers)
+constexpr bool wave_wlds(int kbn, int minw) { return (COSY_WAVE_WLDS && kbn >= 5 && minw >= 4) || kbn >= 9 || (kbn == 4 && minw == 3); }
 
 template <typename T, int KS, int S, int KBN, int PPL, int NI, bool FULLW, int MINW>
 __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
@@ -313,10 +315,12 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     constexpr int NOPEN = (KS + S - 1) / S;                   // output rows that are accumulating at the same time
     constexpr int U = S * NOPEN;                              // input rows per unrolled super-iteration
     constexpr int PF = (4 + KS * KS) * 16 * NI;               // floats of the parameter block
-    constexpr bool WLDS = wave_wlds(KBN, MINW);               // expand-weight fragments parked in LDS instead of registers
+    constexpr int HL = __is_same(T, bf16_t) ? 2 : 1;          // bf16: the expand weights are hi + lo pairs (kernels_net.hip: pw_hl), two fragments per k-block
+    constexpr int NF = KBN * HL;                              // weight fragments (= MFMAs of the expansion chain) per pixel fragment
+    constexpr bool WLDS = wave_wlds(NF, MINW);                // expand-weight fragments parked in LDS instead of registers
     constexpr bool MX = wave_mx(sizeof(T), KS, S, PPL, FULLW);  // depthwise taps on the matrix pipe
     constexpr int PFX = 64 + 2 * KS * 128;                    // floats of the parameter block of that form
-    constexpr int PFW = (MX ? 0 : PF) + (WLDS ? NI * KBN * 256 : 0);
+    constexpr int PFW = (MX ? 0 : PF) + (WLDS ? NI * NF * 256 : 0);
     static_assert(PPL % S == 0, "a lane's pixel run must hold whole output pixels");
     typedef T out_t __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float smem_w[];
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     xfrag_reserve<MINW>();
     constexpr bool XASM = COSY_WAVE_XASM && sizeof(T) == 2;   // the MFMAs read the fragments in place (xfrag_mma)
     constexpr bool PIPE = COSY_WAVE_PIPE && MX && XASM && PPL == 1;       // matrix-pipe form: row iy's expansion side and row iy - 1's tap / output side in one iteration (row_mx)
-    raw_t wf[NI][KBN];                       // the chunk's expand-weight fragments (WLDS: parked in LDS instead)
+    raw_t wf[NI][NF];                        // the chunk's expand-weight fragments, [k-block][hi | lo] (WLDS: parked in LDS instead)
     f32x4 xc[XASM ? 1 : PPL][XASM ? 1 : KBN];
     int st_in_flight = 0;                    // stores issued behind the newest loads (wave-uniform)
     auto load_row = [&](int iy) {            // B fragments of input row iy: fragment q holds the lanes' pixels p*PPL + q
@@ -415,10 +419,10 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
         else asm volatile("s_waitcnt vmcnt(0) ; XWAIT" ::: "memory");
         if constexpr (XASM) {
             unroll_seq([&](auto ic) {
-                constexpr int i = decltype(ic)::value, q = i / KBN, kb = i % KBN;
-                if constexpr (WLDS) xfrag_mma<T, XTOP, i, kb == 0, MX>(mq[q], *(const raw_t*)(Wl + kb * 1024 + lane * 16));
-                else xfrag_mma<T, XTOP, i, kb == 0, MX>(mq[q], wf[0][kb]);
-            }, std::make_integer_sequence<int, PPL * KBN>{});
+                constexpr int i = decltype(ic)::value / HL, h = decltype(ic)::value % HL, q = i / KBN, kb = i % KBN, f = kb * HL + h;
+                if constexpr (WLDS) xfrag_mma<T, XTOP, i, f == 0, MX>(mq[q], *(const raw_t*)(Wl + f * 1024 + lane * 16));
+                else xfrag_mma<T, XTOP, i, f == 0, MX>(mq[q], wf[0][f]);
+            }, std::make_integer_sequence<int, PPL * KBN * HL>{});
             xfrag_mma_done(mq[PPL - 1]);
         }
         if constexpr (!XASM) {
@@ -445,14 +449,18 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     constexpr int NPL = MX ? 1 : (PF / 4 + 63) / 64;
     f32x4 pv[NPL];
     typedef T t4 __attribute__((ext_vector_type(4)));
-    t4 Af[MX ? KS : 1][2];                   // MX: Toeplitz fragments of the tap rows, [ky][quad | halo operand]
+    // operands of the tap MFMAs (matrix-pipe form): fp16 in BOTH 16-bit modes -- a register format between two MFMAs, not storage; bf16's 8 bits on the expanded
+    // values and on the taps were part of what kept it outside the pose bound (round 6; the oracle's emulation follows: front kind 5)
+    using TT = typename std::conditional<sizeof(T) == 2, f16_t, T>::type;
+    typedef TT tt4 __attribute__((ext_vector_type(4)));
+    tt4 Af[MX ? KS : 1][2];                   // MX: Toeplitz fragments of the tap rows, [ky][quad | halo operand]
     float mxp[4] = {0.f, 0.f, 0.f, 0.f};     // MX: s0, b0 of this lane's expansion channel (lane & 15), s1, b1 of its depthwise channel (lane >> 2)
     if (active) {
         if constexpr (MX) {
             const float* PP = a.wparams + (size_t)ch * PFX;
             mxp[0] = PP[lane & 15]; mxp[1] = PP[16 + (lane & 15)]; mxp[2] = PP[32 + (lane >> 2)]; mxp[3] = PP[48 + (lane >> 2)];
 #pragma unroll
-            for (int f = 0; f < 2 * KS; ++f) Af[f >> 1][f & 1] = *(const t4*)(PP + 64 + (f * 64 + lane) * 2);
+            for (int f = 0; f < 2 * KS; ++f) Af[f >> 1][f & 1] = *(const tt4*)(PP + 64 + (f * 64 + lane) * 2);
         } else {
             const f32x4* PP = (const f32x4*)(a.wparams + (size_t)ch * PF);
 #pragma unroll
@@ -462,8 +470,8 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-            for (int kb = 0; kb < KBN; ++kb)
-                wf[ni][kb] = *(const raw_t*)((const T*)a.Wp + ((size_t)(ch * NI + ni) * a.nkb_total + kb) * 64 * EPL + lane * EPL);
+            for (int f = 0; f < NF; ++f)
+                wf[ni][f] = *(const raw_t*)((const T*)a.Wp + (((size_t)(ch * NI + ni) * a.nkb_total + f / HL) * HL + f % HL) * 64 * EPL + lane * EPL);
         // -> the wave-private LDS block (no workgroup barrier: a wave reads only what it wrote itself, and LDS operations of one
         // wave execute in order)
         if constexpr (!MX) {
@@ -477,7 +485,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int kb = 0; kb < KBN; ++kb) *(raw_t*)(Wl + (ni * KBN + kb) * 1024 + lane * 16) = wf[ni][kb];
+                for (int f = 0; f < NF; ++f) *(raw_t*)(Wl + (ni * NF + f) * 1024 + lane * 16) = wf[ni][f];
         }
     }
     if (!active) return;
@@ -513,6 +521,9 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     for (int e = 0; e < 4; ++e) ident[e] = (T)(4 * kg + e == p ? 1.f : 0.f);
     auto cvt = [](float v) -> T {           // fp16 saturates (as to_f16_sat; one v_med3_f32)
         if constexpr (__is_same(T, f16_t)) return (T)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); else return (T)v;
+    };
+    auto cvt_e = [](float v) -> TT {        // the expanded values as tap operands: fp16, saturating
+        if constexpr (sizeof(T) == 2) return (TT)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); else return (TT)v;
     };
     out_t yv[TO][NI];                        // finished output row waiting for its store (issued one row later)
     int oy_pending = -1;
@@ -556,7 +567,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
             WAVE_STAMP_ROW();
             f32x4 mq[XASM ? PPL : 1];
             wait_row(mq);
-            t4 W1[MX ? PPL : 1], W2[MX ? PPL : 1];      // MX: the row's operands of the tap MFMAs, per 16-pixel segment
+            tt4 W1[MX ? PPL : 1], W2[MX ? PPL : 1];      // MX: the row's operands of the tap MFMAs, per 16-pixel segment
             if constexpr (MX) {
                 if (IN || iy < a.H) {
                     int lo[PPL], hi[PPL];
@@ -567,17 +578,17 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
                         if constexpr (XASM) m = mq[q];
                         else {
 #pragma unroll
-                            for (int kb = 0; kb < KBN; ++kb) {
-                                raw_t xv = __builtin_bit_cast(raw_t, xc[q][kb]);
-                                if constexpr (WLDS) mma(m, xv, *(const raw_t*)(Wl + kb * 1024 + lane * 16));
-                                else mma(m, xv, wf[0][kb]);
+                            for (int f = 0; f < NF; ++f) {
+                                raw_t xv = __builtin_bit_cast(raw_t, xc[q][f / HL]);
+                                if constexpr (WLDS) mma(m, xv, *(const raw_t*)(Wl + f * 1024 + lane * 16));
+                                else mma(m, xv, wf[0][f]);
                             }
                         }
                         float y4[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) y4[e] = m[e] * mxp[0] + mxp[1];
                         if (!COSY_DBG(a.dbg & 512)) silu4<false>(y4);      // dbg 512: no SiLU (timing)
-                        const t4 hv = t4{cvt(y4[0]), cvt(y4[1]), cvt(y4[2]), cvt(y4[3])};      // E in the storage type, as the unfused kernels store it
+                        const tt4 hv = tt4{cvt_e(y4[0]), cvt_e(y4[1]), cvt_e(y4[2]), cvt_e(y4[3])};      // E as the tap MFMAs' operand (fp16)
                         const i32x2 hh = __builtin_bit_cast(i32x2, hv);
                         lo[q] = hh[0]; hi[q] = hh[1];
                         if (!COSY_DBG(a.dbg & 128)) { lo[q] = __builtin_amdgcn_ds_bpermute(bp_in, hh[0]); hi[q] = __builtin_amdgcn_ds_bpermute(bp_in, hh[1]); }   // dbg 128: no lane permutation (timing)
@@ -593,7 +604,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
                             if (q < PPL - 1) ln3 = __builtin_amdgcn_update_dpp(0, lo[q < PPL - 1 ? q + 1 : 0], 0x39, 0xf, 0xf, false);   // quad_perm [1,2,3,0]
                         }
                         hp = jq == 0 ? hp0 : hp; ln = jq == 3 ? ln3 : ln;
-                        W1[q] = __builtin_bit_cast(t4, i32x2{lo[q], hi[q]}); W2[q] = __builtin_bit_cast(t4, i32x2{hp, ln});
+                        W1[q] = __builtin_bit_cast(tt4, i32x2{lo[q], hi[q]}); W2[q] = __builtin_bit_cast(tt4, i32x2{hp, ln});
                     }
                 }
             } else
@@ -609,10 +620,10 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
                         if constexpr (XASM) m = mq[q];
                         else {
 #pragma unroll
-                            for (int kb = 0; kb < KBN; ++kb) {
-                                raw_t xv = __builtin_bit_cast(raw_t, xc[q][kb]);
-                                if constexpr (WLDS) mma(m, *(const raw_t*)(Wl + (ni * KBN + kb) * 1024 + lane * 16), xv);
-                                else mma(m, wf[ni][kb], xv);
+                            for (int f = 0; f < NF; ++f) {
+                                raw_t xv = __builtin_bit_cast(raw_t, xc[q][f / HL]);
+                                if constexpr (WLDS) mma(m, *(const raw_t*)(Wl + (ni * NF + f) * 1024 + lane * 16), xv);
+                                else mma(m, wf[ni][f], xv);
                             }
                         }
                         float y4[4];
@@ -755,7 +766,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     // (hipcc's schedule; rows at the job's and the map's edges: every part behind a wave-uniform condition); row_px below is the interior form, every instruction
     // of it placed by hand.  Measured (profiles/r06_wave_rows.txt): row to row alone on a SIMD 1581 -> 1102 cycles (blocks 14-17) / 1333 -> 1004 (block 13), at four
     // waves per SIMD 2323 -> 1931; results bit-identical to the unpipelined form (profiles/exp/ab_bits.py).
-    t4 W1p[PIPE ? PPL : 1], W2p[PIPE ? PPL : 1];
+    tt4 W1p[PIPE ? PPL : 1], W2p[PIPE ? PPL : 1];
     bool prev_fused = false;      // the previous iteration was the fused form (row_px)
     auto row_mx = [&](auto uc, auto inc, const int base) {
         if constexpr (PIPE) {
@@ -764,7 +775,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
             const int iy = base + u, ip = iy - 1;
             const bool doA = IN || (iy >= iy_first && iy <= iy_last), doB = IN || (ip >= iy_first && ip <= iy_last);
             if constexpr (!IN) { if (!doA && !doB) return; }
-            t4 W1n[PPL], W2n[PPL];
+            tt4 W1n[PPL], W2n[PPL];
             if constexpr (!IN) {
                 // behind a fused iteration (row_px, which starts a new output row with SrcC = 0 and never resets): the accumulator slot this iteration's first tap row
                 // adds into still holds the output row the fused iteration finished
@@ -835,7 +846,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) y4[e] = mq[q][e] * mxp[0] + mxp[1];
                         if (!COSY_DBG(a.dbg & 512)) silu4p<false>(y4);
-                        const t4 hv = t4{cvt(y4[0]), cvt(y4[1]), cvt(y4[2]), cvt(y4[3])};
+                        const tt4 hv = tt4{cvt_e(y4[0]), cvt_e(y4[1]), cvt_e(y4[2]), cvt_e(y4[3])};
                         const i32x2 hh = __builtin_bit_cast(i32x2, hv);
                         lo[q] = hh[0]; hi[q] = hh[1];
                         if (!COSY_DBG(a.dbg & 128)) { lo[q] = __builtin_amdgcn_ds_bpermute(bp_in, hh[0]); hi[q] = __builtin_amdgcn_ds_bpermute(bp_in, hh[1]); }
@@ -850,7 +861,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
                             if (q < PPL - 1) ln3 = __builtin_amdgcn_update_dpp(0, lo[q < PPL - 1 ? q + 1 : 0], 0x39, 0xf, 0xf, false);   // quad_perm [1,2,3,0]
                         }
                         hp = jq == 0 ? hp0 : hp; ln = jq == 3 ? ln3 : ln;
-                        W1n[q] = __builtin_bit_cast(t4, i32x2{lo[q], hi[q]}); W2n[q] = __builtin_bit_cast(t4, i32x2{hp, ln});
+                        W1n[q] = __builtin_bit_cast(tt4, i32x2{lo[q], hi[q]}); W2n[q] = __builtin_bit_cast(tt4, i32x2{hp, ln});
                     }
                 }
             }
@@ -884,31 +895,31 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
             // ---- taps of row iy - 1: tap row ky feeds output row ip + LO - ky (accumulator slot compile-time); ky = KS - 1 first: that row is complete behind its pair
             unroll_seq([&](auto kc) {
                 constexpr int ky = KS - 1 - decltype(kc)::value, os = ((up + LO - ky) % NOPEN + NOPEN) % NOPEN;
-                if constexpr (ky == 0) px_tap0<T>(accx[os][0], Af[ky][0], W1p[0]); else px_tap<T>(accx[os][0], Af[ky][0], W1p[0]);
+                if constexpr (ky == 0) px_tap0<TT>(accx[os][0], Af[ky][0], W1p[0]); else px_tap<TT>(accx[os][0], Af[ky][0], W1p[0]);
             }, std::make_integer_sequence<int, KS>{});
             unroll_seq([&](auto kc) {
                 constexpr int ky = KS - 1 - decltype(kc)::value, os = ((up + LO - ky) % NOPEN + NOPEN) % NOPEN;
-                px_tap<T>(accx[os][0], Af[ky][1], W2p[0]);
+                px_tap<TT>(accx[os][0], Af[ky][1], W2p[0]);
             }, std::make_integer_sequence<int, KS>{});
             xfrag_fence<XTOP, PPL * KBN>();
             asm volatile("s_waitcnt vmcnt(1) ; XWAIT" ::: "memory");
             // ---- expansion chain with the output side's first steps in its shadow
             f32x4 macc;
             float yo[4], to[4], ye[4], te[4];
-            unroll_seq([&](auto kc) {
-                constexpr int kb = decltype(kc)::value;
+            unroll_seq([&](auto fc) {
+                constexpr int f = decltype(fc)::value;           // link f of the chain: k-block f / HL (bf16: its hi, then its lo weight fragment)
                 if constexpr (WLDS) {
-                    // fragments in flight at this point: kb .. min(kb + 2, KBN - 1)
-                    px_lgkm<(kb + 2 < KBN ? 2 : KBN - 1 - kb)>();
-                    px_mma<T, XTOP, kb, kb == 0>(macc, wb[kb % 3]);
-                    if constexpr (kb + 3 < KBN) px_wread<(kb + 3) * 1024>(wb[kb % 3], wl_addr);
-                } else px_mma<T, XTOP, kb, kb == 0>(macc, wf[0][kb]);
-                if constexpr (kb == 0) { if constexpr (KS == 3) px_nop<1>(); px_bn(yo, accx[od][0], mxp[2], mxp[3]); }
-                if constexpr (kb == 1) px_silu_a(yo, to);
-                if constexpr (kb == 2) px_silu_b(to);
-                if constexpr (kb == 3) px_silu_c(to);
-            }, std::make_integer_sequence<int, KBN>{});
-            if constexpr (KBN <= 3) px_silu_c(to);
+                    // fragments in flight at this point: f .. min(f + 2, NF - 1)
+                    px_lgkm<(f + 2 < NF ? 2 : NF - 1 - f)>();
+                    px_mma<T, XTOP, f / HL, f == 0>(macc, wb[f % 3]);
+                    if constexpr (f + 3 < NF) px_wread<(f + 3) * 1024>(wb[f % 3], wl_addr);
+                } else px_mma<T, XTOP, f / HL, f == 0>(macc, wf[0][f]);
+                if constexpr (f == 0) { if constexpr (KS == 3) px_nop<1>(); px_bn(yo, accx[od][0], mxp[2], mxp[3]); }
+                if constexpr (f == 1) px_silu_a(yo, to);
+                if constexpr (f == 2) px_silu_b(to);
+                if constexpr (f == 3) px_silu_c(to);
+            }, std::make_integer_sequence<int, NF>{});
+            if constexpr (NF <= 3) px_silu_c(to);
             px_silu_d(to);
             load_row(iy + 1);                        // row iy's fragments are consumed: the next row's loads (they return long after the last link has read its operands)
             px_silu_e(yo, to);
@@ -924,7 +935,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
             px_silu_d(te);
             px_silu_e(ye, te);                   // (the first reciprocal is three instructions old)
             int pe0, pe1, w1lo, w1hi;
-            px_cvt<T>(pe0, pe1, ye, -65504.f, 65504.f);
+            px_cvt<TT>(pe0, pe1, ye, -65504.f, 65504.f);
             px_bperm2(w1lo, w1hi, bp_in, pe0, pe1);
             // ---- the output row: transposed back to (pixel, 4 channels), stored; the next taps' operands under the transposition's latency
             px_lgkm<2>();
@@ -936,7 +947,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
             px_nop<3>();
             px_cvt_store<T>(tr, d_voff, (const T*)D_chunk + (size_t)oy * drow);
             st_in_flight = 1;
-            W1p[0] = __builtin_bit_cast(t4, i32x2{w1lo, w1hi}); W2p[0] = __builtin_bit_cast(t4, i32x2{hp, ln});
+            W1p[0] = __builtin_bit_cast(tt4, i32x2{w1lo, w1hi}); W2p[0] = __builtin_bit_cast(tt4, i32x2{hp, ln});
             prev_fused = true;
         }
     };
@@ -1111,7 +1122,7 @@ void wave_pack_params(const float* s0, const float* b0, const float* dww, const 
                             const int i = lane & 3, cc = ch * 16 + (lane >> 2), kx = off[m][q] - i + lo;
                             float w = 0.f;
                             if (kx >= 0 && kx < k) w = dww[(size_t)(p.transposed ? kx * k + ky : ky * k + kx) * Cmid + cc];
-                            a[(((size_t)ky * 2 + m) * 64 + lane) * 4 + q] = dtype == COSY_BF16 ? wave_bf16_bits(w) : wave_f16_bits(w);
+                            a[(((size_t)ky * 2 + m) * 64 + lane) * 4 + q] = wave_f16_bits(w);      // fp16 in both 16-bit modes (the tap MFMAs' operand type)
                         }
         }
         return;
@@ -1153,7 +1164,8 @@ void wave_kernel_name(int Cin, int Cmid, int k, int s, int dtype, int H, int W, 
 
 template <typename T, int KS, int S, int KBN, int PPL, int NI, bool FW, int MW, int RSP>
 static int launch_wave_k(WaveKArgs k, int* n_tiles_out, hipStream_t s) {
-    size_t lds = (size_t)4 * ((wave_mx(sizeof(T), KS, S, PPL, FW) ? 0 : (4 + KS * KS) * 16 * NI * sizeof(float)) + (wave_wlds(KBN, MW) ? NI * KBN * 1024 : 0));
+    constexpr int HL = __is_same(T, bf16_t) ? 2 : 1;      // bf16: hi + lo weight fragments
+    size_t lds = (size_t)4 * ((wave_mx(sizeof(T), KS, S, PPL, FW) ? 0 : (4 + KS * KS) * 16 * NI * sizeof(float)) + (wave_wlds(KBN * HL, MW) ? NI * KBN * HL * 1024 : 0));
     k.dbg = tune_int("COSY_WAVE_DBG", 0);
     k.stamps = nullptr; k.stamp_stride = 1; k.stamp_slots = 0;
 #ifdef COSY_TUNE

@@ -466,7 +466,7 @@ class TorchRef:
     # bf16 (round 6): the 1x1-conv WEIGHTS are error-compensated pairs -- hi = bf16(w), lo = bf16(w - hi), two MFMAs per fragment against the same
     # activation fragment, fp32 accumulation -- so what multiplies the activations is hi + lo (16 significant bits); the depthwise taps and the expanded
     # values of the matrix-pipe fronts (kinds 5 / 6) are fp16 operands in EVERY 16-bit mode (the small MFMA's operands are a register format, not storage).
-    hilo = False         # True: bf16 weights as hi + lo pairs (set together with the kernels that implement them)
+    hilo = True          # False: bf16 weights as single 8-bit values (the library before round 6)
 
     def _rndw(self, t, storage):
         if storage == 'bf16' and self.hilo:

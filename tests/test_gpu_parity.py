@@ -239,15 +239,16 @@ def test_fused_kernels_vs_storage_emulation(model, oracle, golden_sd, dtype, hw)
     x = np.random.RandomState(40 + hw[0]).random_sample((B, 6) + tuple(hw)).astype(np.float32)
     h, plan = _block_plan(model, hw, dtype, B)
     kinds = [p[7] for p in plan]
+    pairs = dtype == 'bf16'      # bf16: hi + lo weight pairs (round 6) in the GEMM and the wave fronts; the whole-image and the tiled fronts do not carry them: their blocks run unfused
     assert (kinds[0] == 4) == (hw[1] in (256, 320)), kinds       # the stem + block-0 front: 256- and 320-pixel-wide crops (kernels_stem.hip), the unfused kernels elsewhere
     if hw in ((256, 256), (240, 320)):     # blocks 2-17 wave (240x320: block 2's 160-pixel rows are walked as 120-pixel columns), 19-25 small
-        assert all(k in (1, 5) for k in kinds[2:18]) and all(k == (6 if hw == (256, 256) else 2) for k in kinds[19:26]) and kinds[18] == 0, kinds      # 6: the small kernel's matrix-pipe form (8x8 maps)
+        assert all(k in (1, 5) for k in kinds[2:18]) and all(k == (0 if pairs else 6 if hw == (256, 256) else 2) for k in kinds[19:26]) and kinds[18] == 0, kinds      # 6: the small kernel's matrix-pipe form (8x8 maps)
         # 5 = the wave kernel with its depthwise taps on the matrix pipe (stride-1 blocks whose rows are whole 16-pixel segments: 3, 4, 6, 7, 9-17 at 256x256)
         assert [i for i, k in enumerate(kinds) if k == 5] == ([3, 4, 6, 7] + list(range(9, 18)) if hw == (256, 256) else [3, 4]), kinds      # 240x320: the 80-pixel rows of blocks 3 / 4
     if hw == (224, 224):                   # 56-pixel rows of blocks 3 / 4: no wave variant -> tiled; every other front has a !FULLW wave variant
-        assert [i for i, k in enumerate(kinds) if k == 3] == [3, 4] and [i for i, k in enumerate(kinds) if k == 1] == [2] + list(range(5, 18)), kinds
+        assert [i for i, k in enumerate(kinds) if k == 3] == ([] if pairs else [3, 4]) and [i for i, k in enumerate(kinds) if k == 1] == [2] + list(range(5, 18)), kinds
     if hw == (416, 416):                   # 208 / 104-pixel rows: the tiled kernel in all its k / stride forms (k3 s2, k3 s1, k5 s2)
-        assert [i for i, k in enumerate(kinds) if k == 3] == [2, 3, 4, 5] and [i for i, k in enumerate(kinds) if k == 1] == list(range(8, 18)), kinds
+        assert [i for i, k in enumerate(kinds) if k == 3] == ([] if pairs else [2, 3, 4, 5]) and [i for i, k in enumerate(kinds) if k == 1] == list(range(8, 18)), kinds
     from cosypose_amd._lib import lib, check, ptr, stream
     check(lib().cosy_effnet_b3_set_input_nchw(h, ptr(dev(x)), B, stream()))
     tr = oracle.TorchRef(golden_sd)
@@ -288,7 +289,7 @@ def test_fused_kernels_vs_storage_emulation(model, oracle, golden_sd, dtype, hw)
         golden = dict(np.load(os.path.join(os.path.dirname(__file__), 'golden', 'reference_golden.npz')))
         fe2, pe2 = rel_err(feat2, golden[f'bb_{name}_feat']), rel_err(pose2, golden[f'bb_{name}_pose'])
         print(f'{dtype} {hw}: deviation from the reference fp32: features {fe2:.2e}, pose9 {pe2:.2e}')
-        assert fe2 < (1.7e-2 if dtype == 'bf16' else 2.6e-3) and pe2 < (1.6e-4 if dtype == 'bf16' else 3e-5)
+        assert fe2 < (1.7e-2 if dtype == 'bf16' else 2.6e-3) and pe2 < (6e-5 if dtype == 'bf16' else 3e-5)      # bf16 with weight pairs: 8-bit activations only (1.6e-4 before round 6)
     model.compute_dtype = 'fp32'; model.render_size = (240, 320)
 
 
@@ -350,8 +351,8 @@ def test_refiner_loop_low_precision(model, oracle, golden, golden_sd, labels21, 
     print(f'{dtype}: refined poses after {n_it} iterations: vs emulation R {r_e:.2e} t {t_e:.2e}; vs reference fp32 R {r_f:.2e} t {t_f:.2e}')
     # (the emulated LOOP decorrelates from the device with depth like any second evaluation does: reported, loosely bounded;
     # the tight kernel check is block-local, test_fused_kernels_vs_storage_emulation)
-    assert max(r_e, t_e) < (1e-4 if dtype == 'fp16' else 3e-4)
-    assert max(r_f, t_f) < (1e-4 if dtype == 'fp16' else 3e-4)        # bf16: 3x the measured 9.2e-5
+    assert max(r_e, t_e) < 1e-4
+    assert max(r_f, t_f) < 1e-4        # both 16-bit modes inside north_star's bound (bf16 since round 6: hi + lo weight pairs)
 
 
 def test_backbone_module_api(model, oracle, golden_sd):
@@ -494,9 +495,9 @@ def headline_oracle(oracle, golden_sd, mesh_table):
 
 # north_star: "<= 1e-4 relative on pose parameters".  fp32 is the reference's own arithmetic; fp16 is the headline
 # (benched) storage type and is held to the same bound, per parameter group and per crop (conftest.pose_errors /
-# rows_rel_err); bf16 cannot meet it (8 significant bits: every stored activation AND weight carries 2e-3 relative
-# rounding) and is kept as a throughput mode, asserted at <= 3x its measured deviation.
-@pytest.mark.parametrize('dtype,tol', [('fp32', NET_TOL), ('fp16', NET_TOL), ('bf16', 4.5e-4)])     # bf16: 3x the measured 1.4e-4
+# rows_rel_err); bf16 (the type configs[1] names) is held to it too since round 6: its 1x1-conv weights are hi + lo pairs (two MFMAs per
+# fragment), the tap MFMAs' operands fp16 -- what is left of its 8 significant bits sits on the stored activations only.
+@pytest.mark.parametrize('dtype,tol', [('fp32', NET_TOL), ('fp16', NET_TOL), ('bf16', NET_TOL)])
 def test_headline_config_vs_oracle(model, oracle, golden_sd, mesh_table, labels21, headline_oracle, dtype, tol):
     """BASELINE configs[1]'s shape (256x256 crops, 512x512 frames, coarse 1 + refiner 4, the bench's own detections): every
     iteration's poses / crop cameras / boxes against the fp32 oracle loop, per parameter group; the 16-bit modes also against
@@ -670,7 +671,7 @@ def test_headline_schedule_is_bit_identical(model, oracle, golden_sd, mesh_table
             r, t = pose_errors(got.poses.cpu().numpy(), want_oracle['TCO_output'])
             kc = rows_rel_err(got.K_crop.cpu().numpy(), want_oracle['K_crop'])
             print(f'benched schedule, {dtype}, coarse iteration vs fp32 oracle: R {r:.2e} t {t:.2e} K_crop {kc:.2e}')
-            tol = NET_TOL if dtype == 'fp16' else 4.5e-4
+            tol = NET_TOL
             assert r < tol and t < tol and kc < NET_TOL, (dtype, r, t, kc)
 
 
