@@ -49,6 +49,8 @@ _SIGNATURES = {
     'cosy_render_crop_pack_to': ([_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P], _I),
     'cosy_train_workspace_bytes': ([], _c.c_size_t),
     'cosy_crop_pack_to': ([_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P], _I),
+    'cosy_crop_pack_to_ws': ([_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P], _I),
+    'cosy_crop_pack_workspace_bytes': ([_I, _I, _I], _SZ),
     'cosy_bn_train_stats': ([_P, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P], _I),
     'cosy_bn_train_apply': ([_P, _P, _P, _P, _P, _L, _I, _I, _P, _I, _P, _P, _P], _I),
     'cosy_bn_train_backward': ([_P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P], _I),

@@ -256,6 +256,7 @@ __device__ __forceinline__ float axis_weight(const AxisTaps& t, int q) {
 // (validity, clamping and weights factor per axis), so the pixel is a (<= 6 x 6) window of frame pixels weighted by
 // the per-axis tap sums: 9-16 16-byte loads instead of 64 taps x 3 channels.  Falls back to the sample loop for
 // huge bins.  Mathematically identical to the reference sum; fp32 rounding differs at the 1e-7 level.
+template <bool WINDOW4 = true>
 __device__ __forceinline__ void roi_pixel_nhwc4(const f32x4* __restrict__ img, int h, int w, float x1, float y1, float bin_h,
                                                 float bin_w, int ph, int pw, float* acc) {
     AxisTaps ty, tx;
@@ -263,7 +264,9 @@ __device__ __forceinline__ void roi_pixel_nhwc4(const f32x4* __restrict__ img, i
     axis_taps(x1, bin_w, pw, w, tx);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     if (ty.last >= 0 && tx.last >= 0) {
-        if (ty.last - ty.first < 4 && tx.last - tx.first < 4) {
+        // WINDOW4 = false (the tiled kernel's rare fallback): windows of up to 4x4 take the row loop below -- the same weights in the
+        // same order, 64 fewer live registers
+        if (WINDOW4 && ty.last - ty.first < 4 && tx.last - tx.first < 4) {
             // common case (bins up to ~2.6 frame pixels): a 4x4 window, all 16 loads issued back to back so that their
             // latencies overlap; positions past `last` carry weight 0 and read a clamped (valid) address
             float ax[4], ay[4];
@@ -287,6 +290,19 @@ __device__ __forceinline__ void roi_pixel_nhwc4(const f32x4* __restrict__ img, i
                     const float wgt = ay[r] * ax[d];
                     a0 += wgt * p[r][d][0]; a1 += wgt * p[r][d][1]; a2 += wgt * p[r][d][2];
                 }
+        } else if (!WINDOW4 && ty.last - ty.first < 6 && tx.last - tx.first < 6) {
+            // rolled twin of the branch below (same weights, same order)
+#pragma unroll 1
+            for (int Y = ty.first; Y <= ty.last; ++Y) {
+                const float ay = axis_weight(ty, Y);
+                const f32x4* row = img + (size_t)Y * w;
+#pragma unroll 1
+                for (int X = tx.first; X <= tx.last; ++X) {
+                    const f32x4 p = row[X];
+                    const float wgt = ay * axis_weight(tx, X);
+                    a0 += wgt * p[0]; a1 += wgt * p[1]; a2 += wgt * p[2];
+                }
+            }
         } else if (ty.last - ty.first < 6 && tx.last - tx.first < 6) {
             float ax[6];
 #pragma unroll
@@ -432,6 +448,138 @@ __global__ __launch_bounds__(256) void crop_pack_kernel(T* __restrict__ x, const
     store_px8<T>(x + ((size_t)b * PH * PW + pix) * 8, v);
 }
 
+// ----------------------------------------------------------------------------------------
+// Tiled crop + pack (round 6): the frame window under an output tile goes through the LDS.
+// crop_pack_kernel gathers every output pixel's 2x2 .. 4x4 window straight from the frame: 9-16 sixteen-byte gathers per
+// pixel whose addresses repeat between neighbouring lanes and rows (a crop that magnifies its box reads every frame pixel
+// ~20 times), behind a dependent table load -- the launch is bound by the vector-memory address path and by two memory
+// latencies per pixel, not by bytes.  Here a workgroup owns a tile of 16 output rows x 64 columns (wave = 4 rows, lane =
+// column): the tile's frame window -- rows / columns [first, first + span] of the tile's tap entries -- is loaded ONCE,
+// coalesced, into the LDS, and every window position is then an LDS read.  Same tap tables, same weights, same order of
+// the sum as roi_pixel_table -> bit-identical results.  Tiles whose window does not fit (bins above ~1.2 frame pixels) are
+// walked in 2 or 4 passes of fewer rows; tap entries wider than 4 pixels (bins above ~2.6) take the per-pixel path.
+// ----------------------------------------------------------------------------------------
+constexpr int CROP_TW = 64, CROP_TH = 16, CROP_LDS_PX = 2048;      // 32 KB of frame pixels (fp32 RGB + pad) per workgroup
+__device__ __forceinline__ int wave_min_i(int v) {
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+template <typename T>
+__global__ __launch_bounds__(256, 4) void crop_pack_tile_kernel(T* __restrict__ x, const float* __restrict__ frames4,
+                                                                const int* __restrict__ im_id, const float* __restrict__ boxes,
+                                                                const float* __restrict__ renders, const CropTap* __restrict__ taps, int B, int h,
+                                                                int w, int PH, int PW) {
+    __shared__ f32x4 tile[CROP_LDS_PX];
+    const int tcols = (PW + CROP_TW - 1) / CROP_TW, tpc = tcols * ((PH + CROP_TH - 1) / CROP_TH);
+    // XCD-aware order as in crop_pack_kernel: all tiles of one crop on one XCD (one L2 holds the frame region under its box)
+    const int id = blockIdx.x, xcd = id & 7, j = id >> 3, b = (j / tpc) * 8 + xcd;
+    if (b >= B) return;
+    const int t = j % tpc, tr = t / tcols, tc = t - tr * tcols;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: the rows' tap entries come by scalar loads
+    const int pw = tc * CROP_TW + lane;
+    const bool colok = pw < PW;
+    const f32x4* img = (const f32x4*)frames4 + (size_t)(im_id ? im_id[b] : b) * h * w;
+    const CropTap* tb = taps + (size_t)b * (PH + PW);
+    const CropTap tx = tb[PH + min(pw, PW - 1)];
+    // the tile's columns of the frame: [xf, xl] over the valid entries (the same in every wave of the workgroup).  (Extents derived from the box
+    // instead -- a superset with a pixel of margin, so that the window's loads wait for no tap entry -- were measured SLOWER: 206 vs 180 us per
+    // launch, the margins push more tiles over the LDS budget into two passes; profiles/r06_crop_tiled.txt)
+    const bool xvalid = colok && tx.span >= 0;
+    const int xf = wave_min_i(xvalid ? tx.first : 0x7fffffff), xl = wave_max_i(xvalid ? tx.first + tx.span : -1);
+    const bool xwide = __ballot(colok && tx.span >= 4) != 0;        // entries wider than 4 pixels: per-pixel path
+    const int ncols = xl - xf + 1;
+    const float* bx = boxes + (size_t)b * 4;
+    const float bin_h = fmaxf(bx[3] - bx[1], 1.f) / (float)PH;
+    // passes: the fewest of 1 / 2 / 4 whose rows' window is expected to fit (checked per pass against the real entries)
+    int np = 1;
+    while (np < 4 && ((int)((float)(CROP_TH / np) * bin_h) + 5) * ncols > CROP_LDS_PX) np *= 2;
+    const int rp = CROP_TH / np, rpw = rp / 4;                      // rows per pass, rows per wave and pass (4 / 2 / 1)
+    const size_t HW = (size_t)PH * PW;
+    for (int p = 0; p < np; ++p) {
+        const int row0 = tr * CROP_TH + p * rp;                     // first output row of the pass
+        if (row0 >= PH) break;
+        // the pass's rows of the frame
+        const int rq = row0 + lane;
+        const bool rok = lane < rp && rq < PH;
+        const CropTap tq = tb[min(rq, PH - 1)];
+        const bool yvalid = rok && tq.span >= 0;
+        const int yf = wave_min_i(yvalid ? tq.first : 0x7fffffff), yl = wave_max_i(yvalid ? tq.first + tq.span : -1);
+        const bool ywide = __ballot(rok && tq.span >= 4) != 0;
+        const int nrows = yl - yf + 1;
+        const bool any = xl >= 0 && yl >= 0;                        // else: no valid sample in the pass -> zeros
+        const bool fits = any && nrows * ncols <= CROP_LDS_PX;
+        // this lane's pixels: rows ph0 .. ph0 + rpw - 1 of column pw; their tap entries and render channels are requested first
+        const int ph0 = row0 + wv * rpw;
+        float rv[4][3];
+        CropTap tys[4];
+        const bool slow = any && (!fits || xwide || ywide);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < rpw && ph0 + i < PH) {
+                tys[i] = tb[ph0 + i];
+                if (colok) {
+                    const float* r = renders + (size_t)b * 3 * HW + (size_t)(ph0 + i) * PW + pw;
+                    rv[i][0] = r[0]; rv[i][1] = r[HW]; rv[i][2] = r[2 * HW];
+                }
+            }
+        if (p) __syncthreads();                                     // the previous pass's reads of the tile
+        if (fits) {
+            for (int r = wv; r < nrows; r += 4) {
+                const f32x4* src = img + (size_t)(yf + r) * w + xf;
+                for (int c = lane; c < ncols; c += 64) tile[r * ncols + c] = src[c];
+            }
+        }
+        __syncthreads();
+        if (slow) {
+            // rare: tap entries wider than 4 pixels or a window beyond the LDS tile -> the per-pixel path (rolled: its code is large)
+#pragma unroll 1
+            for (int i = 0; i < rpw; ++i) {
+                const int ph = ph0 + i;
+                if (ph >= PH || !colok) break;
+                float v[6];
+                roi_pixel_nhwc4<false>(img, h, w, bx[0], bx[1], bin_h, fmaxf(bx[2] - bx[0], 1.f) / (float)PW, ph, pw, v);
+                const float* r = renders + (size_t)b * 3 * HW + (size_t)ph * PW + pw;
+                v[3] = r[0]; v[4] = r[HW]; v[5] = r[2 * HW];
+                store_px8<T>(x + ((size_t)b * HW + (size_t)ph * PW + pw) * 8, v);
+            }
+            continue;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ph = ph0 + i;
+            if (i >= rpw || ph >= PH) break;                        // wave-uniform
+            const CropTap ty = tys[i];
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            if (any && ty.span >= 0 && xvalid) {
+                int ox[4], oy[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) { ox[d] = min(tx.first + d, xl) - xf; oy[d] = (min(ty.first + d, yl) - yf) * ncols; }
+                const int rows = ty.span + 1;                       // wave-uniform; positions past an entry's span carry weight 0
+                const int cols = __ballot(tx.span > 2 && xvalid) ? 4 : __ballot(tx.span > 1 && xvalid) ? 3 : 2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < rows) {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d)
+                            if (d < cols) {
+                                const f32x4 q = tile[oy[r] + ox[d]];
+                                const float wgt = ty.w[r] * tx.w[d];
+                                a0 += wgt * q[0]; a1 += wgt * q[1]; a2 += wgt * q[2];
+                            }
+                    }
+            }
+            if (colok) {
+                const float v[6] = {a0 / 16.f, a1 / 16.f, a2 / 16.f, rv[i][0], rv[i][1], rv[i][2]};
+                store_px8<T>(x + ((size_t)b * HW + (size_t)ph * PW + pw) * 8, v);
+            }
+        }
+    }
+}
+
 // render + crop + pack: the rasteriser's resolve pass and the crop in one kernel (one 16-byte store per pixel)
 template <typename T>
 __global__ __launch_bounds__(256) void render_crop_pack_kernel(T* __restrict__ x, const float* __restrict__ frames4,
@@ -477,8 +625,13 @@ int launch_crop_pack(void* x, int dtype, const float* frames4, const int* im_id,
     int rc;
     if (taps_ws && (rc = launch_crop_taps(boxes, B, h, w, H, W, taps_ws, s))) return rc;
     dim3 grid((unsigned)(cdiv(H * W, 256) * cdiv(B, 8) * 8));
-    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(crop_pack_kernel<T>, grid, dim3(256), 0, s, (T*)x, frames4, im_id, boxes, renders,
-                                                 (const CropTap*)taps_ws, B, h, w, H, W, tune_int("COSY_CROP_DBG", 0)));
+    if (taps_ws && tune_int("COSY_CROP_TILED", 1)) {
+        dim3 tgrid((unsigned)(cdiv(W, CROP_TW) * cdiv(H, CROP_TH) * cdiv(B, 8) * 8));
+        COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(crop_pack_tile_kernel<T>, tgrid, dim3(256), 0, s, (T*)x, frames4, im_id, boxes, renders,
+                                                     (const CropTap*)taps_ws, B, h, w, H, W));
+    } else
+        COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(crop_pack_kernel<T>, grid, dim3(256), 0, s, (T*)x, frames4, im_id, boxes, renders,
+                                                     (const CropTap*)taps_ws, B, h, w, H, W, tune_int("COSY_CROP_DBG", 0)));
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }

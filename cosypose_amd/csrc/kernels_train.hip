@@ -1225,6 +1225,13 @@ int cosy_crop_pack_to(void* x_nhwc8, int dtype, const float* frames_nhwc4, const
     COSY_REQUIRE(dtype == COSY_F32 || dtype == COSY_BF16 || dtype == COSY_F16, "crop_pack_to: dtype %d", dtype);
     return launch_crop_pack(x_nhwc8, dtype, frames_nhwc4, im_id, boxes_crop, renders, B, N, h, w, H, W, nullptr, (hipStream_t)stream);
 }
+size_t cosy_crop_pack_workspace_bytes(int B, int H, int W) { return crop_taps_bytes(B > 0 ? B : 0, H, W); }
+int cosy_crop_pack_to_ws(void* x_nhwc8, int dtype, const float* frames_nhwc4, const int* im_id, const float* boxes_crop,
+                         const float* renders, int B, int N, int h, int w, int H, int W, void* workspace, cosy_stream_t stream) {
+    COSY_REQUIRE(x_nhwc8 && frames_nhwc4 && boxes_crop && renders && workspace, "crop_pack_to_ws: null argument");
+    COSY_REQUIRE(dtype == COSY_F32 || dtype == COSY_BF16 || dtype == COSY_F16, "crop_pack_to_ws: dtype %d", dtype);
+    return launch_crop_pack(x_nhwc8, dtype, frames_nhwc4, im_id, boxes_crop, renders, B, N, h, w, H, W, workspace, (hipStream_t)stream);
+}
 
 int cosy_bn_train_stats(const float* x, long M, int C, float eps, float momentum, float* mean, float* rstd, float* running_mean,
                         float* running_var, void* workspace, cosy_stream_t stream) {

@@ -45,6 +45,7 @@ struct WaveKArgs {
     int ds_pix, ds_row;      // elements between two neighbouring pixels of a row / between two rows inside a D chunk
     // -DCOSY_TUNE only (null in the shipping library): s_memtime stamps of one job in every `stamp_stride`-th workgroup (wave 0), see WAVE_STAMP
     unsigned long long* stamps; int stamp_stride, stamp_slots;
+    int wpb;                 // jobs (waves) per workgroup
 };
 // Timeline of a job (-DCOSY_WAVE_STAMPS build only): the shader clock (s_memtime) at the job's start, behind its prologue, at the start of every
 // input row (scalar bookkeeping: sum / min / max of the row-to-row intervals) and at its end -> 8 words per recorded job.  A first version with
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p = lane & 15, kg = lane >> 4;
     // XCD-aware job order: the chunks of one sample run on one XCD (block id % 8), 4 jobs (waves) per block
-    const int id = blockIdx.x, xcd = id & 7, sidx = (id >> 3) * 4 + wave;
+    const int id = blockIdx.x, xcd = id & 7, sidx = (id >> 3) * a.wpb + wave;
     // a job = (sample, chunk, row band); the jobs of one sample stay on one XCD
     const int jps = a.nchunks * a.rsplit;
     const int b = (sidx / jps) * 8 + xcd, jrem = sidx % jps;
@@ -1180,9 +1181,6 @@ static int launch_wave_k(WaveKArgs k, int* n_tiles_out, hipStream_t s) {
         }
     }
 #endif
-#ifdef COSY_TUNE
-    lds += (size_t)tune_int("COSY_WAVE_LDS_PAD", 0);      // experiment: fewer resident workgroups per CU
-#endif
     k.rsplit = tune_int("COSY_WAVE_RSPLIT", RSP);
     if (k.rsplit < 1) k.rsplit = 1;
     if (k.rsplit > WAVE_MAX_RSPLIT) k.rsplit = WAVE_MAX_RSPLIT;
@@ -1190,7 +1188,13 @@ static int launch_wave_k(WaveKArgs k, int* n_tiles_out, hipStream_t s) {
     k.rows_per = cdiv(k.Ho, k.rsplit);
     *n_tiles_out = k.rsplit;
     const long jobs_per_xcd = (long)cdiv(k.B, 8) * k.nchunks * k.rsplit;
-    const dim3 grid((unsigned)(cdiv(jobs_per_xcd, 4) * 8)), block(256);
+    k.wpb = tune_int("COSY_WAVE_WPB", 4);
+    if (k.wpb != 1 && k.wpb != 2) k.wpb = 4;
+    lds = lds / 4 * k.wpb;
+#ifdef COSY_TUNE
+    lds += (size_t)tune_int("COSY_WAVE_LDS_PAD", 0);      // experiment: fewer resident workgroups per CU
+#endif
+    const dim3 grid((unsigned)(cdiv(jobs_per_xcd, k.wpb) * 8)), block(64 * k.wpb);
 #ifdef COSY_TUNE
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)mbconv_wave_kernel<T, KS, S, KBN, PPL, NI, FW, MW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #endif

@@ -198,6 +198,11 @@ size_t cosy_train_workspace_bytes(void);
 /* crop + render pack (as cosy_crop_pack) into a caller-owned NHWC8 buffer of element type `dtype` */
 int cosy_crop_pack_to(void* x_nhwc8, int dtype, const float* frames_nhwc4, const int* im_id, const float* boxes_crop,
                       const float* renders, int B, int N, int h, int w, int H, int W, cosy_stream_t stream);
+/* the same through the per-crop tap tables and the LDS-tiled kernel that cosy_crop_pack runs on the net's own buffer (bit-identical
+ * to cosy_crop_pack_to): `workspace` = cosy_crop_pack_workspace_bytes(B, H, W) bytes of device scratch */
+size_t cosy_crop_pack_workspace_bytes(int B, int H, int W);
+int cosy_crop_pack_to_ws(void* x_nhwc8, int dtype, const float* frames_nhwc4, const int* im_id, const float* boxes_crop,
+                         const float* renders, int B, int N, int h, int w, int H, int W, void* workspace, cosy_stream_t stream);
 /* nn.BatchNorm2d in train mode (efficientnet.py:49-68; eps 1e-3, momentum 0.01): batch mean / 1/sqrt(biased var + eps)
  * per channel over the M rows; running_mean/var (optional) updated in place with the unbiased variance. */
 int cosy_bn_train_stats(const float* x, long M, int C, float eps, float momentum, float* mean, float* rstd, float* running_mean,

@@ -1402,6 +1402,51 @@ def test_crop_pack_all_window_paths(oracle):
     assert torch.equal(x8t[..., :3].contiguous().view(torch.int32), x8[..., :3].contiguous().view(torch.int32))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('crop', [(256, 256), (240, 320), (128, 128), (48, 64), (176, 208)])
+def test_crop_pack_tiled_is_bit_identical(oracle, crop):
+    """round 6: the LDS-tiled crop + pack kernel (what cosy_crop_pack runs: the frame window of a 16 x 64 output tile staged once) against
+    the per-pixel kernel (cosy_crop_pack_to, no tables) bit for bit -- every window regime: magnifying boxes (one pass), bins of 1.2-2.6
+    frame pixels (2 / 4 passes), tap entries wider than 4 pixels and huge boxes (per-pixel fallback), boxes partly / entirely outside the
+    frame, degenerate and NaN boxes; output sizes whose last tile is ragged in both directions; all three storage types.  The per-pixel
+    kernel itself is held against the roi_align oracle by test_crop_pack_all_window_paths.  Reference: cosypose/lib3d/cropping.py:64-75."""
+    from cosypose_amd._lib import lib, check, ptr, stream, COSY_F32, COSY_F16, COSY_BF16
+    H, W = crop
+    N, h, w = 3, 200, 264
+    frames = syn.make_frames(23, N, h, w)
+    rs = np.random.RandomState(5)
+    boxes = [[10.3, 5.2, 74.3, 53.2], [0, 0, w, h], [-40, -30, w + 40, h + 30], [-300, -200, 500, 400], [150.2, 110.1, 150.9, 110.4],
+             [400, 300, 500, 380], [np.nan, 0, 50, 50], [-20.5, 30.25, 90.75, 120.5], [w - 60.2, h - 50.1, w + 30.3, h + 25.7]]
+    for side in (0.3, 0.55, 0.8, 1.0, 1.15, 1.3, 1.6, 2.0, 2.4, 2.7, 3.2):           # bin size in frame pixels
+        cx, cy = rs.uniform(60, w - 60), rs.uniform(50, h - 50)
+        boxes.append([cx - side * W / 2, cy - side * H / 2, cx + side * W / 2, cy + side * H / 2])
+        boxes.append([cx - side * W / 2, cy - 0.6 * H / 2, cx + side * W / 2, cy + 0.6 * H / 2])      # wide columns, narrow rows
+    boxes = np.array(boxes, np.float32)
+    B = len(boxes)
+    im = (np.arange(B) % N).astype(np.int32)
+    renders = syn.make_renders(4, B, H, W)
+    frames4 = torch.empty(N, h, w, 4, device='cuda')
+    frames_d = dev(frames)
+    check(lib().cosy_frames_to_nhwc4(ptr(frames_d), ptr(frames4), N, h, w, stream()))
+    im_d, boxes_d, renders_d = dev(im, torch.int32), dev(boxes), dev(renders)
+    ws = torch.empty(lib().cosy_crop_pack_workspace_bytes(B, H, W), dtype=torch.uint8, device='cuda')
+    for code, tdt in ((COSY_F32, torch.float32), (COSY_F16, torch.float16), (COSY_BF16, torch.bfloat16)):
+        want = torch.full((B, H, W, 8), -7.0, device='cuda', dtype=tdt)
+        got = torch.full((B, H, W, 8), -9.0, device='cuda', dtype=tdt)
+        check(lib().cosy_crop_pack_to(ptr(want), code, ptr(frames4), ptr(im_d), ptr(boxes_d), ptr(renders_d), B, N, h, w, H, W, stream()))
+        check(lib().cosy_crop_pack_to_ws(ptr(got), code, ptr(frames4), ptr(im_d), ptr(boxes_d), ptr(renders_d), B, N, h, w, H, W, ptr(ws), stream()))
+        torch.cuda.synchronize()
+        itype = torch.int32 if tdt == torch.float32 else torch.int16
+        same = got.view(itype) == want.view(itype)
+        assert same.all(), f'dtype {code}: crops {sorted(set((~same).nonzero()[:, 0].tolist()))} differ'
+    if crop == (48, 64):      # and against the oracle directly (the tiled path on its own)
+        got32 = torch.empty((B, H, W, 8), device='cuda')
+        check(lib().cosy_crop_pack_to_ws(ptr(got32), COSY_F32, ptr(frames4), ptr(im_d), ptr(boxes_d), ptr(renders_d), B, N, h, w, H, W, ptr(ws), stream()))
+        ok = ~np.isnan(boxes).any(1)
+        rois = np.concatenate([im[:, None].astype(np.float32), boxes], 1)[ok]
+        np.testing.assert_allclose(got32.cpu().numpy()[ok][..., :3].transpose(0, 3, 1, 2), oracle.roi_align(frames, rois, (H, W), 4), rtol=0, atol=2e-6)
+
+
 def test_roi_align_handmade_fixtures():
     """both HIP roi_align paths (cosy_roi_align and the fused crop + pack kernel) against vectors that do not come from
     this repository's 2-D code: separable images whose expected crops are outer products of 1-D means, derived in
