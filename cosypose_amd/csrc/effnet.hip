@@ -77,6 +77,11 @@ struct Block {
     // and residuals do not care about the order.  in_col: the block input X; out_col: D and the block output; to_rowmajor: the last block of
     // such a stage when what follows cannot read column-major -- its output goes through one re-ordering copy (launch_pixels_to_rowmajor).
     bool in_col, out_col, to_rowmajor;
+    // Channel layout of the block INPUT (= the block before's output): NHWC rows, or chunked [sample][ceil(Cin/16)][H*W][16] for the wave fronts with the
+    // taps on the matrix pipe (their fragment q = 16 neighbouring pixels x 32 channels: in the chunked layout 4 neighbouring lanes read one 128-byte line,
+    // which the vector-memory address path takes at twice the rate of 4 NHWC rows -- profiles/r06_ta_patterns.txt).  The project GEMM of the block before
+    // writes that layout (PwArgs::out_chunked), this block's project GEMM reads its residual from it (res_chunked).
+    bool x_chunk;
     float *se_wr_p, *se_br_p, *se_we_p;   // zero-padded copies for the batched form: (CseP, Cmid), (CseP), (Cmid, CseP)
 };
 
@@ -141,6 +146,7 @@ static void fold_bn(const float* bn, int C, int Cpad, std::vector<float>& scale,
 
 // One pass = sizing (bump.base == nullptr) or filling.  Returns the number of blob floats consumed.
 static void plan_pixel_order(cosy_net* n);
+static void plan_channel_layout(cosy_net* n);
 static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hipError_t* herr) {
     const float* p0 = p;
     auto up_f32 = [&](const std::vector<float>& v) -> float* {
@@ -323,6 +329,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
     }
     n->Hf = h; n->Wf = w_;
     plan_pixel_order(n);
+    plan_channel_layout(n);
     mk_pw(n->head, p, HEAD_IN, HEAD_C, p + (size_t)HEAD_C * HEAD_IN, n->Hf * n->Wf, false);
     p += (size_t)HEAD_C * HEAD_IN + 4 * HEAD_C;
     {
@@ -358,6 +365,15 @@ static void plan_pixel_order(cosy_net* n) {
     }
 }
 
+static void plan_channel_layout(cosy_net* n) {
+    static const int allow = tune_int("COSY_X_CHUNKED", 1);
+    for (int i = 0; i < 26; ++i) {
+        Block& b = n->blk[i];
+        b.x_chunk = allow && i >= 1 && n->esz == 2 && b.wave && !n->blk[i - 1].to_rowmajor &&
+                    wave_taps_on_mfma(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
+    }
+}
+
 enum { EARLY_BLOCKS = 9 };  // stem + blocks 0..8 (feature maps >= 32x32 at 256^2) form the "early" segment
 
 // Early segment runs in sample chunks through small buffers that are REUSED for every chunk, so the large
@@ -371,8 +387,9 @@ static void layout_ws(cosy_net* n, Bump& b, cosy_net::WS& w, size_t B) {
         const Block& k = n->blk[i];
         const bool early = i < EARLY_BLOCKS;
         size_t& act = early ? act_e : act_l; size_t& ex = early ? ex_e : ex_l; size_t& dw = early ? dw_e : dw_l;
-        act = std::max(act, (size_t)k.Ho * k.Wo * k.d.cout);
-        if (i == EARLY_BLOCKS - 1) act_l = std::max(act_l, (size_t)k.Ho * k.Wo * k.d.cout);  // hand-over tensor
+        const size_t cpad = (size_t)((k.d.cout + 15) & ~15);      // (the chunked layout of a wave front's input pads the channels to whole 16-channel chunks)
+        act = std::max(act, (size_t)k.Ho * k.Wo * cpad);
+        if (i == EARLY_BLOCKS - 1) act_l = std::max(act_l, (size_t)k.Ho * k.Wo * cpad);  // hand-over tensor
         if (k.d.e != 1 && !k.fused) ex = std::max(ex, (size_t)k.H * k.W * k.cmid);
         if (k.to_rowmajor) ex = std::max(ex, (size_t)k.Ho * k.Wo * k.d.cout);      // the project GEMM writes there, the re-ordering copy into the output
         dw = std::max(dw, (size_t)k.Ho * k.Wo * (i == 0 && n->stem_fused ? (size_t)((k.cmid + 15) & ~15) : (size_t)k.cmid));     // (stem front: chunked D, 40 -> 48 channels)
@@ -428,9 +445,9 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
     char kn[64];
     auto pw_name = [&](const PwLayer& L, const PwArgs& a) { pw_kernel_name(a, L.cfg, n->dtype, kn, sizeof(kn)); };
     auto pw_bytes = [&](const PwArgs& a, int Bc) { return ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N * (a.res ? 2 : 1)) * esz_d + (a.gate ? (double)Bc * a.K * 4 : 0); };
-    auto tap = [&](const void* act, int Bc, int b0, int HW, int C, int idx, int colH = 0) -> int {
+    auto tap = [&](const void* act, int Bc, int b0, int HW, int C, int idx, int colH = 0, int chunked = 0) -> int {
         if (!taps) return COSY_OK;
-        return launch_taps(act, Bc, HW, C, n->dtype, taps + (size_t)b0 * 9 * 16, idx, s, colH);
+        return launch_taps(act, Bc, HW, C, n->dtype, taps + (size_t)b0 * 9 * 16, idx, s, colH, chunked);
     };
     // test probe: the whole activation `layer` as fp32 NCHW (layer -1 stem, 0..25 block outputs, 26 head, 100+i depthwise output
     // D of block i, 200+i SE gate of block i as (B, Cmid))
@@ -460,7 +477,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
             else { f.s0 = b.exp.scale; f.b0 = b.exp.bias; f.dww = b.dw_w; f.s1 = b.dw_scale; f.b1 = b.dw_bias; f.wparams = b.wave_params; }
             f.D = Dbuf; f.partial = w.partial; f.zeros = n->zeros;
             f.B = Bc; f.H = b.H; f.W = b.W; f.Cin = b.d.cin; f.Cmid = b.cmid; f.Ho = b.Ho; f.Wo = b.Wo; f.k = b.d.k; f.s = b.d.s; f.pad_lo = b.pad_lo;
-            f.x_colmajor = b.in_col; f.d_colmajor = b.out_col;
+            f.x_colmajor = b.in_col; f.d_colmajor = b.out_col; f.x_chunked = b.x_chunk;
             if ((rc = b.wave ? launch_mbconv_wave(f, n->dtype, &se_tiles, s) : b.tiled ? launch_mbconv_tile(f, n->dtype, s) : b.smx ? launch_mbconv_small_mx(f, n->dtype, s) : launch_mbconv_small(f, n->dtype, s))) return rc;
             if (b.wave) wave_kernel_name(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W, kn, sizeof(kn));
             else if (b.tiled) tile_kernel_name(b.d.cin, b.d.k, b.d.s, n->dtype, kn, sizeof(kn));
@@ -506,6 +523,8 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         PwArgs a{};
         a.A = Dbuf; a.Wp = b.proj.Wp; a.out = b.to_rowmajor ? Ebuf : out; a.scale = b.proj.scale; a.bias = b.proj.bias;
         a.res = b.skip ? in : nullptr; a.gate = w.gate; a.se_fused = b.se_fused ? &se : nullptr;
+        const int out_chunked = i + 1 < 26 && n->blk[i + 1].x_chunk;      // the next block's front wants its input chunked
+        a.res_chunked = b.x_chunk; a.out_chunked = out_chunked;
         a.M = Bc * b.Ho * b.Wo; a.K = b.cmid; a.N = b.d.cout; a.HW = b.Ho * b.Wo; a.silu = 0; a.zeros = n->zeros;
         // the wave front (and the row-mapped 8x8 kernel) write D as [sample][Cmid/16][HW][16]
         a.a_chunked = stem_x != nullptr || b.wave || b.smx || (b.small && small_writes_chunked(b.d.cin, b.cmid, b.H, b.W, b.Ho, b.Wo, b.d.k, b.d.s, n->dtype));
@@ -519,13 +538,14 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
             if ((rc = launch_pixels_to_rowmajor(Ebuf, out, Bc, b.Ho, b.Wo, b.d.cout, n->dtype, s))) return rc;
             if ((rc = mark("pixels_to_rowmajor_kernel", i, 2.0 * Bc * b.Ho * b.Wo * b.d.cout * esz_d, 0.0, 0.0))) return rc;
         }
-        return probe(i, out, Bc, b0, b.Ho * b.Wo, b.d.cout, 0, b.out_col && !b.to_rowmajor ? b.Ho : 0);
+        return probe(i, out, Bc, b0, b.Ho * b.Wo, b.d.cout, out_chunked, b.out_col && !b.to_rowmajor ? b.Ho : 0);
     };
+    auto out_is_chunked = [&](int i) -> int { return i + 1 < 26 && n->blk[i + 1].x_chunk; };
     auto stage_tap_index = [&](int i) -> int { for (int q = 0; q < 7; ++q) if (STAGE_END[q] == i) return q + 1; return -1; };
 
     // ---- early segment, chunked
     const Block& last_e = n->blk[EARLY_BLOCKS - 1];
-    const size_t handover = (size_t)last_e.Ho * last_e.Wo * last_e.d.cout * e;
+    const size_t handover = (size_t)last_e.Ho * last_e.Wo * (n->blk[EARLY_BLOCKS].x_chunk ? (size_t)((last_e.d.cout + 15) & ~15) : (size_t)last_e.d.cout) * e;
     const int chunk = std::min(n->chunk, n->maxB);
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int Bc = std::min(chunk, B - b0);
@@ -548,7 +568,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
             if ((rc = run_block(i, w.actc[cur], out, Bc, w.Ec, w.Dc, b0, i == 0 && stemf ? x : nullptr))) return rc;
             cur ^= 1;
             const int ti = stage_tap_index(i);
-            if (ti >= 0 && (rc = tap(out, Bc, b0, b.Ho * b.Wo, b.d.cout, ti, b.out_col && !b.to_rowmajor ? b.Ho : 0))) return rc;
+            if (ti >= 0 && (rc = tap(out, Bc, b0, b.Ho * b.Wo, b.d.cout, ti, b.out_col && !b.to_rowmajor ? b.Ho : 0, out_is_chunked(i)))) return rc;
         }
     }
     // ---- late segment, full batch
@@ -558,7 +578,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         if ((rc = run_block(i, w.act[cur], w.act[cur ^ 1], B, w.E, w.D, 0))) return rc;
         cur ^= 1;
         const int ti = stage_tap_index(i);
-        if (ti >= 0 && (rc = tap(w.act[cur], B, 0, b.Ho * b.Wo, b.d.cout, ti, b.out_col && !b.to_rowmajor ? b.Ho : 0))) return rc;
+        if (ti >= 0 && (rc = tap(w.act[cur], B, 0, b.Ho * b.Wo, b.d.cout, ti, b.out_col && !b.to_rowmajor ? b.Ho : 0, out_is_chunked(i)))) return rc;
     }
     PwArgs a{};
     a.A = w.act[cur]; a.Wp = n->head.Wp; a.out = w.Hd; a.scale = n->head.scale; a.bias = n->head.bias;

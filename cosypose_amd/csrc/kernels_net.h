@@ -34,6 +34,10 @@ struct PwArgs {
     int silu;
     const void* zeros;   // >= 16 zero bytes (global): source of padded rows/k for the LDS-DMA pipeline
     int a_chunked;       // 1: A is laid out [sample][K/16][HW][16] (what the wave front writes: a wave's row is one contiguous run)
+    int out_chunked;     // 1: out is written as [sample][ceil(N/16)][HW][16] -- the block-input layout of the matrix-pipe wave fronts (round 6: their fragment
+                         //    loads put 4 neighbouring pixels' 16-byte pieces into one 128-byte line, which the vector-memory address path takes at twice the
+                         //    rate of NHWC rows: profiles/r06_ta_patterns.txt); channels N .. 16 ceil(N/16) - 1 of the last chunk are not written
+    int res_chunked;     // 1: res is in that layout
     const struct SeArgs* se_fused;   // non-null: NO squeeze-excite launch ran -- every workgroup computes the gates of the samples under its
                                      // m-tile in its prologue from the squeeze partial sums (se_fused->gate == gate, written for probes)
 };
@@ -73,6 +77,7 @@ struct FuseArgs {
     // wave kernel only: pixel order of the block input X / of D inside a sample.  0 = row-major (y * W + x); 1 = column-major (x * H + y): the whole
     // resolution stage is stored transposed so that a wave that walks the map's columns (wave_walks_columns) reads and writes contiguous runs
     int x_colmajor, d_colmajor;
+    int x_chunked;       // wave kernel only: X is laid out [sample][ceil(Cin/16)][H*W][16] (PwArgs::out_chunked of the block before)
 };
 // tiled variant (LDS tile per workgroup) for high-resolution blocks whose row width the wave kernel is not built for
 bool tile_supported(int Cin, int Cmid, int k, int s, int dtype);
@@ -149,7 +154,7 @@ int launch_pool_fc(const void* head /*(B,HW,1536)*/, const float* fc_w /*(9,1536
 // colH > 0: the activation's pixels are stored column-major (x * colH + y, colH = the map's height); the probes index them row-major
 int launch_nhwc_to_nchw(const void* act /*(B,HW,C)*/, int B, int HW, int C, int dtype, float* out, hipStream_t s, int chunked = 0, int colH = 0);
 int launch_taps(const void* act /*(B,HW,C)*/, int B, int HW, int C, int dtype, float* taps /*(B,9,16)*/, int tap_index,
-                hipStream_t s, int colH = 0);
+                hipStream_t s, int colH = 0, int chunked = 0);   // chunked: [sample][ceil(C/16)][HW][16]
 // out (B, H*W, C) row-major pixels <- in (B, W*H, C) column-major pixels: the exit of a resolution stage that is stored transposed
 int launch_pixels_to_rowmajor(const void* in, void* out, int B, int H, int W, int C, int dtype, hipStream_t s);
 

@@ -116,6 +116,13 @@ void pw_pack_weights(const float* w, int K, int N, PwCfg c, int dtype, void* dst
                         }
 }
 
+// element offsets in the chunked activation layout [sample][ceil(C/16)][HW][16]: row m = (sample, pixel) / channel c
+__device__ __forceinline__ size_t chunked_row(int m, int HW, int C) {
+    const int bs = m / HW;
+    return ((size_t)bs * (size_t)((C + 15) >> 4) * (size_t)HW + (size_t)(m - bs * HW)) * 16;
+}
+__device__ __forceinline__ size_t chunked_col(int c, int HW) { return (size_t)(c >> 4) * (size_t)HW * 16 + (size_t)(c & 15); }
+
 // samples an m-tile of bm rows can touch when a sample has hw rows
 static inline int pw_gate_nsamp(int bm, int hw) { return (bm + hw - 2) / hw + 1; }
 struct PwKArgs {
@@ -124,6 +131,7 @@ struct PwKArgs {
     const void* zeros;
     int nsamp, rowgate;   // DMA kernel gate: samples under one m-tile; 1 = gate the activation fragments per row
     int a_chunked;        // A is [sample][K/16][HW][16] (see PwArgs)
+    int out_chunked, res_chunked;   // out / res are [sample][ceil(N/16)][HW][16] (see PwArgs)
     int a_nt;             // A is read exactly once (one n-tile) and is large: its DMAs carry the non-temporal hint
     // squeeze-excite computed in the prologue (PwArgs::se_fused): squeeze partial sums (B, se_tiles, K), reduce FC (Cse, K) + bias,
     // expand FC stored (Cse, K) + bias (K); se_wr == nullptr: the gate rows are read from `gate` (a squeeze-excite kernel wrote them)
@@ -250,6 +258,7 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
     // YOUNGER than the DMAs and are waited for with the vmcnt(0) of the barrier below, so no count spans both kinds.
     typedef T rv4_t __attribute__((ext_vector_type(4)));
     constexpr bool RES_PREFETCH = sizeof(T) == 2;
+    constexpr bool CHK = KG == 1 && sizeof(T) == 2;      // tiles that can meet the chunked output / residual layout (the split-K tiles of the 8x8 maps never do)
     rv4_t rpre[RES_PREFETCH ? MI : 1][RES_PREFETCH ? NI : 1];
     auto prefetch_residual = [&]() {
         if constexpr (RES_PREFETCH) {
@@ -258,9 +267,12 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     const int m = min(m0 + (wm * MI + mi) * 16 + row, M - 1);
+                    const size_t rbase = CHK && a.res_chunked ? chunked_row(m, a.HW, N) : (size_t)m * N;
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        rpre[mi][ni] = *(const rv4_t*)((const T*)a.res + (size_t)m * N + min(nl_ + ni * 4, N - 4));
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const int c = min(nl_ + ni * 4, N - 4);
+                        rpre[mi][ni] = *(const rv4_t*)((const T*)a.res + rbase + (CHK && a.res_chunked ? chunked_col(c, a.HW) : (size_t)c));
+                    }
                 }
             }
         }
@@ -487,7 +499,9 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
                         if (a.silu) v = v * sigmoid_t<T>(v);
                         y[c * 4 + r] = v;
                     }
-                const size_t o = (size_t)m * N + nl + n1 * 4;
+                // a lane's run of 4 CG channels starts at a multiple of 4 CG: it never straddles a 16-channel chunk
+                const int c0 = nl + n1 * 4;
+                const size_t o = CHK && a.out_chunked ? chunked_row(m, a.HW, N) + chunked_col(c0, a.HW) : (size_t)m * N + c0;
                 if (res) {
 #pragma unroll
                     for (int c = 0; c < CG; ++c) {
@@ -496,7 +510,7 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
 #pragma unroll
                             for (int r = 0; r < 4; ++r) rv[r] = (float)rpre[mi][n1 + c][r];
                         } else {
-                            load4(res + o + c * 4, rv);
+                            load4(res + (CHK && a.res_chunked ? chunked_row(m, a.HW, N) + chunked_col(c0 + c * 4, a.HW) : (size_t)m * N + c0 + c * 4), rv);
                         }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) y[c * 4 + r] += rv[r];
@@ -511,6 +525,7 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
 template <typename T, int NI, int WN, bool GATE, int NS, int MI, int NWV = 4, int KG = 1, bool SEF = false>
 static int launch_pw_dma_mi(PwKArgs k, hipStream_t s) {
     if constexpr (!SEF) COSY_REQUIRE(!k.se_wr, "pw_gemm_dma: this tile shape has no squeeze-excite prologue (NI=%d WN=%d)", NI, WN);
+    if constexpr (!(KG == 1 && sizeof(T) == 2)) COSY_REQUIRE(!k.out_chunked && !k.res_chunked, "pw_gemm_dma: this tile shape does not write / read the chunked layout (NI=%d WN=%d)", NI, WN);
     constexpr int WM = NWV / KG / WN, NB = KG * (MI * WM + NI * WN * (__is_same(T, bf16_t) ? 2 : 1));
     k.MT = cdiv(k.M, 16 * MI * WM);
     const int grid = cdiv(k.MT, 8) * 8 * k.NT;
@@ -604,7 +619,7 @@ static int launch_pw_dma(const PwKArgs& k, PwCfg c, int grid, hipStream_t s) {
 template <typename T>
 static int launch_pw_t(const PwArgs& a, PwCfg c, int dtype, hipStream_t s) {
     PwKArgs k;
-    k.a_chunked = a.a_chunked;
+    k.a_chunked = a.a_chunked; k.out_chunked = a.out_chunked; k.res_chunked = a.res_chunked;
     k.A = a.A; k.Wp = a.Wp; k.out = a.out; k.scale = a.scale; k.bias = a.bias; k.res = a.res; k.gate = a.gate;
     k.M = a.M; k.K = a.K; k.N = a.N; k.HW = a.HW; k.silu = a.silu;
     k.MT = cdiv(a.M, pw_bm(c)); k.NT = cdiv(a.N, pw_bn(c));

@@ -262,13 +262,15 @@ int launch_nhwc_to_nchw(const void* act, int B, int HW, int C, int dtype, float*
 // test probe: [mean, mean|x|, 14 strided samples] of one NHWC activation, indexed as if NCHW-flattened
 // ==========================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void taps_kernel(const T* __restrict__ act, int HW, int C, float* __restrict__ taps, int tap_index, int colH) {
+__global__ __launch_bounds__(256) void taps_kernel(const T* __restrict__ act, int HW, int C, float* __restrict__ taps, int tap_index, int colH, int chunked) {
     __shared__ double s1[256], s2[256];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const T* a = act + (size_t)b * HW * C;
+    // chunked = 1: [sample][ceil(C/16)][HW][16] (the input layout of the matrix-pipe wave fronts; the pad channels of the last chunk are not part of the tensor)
+    const T* a = act + (size_t)b * HW * (chunked ? (size_t)((C + 15) & ~15) : (size_t)C);
     const size_t n = (size_t)HW * C;
+    auto at = [&](size_t p, size_t c) -> float { return (float)(chunked ? a[((c >> 4) * HW + p) * 16 + (c & 15)] : a[p * C + c]); };
     double x1 = 0, x2 = 0;
-    for (size_t i = tid; i < n; i += 256) { const float v = (float)a[i]; x1 += v; x2 += fabsf(v); }
+    for (size_t i = tid; i < n; i += 256) { const float v = at(i / C, i % C); x1 += v; x2 += fabsf(v); }
     s1[tid] = x1; s2[tid] = x2;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -282,12 +284,12 @@ __global__ __launch_bounds__(256) void taps_kernel(const T* __restrict__ act, in
         const size_t c = idx / HW;
         size_t p = idx % HW;
         if (colH > 0) { const size_t Wm = (size_t)HW / colH; p = (p % Wm) * colH + p / Wm; }
-        t[2 + tid] = (float)a[p * C + c];
+        t[2 + tid] = at(p, c);
     }
 }
-int launch_taps(const void* act, int B, int HW, int C, int dtype, float* taps, int tap_index, hipStream_t s, int colH) {
+int launch_taps(const void* act, int B, int HW, int C, int dtype, float* taps, int tap_index, hipStream_t s, int colH, int chunked) {
     if (B == 0) return COSY_OK;
-    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(taps_kernel<T>, dim3(B), dim3(256), 0, s, (const T*)act, HW, C, taps, tap_index, colH));
+    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(taps_kernel<T>, dim3(B), dim3(256), 0, s, (const T*)act, HW, C, taps, tap_index, colH, chunked));
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }

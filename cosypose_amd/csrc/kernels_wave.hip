@@ -42,6 +42,10 @@ struct WaveKArgs {
     // H / W / Ho / Wo are the WALKED axes: the wave walks H "rows" of W pixels.  For a transposed job (host: wave_plan) the rows are the
     // map's columns; only the four strides below and the order of the taps know: the map is addressed through them.
     int xs_pix, xs_row;      // bytes between two neighbouring pixels of a row / between two rows of the block input
+    // channel addressing of the block input: channel k of a pixel lives (k >> 4) * xs_chunk + (k & 15) * sizeof(T) bytes behind the pixel's first byte.
+    // NHWC rows: xs_chunk = 16 * sizeof(T) (i.e. k * sizeof(T)); chunked input [sample][ceil(Cin/16)][H*W][16] (FuseArgs::x_chunked): xs_chunk = H * W * 16 * sizeof(T).
+    int xs_chunk;
+    long xs_sample;          // elements between two samples of the block input
     int ds_pix, ds_row;      // elements between two neighbouring pixels of a row / between two rows inside a D chunk
     // -DCOSY_TUNE only (null in the shipping library): s_memtime stamps of one job in every `stamp_stride`-th workgroup (wave 0), see WAVE_STAMP
     unsigned long long* stamps; int stamp_stride, stamp_slots;
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
 #define WAVE_STAMP_ROW() do { } while (0)
 #endif
 
-    const T* __restrict__ X = (const T*)a.X + (size_t)min(b, a.B - 1) * a.H * a.W * a.Cin;
+    const T* __restrict__ X = (const T*)a.X + (size_t)min(b, a.B - 1) * (size_t)a.xs_sample;
     const float* Pl = P + kg * 4;            // this lane's channel quad inside every 16-float group
     const float* taps = Pl + 4 * 16 * NI;
 
@@ -373,16 +377,19 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     constexpr bool XUNI = FULLW;
     const int qstep = (MX ? 16 : 1) * a.xs_pix;
     int xoff[XUNI ? 1 : PPL][XUNI ? 2 : KBN];
+    auto koff = [&](int k) -> int { return (k >> 4) * a.xs_chunk + (k & 15) * (int)sizeof(T); };      // byte offset of channel k inside a pixel (NHWC: k * sizeof(T))
+    const int kbstep = (KB >> 4) * a.xs_chunk;     // bytes from k-block to k-block (wave-uniform: added to the row's scalar base; a k-block is whole 16-channel chunks)
+    static_assert(KB % 16 == 0 && (EPL == 4 || EPL == 8), "a lane's EPL channels lie inside one 16-channel chunk");
     if constexpr (XUNI) {
         const int px = (MX ? p : p * PPL) * a.xs_pix;
-        xoff[0][0] = px + kg * EPL * (int)sizeof(T);
-        xoff[0][1] = px + min((KBN - 1) * KB + kg * EPL, a.Cin - EPL) * (int)sizeof(T);
+        xoff[0][0] = px + koff(kg * EPL);
+        xoff[0][1] = px + koff(min((KBN - 1) * KB + kg * EPL, a.Cin - EPL));
     } else {
 #pragma unroll
         for (int kb = 0; kb < KBN; ++kb) {
             const int k = kb * KB + kg * EPL;
 #pragma unroll
-            for (int q = 0; q < PPL; ++q) xoff[q][kb] = min(p * PPL + q, a.W - 1) * a.xs_pix + min(k, a.Cin - EPL) * (int)sizeof(T);
+            for (int q = 0; q < PPL; ++q) xoff[q][kb] = min(p * PPL + q, a.W - 1) * a.xs_pix + koff(min(k, a.Cin - EPL));
         }
     }
     // The input fragments are loaded by inline asm and waited for with a COUNTED s_waitcnt: vmcnt retires loads and stores
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
             if constexpr (XUNI) {
                 constexpr int q = i / KBN, kb = i % KBN;
                 if constexpr (kb == KBN - 1) xfrag_load<XTOP, i>(xoff[0][1], rowp + (size_t)q * qstep);
-                else xfrag_load<XTOP, i, kb * KB * (int)sizeof(T)>(xoff[0][0], rowp + (size_t)q * qstep);
+                else xfrag_load<XTOP, i>(xoff[0][0], rowp + (size_t)q * qstep + (size_t)kb * kbstep);
             } else xfrag_load<XTOP, i>(xoff[i / KBN][i % KBN], rowp);
         }, std::make_integer_sequence<int, PPL * KBN>{});
         xfrag_fence<XTOP, PPL * KBN>();
@@ -1212,7 +1219,9 @@ static int launch_wave_t(const FuseArgs& a, int* n_tiles_out, hipStream_t s) {
     k.zeros = a.zeros; k.B = a.B; k.H = a.H; k.W = a.W; k.Cin = a.Cin; k.Cmid = a.Cmid; k.Ho = a.Ho; k.Wo = a.Wo;
     // strides of the walked axes through the stored map: a pixel step / a row step of the walk is a y or an x step of the map (transposed walk: rows =
     // the map's columns), and the map is stored row-major (y * W + x) or column-major (x * H + y; FuseArgs::x_colmajor / d_colmajor)
-    const int px = a.Cin * (int)sizeof(T);
+    const int px = (a.x_chunked ? 16 : a.Cin) * (int)sizeof(T);
+    k.xs_chunk = a.x_chunked ? a.H * a.W * 16 * (int)sizeof(T) : 16 * (int)sizeof(T);
+    k.xs_sample = a.x_chunked ? (long)((a.Cin + 15) >> 4) * a.H * a.W * 16 : (long)a.H * a.W * a.Cin;
     const int x_dx = a.x_colmajor ? a.H * px : px, x_dy = a.x_colmajor ? px : a.W * px;          // bytes per x step / y step of the block input
     const int d_dx = a.d_colmajor ? a.Ho * 16 : 16, d_dy = a.d_colmajor ? 16 : a.Wo * 16;       // elements per x step / y step inside a D chunk
     k.xs_pix = x_dx; k.xs_row = x_dy; k.ds_pix = d_dx; k.ds_row = d_dy;
