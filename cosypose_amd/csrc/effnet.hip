@@ -82,6 +82,7 @@ struct Block {
     // which the vector-memory address path takes at twice the rate of 4 NHWC rows -- profiles/r06_ta_patterns.txt).  The project GEMM of the block before
     // writes that layout (PwArgs::out_chunked), this block's project GEMM reads its residual from it (res_chunked).
     bool x_chunk;
+    int x_perm_lp;        // x_chunk and the front is the fp32-FMA form: log2 of its pixels per lane -- the rows of the input are stored permuted (PwArgs::out_perm_*); else 0
     float *se_wr_p, *se_br_p, *se_we_p;   // zero-padded copies for the batched form: (CseP, Cmid), (CseP), (Cmid, CseP)
 };
 
@@ -365,12 +366,21 @@ static void plan_pixel_order(cosy_net* n) {
     }
 }
 
+static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static void plan_channel_layout(cosy_net* n) {
     static const int allow = tune_int("COSY_X_CHUNKED", 1);
     for (int i = 0; i < 26; ++i) {
         Block& b = n->blk[i];
         b.x_chunk = allow && i >= 1 && n->esz == 2 && b.wave && !n->blk[i - 1].to_rowmajor &&
                     wave_taps_on_mfma(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
+        // the fp32-FMA fronts (stride-2 blocks 2 / 5 / 8 at 256x256): a lane owns a run of P pixels, fragment q = the 16 lanes' pixels p * P + q -- 16 neighbours only
+        // if the row is stored in that order
+        b.x_perm_lp = 0;
+        static const int allow_perm = tune_int("COSY_X_PERM", 1);
+        if (allow && allow_perm && !b.x_chunk && i >= 1 && n->esz == 2 && b.wave && !b.in_col && !n->blk[i - 1].to_rowmajor && !n->blk[i - 1].out_col && (b.W & (b.W - 1)) == 0) {
+            b.x_perm_lp = wave_input_perm_lp(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
+            b.x_chunk = b.x_perm_lp > 0;
+        }
     }
 }
 
@@ -445,15 +455,15 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
     char kn[64];
     auto pw_name = [&](const PwLayer& L, const PwArgs& a) { pw_kernel_name(a, L.cfg, n->dtype, kn, sizeof(kn)); };
     auto pw_bytes = [&](const PwArgs& a, int Bc) { return ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N * (a.res ? 2 : 1)) * esz_d + (a.gate ? (double)Bc * a.K * 4 : 0); };
-    auto tap = [&](const void* act, int Bc, int b0, int HW, int C, int idx, int colH = 0, int chunked = 0) -> int {
+    auto tap = [&](const void* act, int Bc, int b0, int HW, int C, int idx, int colH = 0, int chunked = 0, int lw = 0, int lp = 0) -> int {
         if (!taps) return COSY_OK;
-        return launch_taps(act, Bc, HW, C, n->dtype, taps + (size_t)b0 * 9 * 16, idx, s, colH, chunked);
+        return launch_taps(act, Bc, HW, C, n->dtype, taps + (size_t)b0 * 9 * 16, idx, s, colH, chunked, lw, lp);
     };
     // test probe: the whole activation `layer` as fp32 NCHW (layer -1 stem, 0..25 block outputs, 26 head, 100+i depthwise output
     // D of block i, 200+i SE gate of block i as (B, Cmid))
-    auto probe = [&](int layer, const void* act, int Bc, int b0, int HW, int C, int chunked, int colH = 0) -> int {
+    auto probe = [&](int layer, const void* act, int Bc, int b0, int HW, int C, int chunked, int colH = 0, int lw = 0, int lp = 0) -> int {
         if (n->probe_layer != layer || !n->probe_out) return COSY_OK;
-        return launch_nhwc_to_nchw(act, Bc, HW, C, n->dtype, n->probe_out + (size_t)b0 * HW * C, s, chunked, colH);
+        return launch_nhwc_to_nchw(act, Bc, HW, C, n->dtype, n->probe_out + (size_t)b0 * HW * C, s, chunked, colH, lw, lp);
     };
     // one MBConv block on Bc samples: [expand 1x1] -> depthwise (+squeeze partials) -> SE gate -> project 1x1 (+residual)
     // stem_x != nullptr (block 0 only): the front is the fused stem + depthwise kernel reading the network input; `in` is unused then
@@ -477,7 +487,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
             else { f.s0 = b.exp.scale; f.b0 = b.exp.bias; f.dww = b.dw_w; f.s1 = b.dw_scale; f.b1 = b.dw_bias; f.wparams = b.wave_params; }
             f.D = Dbuf; f.partial = w.partial; f.zeros = n->zeros;
             f.B = Bc; f.H = b.H; f.W = b.W; f.Cin = b.d.cin; f.Cmid = b.cmid; f.Ho = b.Ho; f.Wo = b.Wo; f.k = b.d.k; f.s = b.d.s; f.pad_lo = b.pad_lo;
-            f.x_colmajor = b.in_col; f.d_colmajor = b.out_col; f.x_chunked = b.x_chunk;
+            f.x_colmajor = b.in_col; f.d_colmajor = b.out_col; f.x_chunked = b.x_chunk; f.x_perm = b.x_perm_lp > 0;
             if ((rc = b.wave ? launch_mbconv_wave(f, n->dtype, &se_tiles, s) : b.tiled ? launch_mbconv_tile(f, n->dtype, s) : b.smx ? launch_mbconv_small_mx(f, n->dtype, s) : launch_mbconv_small(f, n->dtype, s))) return rc;
             if (b.wave) wave_kernel_name(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W, kn, sizeof(kn));
             else if (b.tiled) tile_kernel_name(b.d.cin, b.d.k, b.d.s, n->dtype, kn, sizeof(kn));
@@ -525,6 +535,8 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         a.res = b.skip ? in : nullptr; a.gate = w.gate; a.se_fused = b.se_fused ? &se : nullptr;
         const int out_chunked = i + 1 < 26 && n->blk[i + 1].x_chunk;      // the next block's front wants its input chunked
         a.res_chunked = b.x_chunk; a.out_chunked = out_chunked;
+        const int out_lp = out_chunked ? n->blk[i + 1].x_perm_lp : 0, out_lw = out_lp ? ilog2(b.Wo) : 0;      // (a block with a permuted input has stride 2: no residual reads it)
+        a.out_perm_lw = out_lw; a.out_perm_lp = out_lp;
         a.M = Bc * b.Ho * b.Wo; a.K = b.cmid; a.N = b.d.cout; a.HW = b.Ho * b.Wo; a.silu = 0; a.zeros = n->zeros;
         // the wave front (and the row-mapped 8x8 kernel) write D as [sample][Cmid/16][HW][16]
         a.a_chunked = stem_x != nullptr || b.wave || b.smx || (b.small && small_writes_chunked(b.d.cin, b.cmid, b.H, b.W, b.Ho, b.Wo, b.d.k, b.d.s, n->dtype));
@@ -538,9 +550,11 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
             if ((rc = launch_pixels_to_rowmajor(Ebuf, out, Bc, b.Ho, b.Wo, b.d.cout, n->dtype, s))) return rc;
             if ((rc = mark("pixels_to_rowmajor_kernel", i, 2.0 * Bc * b.Ho * b.Wo * b.d.cout * esz_d, 0.0, 0.0))) return rc;
         }
-        return probe(i, out, Bc, b0, b.Ho * b.Wo, b.d.cout, out_chunked, b.out_col && !b.to_rowmajor ? b.Ho : 0);
+        return probe(i, out, Bc, b0, b.Ho * b.Wo, b.d.cout, out_chunked, b.out_col && !b.to_rowmajor ? b.Ho : 0, out_lw, out_lp);
     };
     auto out_is_chunked = [&](int i) -> int { return i + 1 < 26 && n->blk[i + 1].x_chunk; };
+    auto out_perm_lp = [&](int i) -> int { return out_is_chunked(i) ? n->blk[i + 1].x_perm_lp : 0; };
+    auto out_perm_lw = [&](int i) -> int { return out_perm_lp(i) ? ilog2(n->blk[i].Wo) : 0; };
     auto stage_tap_index = [&](int i) -> int { for (int q = 0; q < 7; ++q) if (STAGE_END[q] == i) return q + 1; return -1; };
 
     // ---- early segment, chunked
@@ -568,7 +582,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
             if ((rc = run_block(i, w.actc[cur], out, Bc, w.Ec, w.Dc, b0, i == 0 && stemf ? x : nullptr))) return rc;
             cur ^= 1;
             const int ti = stage_tap_index(i);
-            if (ti >= 0 && (rc = tap(out, Bc, b0, b.Ho * b.Wo, b.d.cout, ti, b.out_col && !b.to_rowmajor ? b.Ho : 0, out_is_chunked(i)))) return rc;
+            if (ti >= 0 && (rc = tap(out, Bc, b0, b.Ho * b.Wo, b.d.cout, ti, b.out_col && !b.to_rowmajor ? b.Ho : 0, out_is_chunked(i), out_perm_lw(i), out_perm_lp(i)))) return rc;
         }
     }
     // ---- late segment, full batch
@@ -578,7 +592,7 @@ static int net_forward(cosy_net* n, const cosy_net::WS& w, int x_off, int B, flo
         if ((rc = run_block(i, w.act[cur], w.act[cur ^ 1], B, w.E, w.D, 0))) return rc;
         cur ^= 1;
         const int ti = stage_tap_index(i);
-        if (ti >= 0 && (rc = tap(w.act[cur], B, 0, b.Ho * b.Wo, b.d.cout, ti, b.out_col && !b.to_rowmajor ? b.Ho : 0, out_is_chunked(i)))) return rc;
+        if (ti >= 0 && (rc = tap(w.act[cur], B, 0, b.Ho * b.Wo, b.d.cout, ti, b.out_col && !b.to_rowmajor ? b.Ho : 0, out_is_chunked(i), out_perm_lw(i), out_perm_lp(i)))) return rc;
     }
     PwArgs a{};
     a.A = w.act[cur]; a.Wp = n->head.Wp; a.out = w.Hd; a.scale = n->head.scale; a.bias = n->head.bias;

@@ -38,6 +38,9 @@ struct PwArgs {
                          //    loads put 4 neighbouring pixels' 16-byte pieces into one 128-byte line, which the vector-memory address path takes at twice the
                          //    rate of NHWC rows: profiles/r06_ta_patterns.txt); channels N .. 16 ceil(N/16) - 1 of the last chunk are not written
     int res_chunked;     // 1: res is in that layout
+    int out_perm_lw, out_perm_lp;   // out_chunked only, 0 = none: the pixels of a row of 2^lw pixels are stored in the order the fp32-FMA wave fronts' fragments want them --
+                         //    pixel x at position (x mod P) * 16 + x / P, P = 2^lp = pixels per lane: fragment q = the 16 lanes' pixels p * P + q is then 16 NEIGHBOURING
+                         //    32-byte pixels like a matrix-pipe front's segment (FuseArgs::x_perm); rows per sample in row-major order (HW a multiple of 2^lw)
     const struct SeArgs* se_fused;   // non-null: NO squeeze-excite launch ran -- every workgroup computes the gates of the samples under its
                                      // m-tile in its prologue from the squeeze partial sums (se_fused->gate == gate, written for probes)
 };
@@ -78,6 +81,7 @@ struct FuseArgs {
     // resolution stage is stored transposed so that a wave that walks the map's columns (wave_walks_columns) reads and writes contiguous runs
     int x_colmajor, d_colmajor;
     int x_chunked;       // wave kernel only: X is laid out [sample][ceil(Cin/16)][H*W][16] (PwArgs::out_chunked of the block before)
+    int x_perm;          // ... with the pixels of a row permuted for a lane's run of P pixels (PwArgs::out_perm_lw / out_perm_lp)
 };
 // tiled variant (LDS tile per workgroup) for high-resolution blocks whose row width the wave kernel is not built for
 bool tile_supported(int Cin, int Cmid, int k, int s, int dtype);
@@ -101,6 +105,7 @@ int launch_mbconv_small_mx(const FuseArgs& a, int dtype, hipStream_t s);
 bool wave_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W);
 bool wave_walks_columns(int Cin, int Cmid, int k, int s, int dtype, int H, int W);   // the job's rows are the map's columns (transposed walk)
 size_t wave_params_floats(int Cin, int Cmid, int k, int s, int dtype, int H, int W);
+int wave_input_perm_lp(int Cin, int Cmid, int k, int s, int dtype, int H, int W);    // > 0: this block's wave front (fp32-FMA taps, full power-of-two rows) reads its input with the pixels of a row permuted for runs of 2^lp
 bool wave_taps_on_mfma(int Cin, int Cmid, int k, int s, int dtype, int H, int W);     // the wave kernel applies this block's depthwise taps with small MFMAs (E and the taps in the storage type)
 void wave_pack_params(const float* s0, const float* b0, const float* dww, const float* s1, const float* b1, int Cin, int Cmid, int k, int s,
                       int dtype, int H, int W, float* dst);
@@ -152,9 +157,9 @@ int launch_stem(const void* x_nhwc8, const void* w_packed, const float* scale, c
 int launch_pool_fc(const void* head /*(B,HW,1536)*/, const float* fc_w /*(9,1536)*/, const float* fc_b, float* feat_or_null,
                    float* feat_scratch, float* pose, int B, int HW, int dtype, hipStream_t s);
 // colH > 0: the activation's pixels are stored column-major (x * colH + y, colH = the map's height); the probes index them row-major
-int launch_nhwc_to_nchw(const void* act /*(B,HW,C)*/, int B, int HW, int C, int dtype, float* out, hipStream_t s, int chunked = 0, int colH = 0);
+int launch_nhwc_to_nchw(const void* act /*(B,HW,C)*/, int B, int HW, int C, int dtype, float* out, hipStream_t s, int chunked = 0, int colH = 0, int perm_lw = 0, int perm_lp = 0);
 int launch_taps(const void* act /*(B,HW,C)*/, int B, int HW, int C, int dtype, float* taps /*(B,9,16)*/, int tap_index,
-                hipStream_t s, int colH = 0, int chunked = 0);   // chunked: [sample][ceil(C/16)][HW][16]
+                hipStream_t s, int colH = 0, int chunked = 0, int perm_lw = 0, int perm_lp = 0);   // chunked: [sample][ceil(C/16)][HW][16] (+ PwArgs::out_perm_*)
 // out (B, H*W, C) row-major pixels <- in (B, W*H, C) column-major pixels: the exit of a resolution stage that is stored transposed
 int launch_pixels_to_rowmajor(const void* in, void* out, int B, int H, int W, int C, int dtype, hipStream_t s);
 

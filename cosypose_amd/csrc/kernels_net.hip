@@ -117,9 +117,14 @@ void pw_pack_weights(const float* w, int K, int N, PwCfg c, int dtype, void* dst
 }
 
 // element offsets in the chunked activation layout [sample][ceil(C/16)][HW][16]: row m = (sample, pixel) / channel c
-__device__ __forceinline__ size_t chunked_row(int m, int HW, int C) {
+__device__ __forceinline__ size_t chunked_row(int m, int HW, int C, int lw = 0, int lp = 0) {
     const int bs = m / HW;
-    return ((size_t)bs * (size_t)((C + 15) >> 4) * (size_t)HW + (size_t)(m - bs * HW)) * 16;
+    int pix = m - bs * HW;
+    if (lw) {      // pixel x of a 2^lw-pixel row -> position (x mod 2^lp) * 16 + x / 2^lp
+        const int x = pix & ((1 << lw) - 1);
+        pix = (pix - x) + ((x & ((1 << lp) - 1)) << 4) + (x >> lp);
+    }
+    return ((size_t)bs * (size_t)((C + 15) >> 4) * (size_t)HW + (size_t)pix) * 16;
 }
 __device__ __forceinline__ size_t chunked_col(int c, int HW) { return (size_t)(c >> 4) * (size_t)HW * 16 + (size_t)(c & 15); }
 
@@ -132,6 +137,7 @@ struct PwKArgs {
     int nsamp, rowgate;   // DMA kernel gate: samples under one m-tile; 1 = gate the activation fragments per row
     int a_chunked;        // A is [sample][K/16][HW][16] (see PwArgs)
     int out_chunked, res_chunked;   // out / res are [sample][ceil(N/16)][HW][16] (see PwArgs)
+    int out_perm_lw, out_perm_lp;
     int a_nt;             // A is read exactly once (one n-tile) and is large: its DMAs carry the non-temporal hint
     // squeeze-excite computed in the prologue (PwArgs::se_fused): squeeze partial sums (B, se_tiles, K), reduce FC (Cse, K) + bias,
     // expand FC stored (Cse, K) + bias (K); se_wr == nullptr: the gate rows are read from `gate` (a squeeze-excite kernel wrote them)
@@ -501,7 +507,7 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
                     }
                 // a lane's run of 4 CG channels starts at a multiple of 4 CG: it never straddles a 16-channel chunk
                 const int c0 = nl + n1 * 4;
-                const size_t o = CHK && a.out_chunked ? chunked_row(m, a.HW, N) + chunked_col(c0, a.HW) : (size_t)m * N + c0;
+                const size_t o = CHK && a.out_chunked ? chunked_row(m, a.HW, N, a.out_perm_lw, a.out_perm_lp) + chunked_col(c0, a.HW) : (size_t)m * N + c0;
                 if (res) {
 #pragma unroll
                     for (int c = 0; c < CG; ++c) {
@@ -619,7 +625,7 @@ static int launch_pw_dma(const PwKArgs& k, PwCfg c, int grid, hipStream_t s) {
 template <typename T>
 static int launch_pw_t(const PwArgs& a, PwCfg c, int dtype, hipStream_t s) {
     PwKArgs k;
-    k.a_chunked = a.a_chunked; k.out_chunked = a.out_chunked; k.res_chunked = a.res_chunked;
+    k.a_chunked = a.a_chunked; k.out_chunked = a.out_chunked; k.res_chunked = a.res_chunked; k.out_perm_lw = a.out_chunked ? a.out_perm_lw : 0; k.out_perm_lp = a.out_perm_lp;
     k.A = a.A; k.Wp = a.Wp; k.out = a.out; k.scale = a.scale; k.bias = a.bias; k.res = a.res; k.gate = a.gate;
     k.M = a.M; k.K = a.K; k.N = a.N; k.HW = a.HW; k.silu = a.silu;
     k.MT = cdiv(a.M, pw_bm(c)); k.NT = cdiv(a.N, pw_bn(c));

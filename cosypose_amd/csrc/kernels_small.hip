@@ -239,21 +239,26 @@ int launch_pool_fc(const void* head, const float* fc_w, const float* fc_b, float
 
 // NHWC (T) -> NCHW fp32 export of an activation (API parity for backbone(x) and the test probes; not on the hot path).
 // chunked = 1: the source is in the fused fronts' D layout [sample][C/16][HW][16].
+__device__ __forceinline__ size_t perm_pixel(size_t p, int lw, int lp) {      // PwArgs::out_perm_lw / out_perm_lp
+    if (!lw) return p;
+    const size_t x = p & (((size_t)1 << lw) - 1);
+    return (p - x) + ((x & (((size_t)1 << lp) - 1)) << 4) + (x >> lp);
+}
 template <typename T>
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ act, int HW, int C, float* __restrict__ out, int chunked, int colH) {
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ act, int HW, int C, float* __restrict__ out, int chunked, int colH, int lw, int lp) {
     const int b = blockIdx.y;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // index in (C,HW)
     if (i >= (size_t)HW * C) return;
     const size_t c = i / HW;
     size_t p = i % HW;
     if (colH > 0) { const size_t Wm = (size_t)HW / colH; p = (p % Wm) * colH + p / Wm; }      // row-major pixel (y, x) lives at x * H + y
-    const size_t src = chunked ? ((size_t)b * ((C + 15) >> 4) + (c >> 4)) * HW * 16 + p * 16 + (c & 15) : ((size_t)b * HW + p) * C + c;
+    const size_t src = chunked ? ((size_t)b * ((C + 15) >> 4) + (c >> 4)) * HW * 16 + perm_pixel(p, lw, lp) * 16 + (c & 15) : ((size_t)b * HW + p) * C + c;
     out[(size_t)b * HW * C + i] = (float)act[src];
 }
-int launch_nhwc_to_nchw(const void* act, int B, int HW, int C, int dtype, float* out, hipStream_t s, int chunked, int colH) {
+int launch_nhwc_to_nchw(const void* act, int B, int HW, int C, int dtype, float* out, hipStream_t s, int chunked, int colH, int perm_lw, int perm_lp) {
     if (B == 0) return COSY_OK;
     dim3 grid(cdiv((long)HW * C, 256), B);
-    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, grid, dim3(256), 0, s, (const T*)act, HW, C, out, chunked, colH));
+    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, grid, dim3(256), 0, s, (const T*)act, HW, C, out, chunked, colH, perm_lw, perm_lp));
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }
@@ -262,13 +267,13 @@ int launch_nhwc_to_nchw(const void* act, int B, int HW, int C, int dtype, float*
 // test probe: [mean, mean|x|, 14 strided samples] of one NHWC activation, indexed as if NCHW-flattened
 // ==========================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void taps_kernel(const T* __restrict__ act, int HW, int C, float* __restrict__ taps, int tap_index, int colH, int chunked) {
+__global__ __launch_bounds__(256) void taps_kernel(const T* __restrict__ act, int HW, int C, float* __restrict__ taps, int tap_index, int colH, int chunked, int lw, int lp) {
     __shared__ double s1[256], s2[256];
     const int b = blockIdx.x, tid = threadIdx.x;
     // chunked = 1: [sample][ceil(C/16)][HW][16] (the input layout of the matrix-pipe wave fronts; the pad channels of the last chunk are not part of the tensor)
     const T* a = act + (size_t)b * HW * (chunked ? (size_t)((C + 15) & ~15) : (size_t)C);
     const size_t n = (size_t)HW * C;
-    auto at = [&](size_t p, size_t c) -> float { return (float)(chunked ? a[((c >> 4) * HW + p) * 16 + (c & 15)] : a[p * C + c]); };
+    auto at = [&](size_t p, size_t c) -> float { return (float)(chunked ? a[((c >> 4) * HW + perm_pixel(p, lw, lp)) * 16 + (c & 15)] : a[p * C + c]); };
     double x1 = 0, x2 = 0;
     for (size_t i = tid; i < n; i += 256) { const float v = at(i / C, i % C); x1 += v; x2 += fabsf(v); }
     s1[tid] = x1; s2[tid] = x2;
@@ -287,9 +292,9 @@ __global__ __launch_bounds__(256) void taps_kernel(const T* __restrict__ act, in
         t[2 + tid] = at(p, c);
     }
 }
-int launch_taps(const void* act, int B, int HW, int C, int dtype, float* taps, int tap_index, hipStream_t s, int colH, int chunked) {
+int launch_taps(const void* act, int B, int HW, int C, int dtype, float* taps, int tap_index, hipStream_t s, int colH, int chunked, int perm_lw, int perm_lp) {
     if (B == 0) return COSY_OK;
-    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(taps_kernel<T>, dim3(B), dim3(256), 0, s, (const T*)act, HW, C, taps, tap_index, colH, chunked));
+    COSY_DISPATCH_STMT(dtype, hipLaunchKernelGGL(taps_kernel<T>, dim3(B), dim3(256), 0, s, (const T*)act, HW, C, taps, tap_index, colH, chunked, perm_lw, perm_lp));
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }

@@ -46,6 +46,7 @@ struct WaveKArgs {
     // NHWC rows: xs_chunk = 16 * sizeof(T) (i.e. k * sizeof(T)); chunked input [sample][ceil(Cin/16)][H*W][16] (FuseArgs::x_chunked): xs_chunk = H * W * 16 * sizeof(T).
     int xs_chunk;
     long xs_sample;          // elements between two samples of the block input
+    int x_perm;              // fp32-FMA form: the pixels of an input row are stored permuted (FuseArgs::x_perm): the lanes' pixels p * PPL + q of fragment q are 16 neighbours
     int ds_pix, ds_row;      // elements between two neighbouring pixels of a row / between two rows inside a D chunk
     // -DCOSY_TUNE only (null in the shipping library): s_memtime stamps of one job in every `stamp_stride`-th workgroup (wave 0), see WAVE_STAMP
     unsigned long long* stamps; int stamp_stride, stamp_slots;
@@ -375,13 +376,14 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     // and k-block kb's are k-block 0's plus 64 kb bytes (the instruction's immediate) except for the last k-block, whose channel tail is clamped:
     // two offset registers instead of PPL * KBN.
     constexpr bool XUNI = FULLW;
-    const int qstep = (MX ? 16 : 1) * a.xs_pix;
+    const bool seg_addr = MX || a.x_perm;      // fragment q = 16 neighbouring stored pixels, 16 pixels behind fragment q - 1
+    const int qstep = (seg_addr ? 16 : 1) * a.xs_pix;
     int xoff[XUNI ? 1 : PPL][XUNI ? 2 : KBN];
     auto koff = [&](int k) -> int { return (k >> 4) * a.xs_chunk + (k & 15) * (int)sizeof(T); };      // byte offset of channel k inside a pixel (NHWC: k * sizeof(T))
     const int kbstep = (KB >> 4) * a.xs_chunk;     // bytes from k-block to k-block (wave-uniform: added to the row's scalar base; a k-block is whole 16-channel chunks)
     static_assert(KB % 16 == 0 && (EPL == 4 || EPL == 8), "a lane's EPL channels lie inside one 16-channel chunk");
     if constexpr (XUNI) {
-        const int px = (MX ? p : p * PPL) * a.xs_pix;
+        const int px = (seg_addr ? p : p * PPL) * a.xs_pix;
         xoff[0][0] = px + koff(kg * EPL);
         xoff[0][1] = px + koff(min((KBN - 1) * KB + kg * EPL, a.Cin - EPL));
     } else {
@@ -1146,6 +1148,14 @@ void wave_pack_params(const float* s0, const float* b0, const float* dww, const 
             }
         }
 }
+int wave_input_perm_lp(int Cin, int Cmid, int k, int s, int dtype, int H, int W) {
+    if (H <= 0 || dtype == COSY_F32) return 0;
+    const WavePlan p = wave_plan(Cin, Cmid, H, W, k, s, dtype);
+    if (!p.ok || p.mx || p.transposed || !p.fullw || p.ppl < 2 || (p.ppl & (p.ppl - 1))) return 0;      // full rows of 16 * 2^lp pixels (the uniform-offset loads)
+    int lp = 0;
+    while ((1 << lp) < p.ppl) ++lp;
+    return lp;
+}
 bool wave_taps_on_mfma(int Cin, int Cmid, int k, int s, int dtype, int H, int W) {
     if (H <= 0) return false;
     return wave_plan(Cin, Cmid, H, W, k, s, dtype).mx;
@@ -1222,6 +1232,8 @@ static int launch_wave_t(const FuseArgs& a, int* n_tiles_out, hipStream_t s) {
     const int px = (a.x_chunked ? 16 : a.Cin) * (int)sizeof(T);
     k.xs_chunk = a.x_chunked ? a.H * a.W * 16 * (int)sizeof(T) : 16 * (int)sizeof(T);
     k.xs_sample = a.x_chunked ? (long)((a.Cin + 15) >> 4) * a.H * a.W * 16 : (long)a.H * a.W * a.Cin;
+    k.x_perm = a.x_chunked && a.x_perm;
+    COSY_REQUIRE(!k.x_perm || (wave_input_perm_lp(a.Cin, a.Cmid, a.k, a.s, sizeof(T) == 4 ? COSY_F32 : COSY_BF16, a.H, a.W) > 0 && !a.x_colmajor), "mbconv_wave: permuted input rows need full power-of-two rows (%dx%d)", a.H, a.W);
     const int x_dx = a.x_colmajor ? a.H * px : px, x_dy = a.x_colmajor ? px : a.W * px;          // bytes per x step / y step of the block input
     const int d_dx = a.d_colmajor ? a.Ho * 16 : 16, d_dy = a.d_colmajor ? 16 : a.Wo * 16;       // elements per x step / y step inside a D chunk
     k.xs_pix = x_dx; k.xs_row = x_dy; k.ds_pix = d_dx; k.ds_row = d_dy;
