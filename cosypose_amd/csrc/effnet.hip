@@ -198,7 +198,10 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
         // on 8x8 / 7x10 maps (2-byte types), the tiled kernel on blocks 2-5 / 8 otherwise; whatever is left runs the shape-agnostic
         // unfused kernels (pw_gemm_dma -> E -> dwconv)
         b.wave = n->fuse && b.d.e != 1 && ((n->wave_mask >> i) & 1) && wave_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
-        b.small = !b.wave && n->fuse && b.d.e != 1 && ((n->small_mask >> i) & 1) && small_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
+        b.small = !b.wave && n->fuse && b.d.e != 1 && ((n->small_mask >> i) & 1) && small_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W) &&
+                  (n->dtype != COSY_BF16 || (tune_int("COSY_SMALL_MX_BF16", 0) && small_mx_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W)));
+        // bf16's hi + lo weight pairs: only the matrix-pipe form carries them (kernels_smx.hip, parity-green) -- and it is OFF: the doubled weight ring (91-104 KB of LDS)
+        // leaves one workgroup per CU, 98 / 63 / 191 us per block (19-23 / 24 / 25) against 90 / 72 / 113 us of the unfused pair (profiles/r06_dead_ends.txt)
         b.smx = b.small && small_mx_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
         b.tiled = !b.wave && !b.small && n->fuse && b.d.e != 1 && ((n->tile_mask >> i) & 1) && tile_supported(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype);
         b.fused = b.wave || b.small || b.tiled;
@@ -372,7 +375,7 @@ static void plan_channel_layout(cosy_net* n) {
     for (int i = 0; i < 26; ++i) {
         Block& b = n->blk[i];
         b.x_chunk = allow && i >= 1 && n->esz == 2 && b.wave && !n->blk[i - 1].to_rowmajor &&
-                    wave_taps_on_mfma(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
+                    wave_input_chunk_ok(b.d.cin, b.cmid, b.d.k, b.d.s, n->dtype, b.H, b.W);
         // the fp32-FMA fronts (stride-2 blocks 2 / 5 / 8 at 256x256): a lane owns a run of P pixels, fragment q = the 16 lanes' pixels p * P + q -- 16 neighbours only
         // if the row is stored in that order
         b.x_perm_lp = 0;
@@ -688,10 +691,10 @@ int cosy_effnet_b3_create(const float* host_params, size_t n_floats, int dtype, 
         n->stem_fused = n->fuse && stem_front_supported(dtype, H, W) &&
                         (size_t)max_batch * H * W * 8 * n->esz + 256 < ((size_t)1 << 32) - ((size_t)1 << 24);
         n->stemf_w = nullptr; n->stemf_params = nullptr;
-        // bf16 (round 6: hi + lo weight pairs in the GEMM and the wave fronts): the whole-image fronts of the 8x8 / 7x10 maps and the LDS-tiled front do not carry the
-        // pairs -- their blocks run the unfused kernels (pw_gemm_dma -> E -> dwconv), which do
+        // bf16 (round 6: hi + lo weight pairs in the GEMM, the wave fronts and the matrix-pipe form of the 8x8-map front): mbconv_small_kernel (7x10 maps) and the
+        // LDS-tiled front do not carry the pairs -- their blocks run the unfused kernels (pw_gemm_dma -> E -> dwconv), which do
         const bool pairs = dtype == COSY_BF16;
-        n->small_mask = pairs ? 0u : (unsigned)tune_int("COSY_SMALL_MASK", 0x3f80000);
+        n->small_mask = (unsigned)tune_int("COSY_SMALL_MASK", 0x3f80000);      // (bf16: only where the matrix-pipe form exists, build_weights)
         n->tile_mask = pairs ? 0u : (unsigned)tune_int("COSY_TILE_MASK", 0x13c);         // blocks 2-5 and 8 (measured in round 1: it loses on the k=5 stride-1 blocks 6/7)   // blocks 19-25 (8x8 / 7x10 maps): whole-image kernel
         n->wave_mask = (unsigned)tune_int("COSY_WAVE_MASK", 0x3fffc);   // blocks 2-17: maps 16..128 pixels wide, stride per shape table
         n->nstreams = tune_int("COSY_STREAMS", 1) == 2 && max_batch >= 32 ? 2 : 1;   // measured: 2 streams x half batches is ~10 % slower

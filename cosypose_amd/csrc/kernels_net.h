@@ -106,6 +106,7 @@ bool wave_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W);
 bool wave_walks_columns(int Cin, int Cmid, int k, int s, int dtype, int H, int W);   // the job's rows are the map's columns (transposed walk)
 size_t wave_params_floats(int Cin, int Cmid, int k, int s, int dtype, int H, int W);
 int wave_input_perm_lp(int Cin, int Cmid, int k, int s, int dtype, int H, int W);    // > 0: this block's wave front (fp32-FMA taps, full power-of-two rows) reads its input with the pixels of a row permuted for runs of 2^lp
+bool wave_input_chunk_ok(int Cin, int Cmid, int k, int s, int dtype, int H, int W);   // the wave front of this block reads a chunked input [sample][C/16][HW][16] at the full address rate
 bool wave_taps_on_mfma(int Cin, int Cmid, int k, int s, int dtype, int H, int W);     // the wave kernel applies this block's depthwise taps with small MFMAs (E and the taps in the storage type)
 void wave_pack_params(const float* s0, const float* b0, const float* dww, const float* s1, const float* b1, int Cin, int Cmid, int k, int s,
                       int dtype, int H, int W, float* dst);

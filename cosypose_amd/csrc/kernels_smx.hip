@@ -17,7 +17,8 @@
 //     the row ends).  2 KS small MFMAs per tile against Toeplitz fragments packed on the host (the wave kernel's);
 //   * BatchNorm 1 + SiLU + squeeze sums where the outputs land (lane = (channel, quad)), rounding, lane permutation back and the transposing
 //     v_mfma_f32_16x16x16 against the identity -> lane = (pixel, 4 channels): 8-byte stores into the chunked D layout [sample][Cmid/16][64][16].
-// Numerics: E and the taps are rounded to the storage type (block_info kind 6; the oracle's emulation follows), accumulation fp32.
+// Numerics: E and the taps are rounded to the tap MFMAs' operand type -- fp16 in both 16-bit modes, as in the wave kernel (block_info kind 6; the oracle's emulation
+// follows), accumulation fp32.  bf16 (round 6): the expand weights are hi + lo pairs (kernels_net.hip: pw_hl), two MFMAs per k-block against the same input fragment.
 #include "net_device.h"
 
 namespace cosy {
@@ -47,12 +48,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     using raw_t = typename DT<T>::raw_t;
     constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
     constexpr int NI = 3, CC = 48, LO = (KS - 1) / 2, PBYTES = smx_pbytes(KS), PJ = PBYTES / 1024;
+    constexpr int HL = __is_same(T, bf16_t) ? 2 : 1, NF = KBN * HL;      // weight fragments per 16-channel tile: [k-block][hi | lo]
     typedef T t4 __attribute__((ext_vector_type(4)));
+    typedef f16_t tt4 __attribute__((ext_vector_type(4)));          // operands of the tap MFMAs: fp16 in both 16-bit modes (a register / LDS format between two MFMAs, not storage)
     typedef T out_t __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Eh = smem;                               // [6 segments][NI][64 lanes] 8 bytes
     char* Wl = Eh + 6 * NI * 512;
-    char* Pl = Wl + NI * KBN * 1024;
+    char* Pl = Wl + NI * NF * 1024;
     float* red = (float*)(Pl + 2 * PBYTES);        // [4 waves][48]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -63,9 +66,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const int cb = lane >> 2, jq = lane & 3;       // small-MFMA roles: channel of the tile, quad (row jq >> 1 of the segment, half jq & 1)
 
     auto issue_w = [&](int ch) {
-        for (int blk = wave; blk < NI * KBN; blk += 4) {
-            const int ni = blk / KBN, kb = blk - ni * KBN;
-            const T* src = (const T*)a.Wp + ((size_t)(ch * NI + ni) * a.nkb_total + kb) * 64 * EPL + lane * EPL;
+        for (int blk = wave; blk < NI * NF; blk += 4) {
+            const int ni = blk / NF, f = blk - ni * NF;
+            const T* src = (const T*)a.Wp + (((size_t)(ch * NI + ni) * a.nkb_total + f / HL) * HL + f % HL) * 64 * EPL + lane * EPL;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(Wl + (size_t)blk * 1024), 16, 0, 0);
         }
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 #pragma unroll
     for (int e = 0; e < 4; ++e) ident[e] = (T)(4 * kg + e == prow ? 1.f : 0.f);
     auto cvt = [](float v) -> T { if constexpr (__is_same(T, f16_t)) return (T)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); else return (T)v; };
+    auto cvt_e = [](float v) -> f16_t { return (f16_t)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); };      // E as a tap operand: fp16, saturating
     const bool row0 = jq < 2, half0 = (jq & 1) == 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weights / parameters of the first chunk and the input fragments have landed
     __syncthreads();
@@ -108,17 +112,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                 acc[ni] = f32x4{b0, b0, b0, b0};
             }
 #pragma unroll
-            for (int kb = 0; kb < KBN; ++kb)
+            for (int f = 0; f < NF; ++f)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) mma(acc[ni], xf[kb], *(const raw_t*)(Wl + (size_t)(ni * KBN + kb) * 1024 + lane * 16));
+                for (int ni = 0; ni < NI; ++ni) mma(acc[ni], xf[f / HL], *(const raw_t*)(Wl + (size_t)(ni * NF + f) * 1024 + lane * 16));
             smx_i32x2 hh[NI];
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                t4 hv;
+                tt4 hv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float t = acc[ni][e];                             // = log2(e) * BN0(expand)
-                    hv[e] = cvt(t * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-t)) * 0.6931471805599453f);      // silu
+                    hv[e] = cvt_e(t * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-t)) * 0.6931471805599453f);      // silu
                 }
                 hh[ni] = __builtin_bit_cast(smx_i32x2, hv);
             }
@@ -144,13 +148,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                 for (int q = 0; q < 3; ++q) Sw[ni][q] = smx_i32x2{smx_dpp<0x4E>(S[ni][q][0]), smx_dpp<0x4E>(S[ni][q][1])};             // rows of the segment swapped (quad_perm [2,3,0,1])
             // every LDS read of the phase is issued up front (the Toeplitz fragments: 2 KS x 3 register pairs): a read's round trip is several hundred
             // cycles while the next chunk's DMA is writing into the LDS, and 2 waves per SIMD do not hide one per tap row
-            t4 A0[KS][NI], A1[KS][NI];
+            tt4 A0[KS][NI], A1[KS][NI];
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    A0[ky][ni] = *(const t4*)(P + SMX_HDR + (size_t)((ni * KS + ky) * 2 + 0) * 512 + lane * 8);
-                    A1[ky][ni] = *(const t4*)(P + SMX_HDR + (size_t)((ni * KS + ky) * 2 + 1) * 512 + lane * 8);
+                    A0[ky][ni] = *(const tt4*)(P + SMX_HDR + (size_t)((ni * KS + ky) * 2 + 0) * 512 + lane * 8);
+                    A1[ky][ni] = *(const tt4*)(P + SMX_HDR + (size_t)((ni * KS + ky) * 2 + 1) * 512 + lane * 8);
                 }
             float s1v[NI], b1v[NI];
 #pragma unroll
@@ -176,9 +180,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                     w2[ni] = smx_i32x2{half0 ? 0 : hpm, half0 ? lnm : 0};
                 }
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) accx[ni] = smx_mma4(A0[ky][ni], __builtin_bit_cast(t4, op[ni]), accx[ni]);
+                for (int ni = 0; ni < NI; ++ni) accx[ni] = smx_mma4(A0[ky][ni], __builtin_bit_cast(tt4, op[ni]), accx[ni]);
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) accx[ni] = smx_mma4(A1[ky][ni], __builtin_bit_cast(t4, w2[ni]), accx[ni]);
+                for (int ni = 0; ni < NI; ++ni) accx[ni] = smx_mma4(A1[ky][ni], __builtin_bit_cast(tt4, w2[ni]), accx[ni]);
             }
             smx_i32x2 hh[NI];
 #pragma unroll
@@ -250,7 +254,7 @@ void small_mx_pack_params(const float* b0l2e, const float* dww, const float* s1,
                         for (int q = 0; q < 4; ++q) {
                             const int i = lane & 3, cc = ch * 48 + ni * 16 + (lane >> 2), kx = off[m][q] - i + lo;
                             const float w = (kx >= 0 && kx < k) ? dww[(size_t)(ky * k + kx) * Cmid + cc] : 0.f;
-                            fr[((((size_t)ni * k + ky) * 2 + m) * 64 + lane) * 4 + q] = dtype == COSY_BF16 ? smx_bf16_bits(w) : smx_f16_bits(w);
+                            fr[((((size_t)ni * k + ky) * 2 + m) * 64 + lane) * 4 + q] = smx_f16_bits(w);      // fp16 in both 16-bit modes (the tap MFMAs' operand type)
                         }
     }
 }
@@ -260,7 +264,8 @@ void small_mx_kernel_name(int Cin, int k, int dtype, char* buf, size_t n) {
 
 template <typename T, int KS, int KBN>
 static int launch_smx_k(const SmxKArgs& k, int B, hipStream_t s) {
-    const size_t lds = (size_t)6 * 3 * 512 + (size_t)3 * KBN * 1024 + (size_t)2 * smx_pbytes(KS) + 4 * 48 * sizeof(float);
+    constexpr int HL = __is_same(T, bf16_t) ? 2 : 1;      // bf16: hi + lo weight fragments
+    const size_t lds = (size_t)6 * 3 * 512 + (size_t)3 * KBN * HL * 1024 + (size_t)2 * smx_pbytes(KS) + 4 * 48 * sizeof(float);
     static const hipError_t attr_rc = hipFuncSetAttribute((const void*)mbconv_small_mx_kernel<T, KS, KBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     COSY_CHECK_HIP(attr_rc);
     hipLaunchKernelGGL((mbconv_small_mx_kernel<T, KS, KBN>), dim3((unsigned)(B * k.ncg)), dim3(256), lds, s, k);

@@ -1156,6 +1156,14 @@ int wave_input_perm_lp(int Cin, int Cmid, int k, int s, int dtype, int H, int W)
     while ((1 << lp) < p.ppl) ++lp;
     return lp;
 }
+// does this block's wave front read its input at the full rate of the vector-memory address path from the chunked layout [sample][C/16][H*W][16]?  Yes when the 16
+// lanes of a fragment are 16 NEIGHBOURING pixels of the walk (32 bytes apart: 4 lanes per 128-byte line): the matrix-pipe form (fragment = a 16-pixel segment) and the
+// fp32-FMA form with one pixel per lane.  (A lane's run of P > 1 pixels puts the lanes 32 P bytes apart -- P = 4 is the 128-byte stride that costs four cycles per quad.)
+bool wave_input_chunk_ok(int Cin, int Cmid, int k, int s, int dtype, int H, int W) {
+    if (H <= 0 || dtype == COSY_F32) return false;
+    const WavePlan p = wave_plan(Cin, Cmid, H, W, k, s, dtype);
+    return p.ok && (p.mx || p.ppl == 1);
+}
 bool wave_taps_on_mfma(int Cin, int Cmid, int k, int s, int dtype, int H, int W) {
     if (H <= 0) return false;
     return wave_plan(Cin, Cmid, H, W, k, s, dtype).mx;
