@@ -5,7 +5,7 @@
 # the rocprofv3 stats + PMC summaries (profiles/collect.sh) and the batch sweep with matrix-core utilisation.
 # Copy what is to be judged into profiles/ afterwards (profiles/publish.sh <tag>).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/all_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

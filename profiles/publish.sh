@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy the judged artefacts of a profiles/collect_all.sh run from gpurun_out/ (scratch) into profiles/ (tracked):
 #   profiles/publish.sh <tag> [round-prefix]      e.g. profiles/publish.sh r02c r02
-TAG=${1:?tag}; R=${2:-r05}
+TAG=${1:?tag}; R=${2:-r06}
 S=gpurun_out/all_$TAG
 cp $S/bench.json profiles/${R}_bench.json
 cp $S/layers_events.txt profiles/${R}_layers_events.txt
