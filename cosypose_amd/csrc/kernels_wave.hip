@@ -189,7 +189,13 @@ template <int MINW> __device__ __forceinline__ void xfrag_reserve() {
 #ifndef COSY_WAVE_MX
 #define COSY_WAVE_MX 1
 #endif
-constexpr bool wave_mx(int esz, int ks, int s, int ppl, bool fullw) { return COSY_WAVE_MX && esz == 2 && s == 1 && ppl >= 1 && fullw && (ks == 3 || ks == 5); }
+// Rows that do not fill their last 16-pixel segment (round 6; 240x320 crops: the 15- and 30-pixel columns of the 15x20 / 30x40 maps): the pixels beyond the row end
+// are expanded from a clamped address, forced to zero before they become tap operands (= the zero padding their neighbours need), left out of the squeeze sums and
+// not stored.  -DCOSY_WAVE_MXP=0: such rows keep the fp32-FMA form.
+#ifndef COSY_WAVE_MXP
+#define COSY_WAVE_MXP 1
+#endif
+constexpr bool wave_mx(int esz, int ks, int s, int ppl, bool fullw) { return COSY_WAVE_MX && esz == 2 && s == 1 && ppl >= 1 && (fullw || COSY_WAVE_MXP) && (ks == 3 || ks == 5); }
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 mma4(f16x4 a, f16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x4f16(a, b, c, 0, 0, 0); }
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
         for (int kb = 0; kb < KBN; ++kb) {
             const int k = kb * KB + kg * EPL;
 #pragma unroll
-            for (int q = 0; q < PPL; ++q) xoff[q][kb] = min(p * PPL + q, a.W - 1) * a.xs_pix + koff(min(k, a.Cin - EPL));
+            for (int q = 0; q < PPL; ++q) xoff[q][kb] = min(MX ? 16 * q + p : p * PPL + q, a.W - 1) * a.xs_pix + koff(min(k, a.Cin - EPL));      // (MX: fragment q = the segment's 16 pixels)
         }
     }
     // The input fragments are loaded by inline asm and waited for with a COUNTED s_waitcnt: vmcnt retires loads and stores
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
     static_assert(MINW >= 2 && MINW <= 5);
     xfrag_reserve<MINW>();
     constexpr bool XASM = COSY_WAVE_XASM && sizeof(T) == 2;   // the MFMAs read the fragments in place (xfrag_mma)
-    constexpr bool PIPE = COSY_WAVE_PIPE && MX && XASM && PPL == 1;       // matrix-pipe form: row iy's expansion side and row iy - 1's tap / output side in one iteration (row_mx)
+    constexpr bool PIPE = COSY_WAVE_PIPE && MX && XASM && PPL == 1 && FULLW;       // matrix-pipe form: row iy's expansion side and row iy - 1's tap / output side in one iteration (row_mx)
     raw_t wf[NI][NF];                        // the chunk's expand-weight fragments, [k-block][hi | lo] (WLDS: parked in LDS instead)
     f32x4 xc[XASM ? 1 : PPL][XASM ? 1 : KBN];
     int st_in_flight = 0;                    // stores issued behind the newest loads (wave-uniform)
@@ -554,7 +560,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
 #pragma unroll
             for (int t = 0; t < TO; ++t) {
                 if (COSY_DBG(a.dbg & 4) && t > 0) break;                                 // dbg 4: one store per row
-                if (FULLW || p * TO + t < a.Wo) {
+                if (FULLW || (MX ? 16 * t + p : p * TO + t) < a.Wo) {
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) *(out_t*)(o + t * dpix) = yv[t][ni];
                 }
@@ -598,6 +604,10 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) y4[e] = m[e] * mxp[0] + mxp[1];
                         if (!COSY_DBG(a.dbg & 512)) silu4<false>(y4);      // dbg 512: no SiLU (timing)
+                        if constexpr (!FULLW) {                           // pixels beyond the row end pad their neighbours (this lane: pixels 16 q + 4 (lane >> 4) + e)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y4[e] = 16 * q + 4 * kg + e < a.W ? y4[e] : 0.f;
+                        }
                         const tt4 hv = tt4{cvt_e(y4[0]), cvt_e(y4[1]), cvt_e(y4[2]), cvt_e(y4[3])};      // E as the tap MFMAs' operand (fp16)
                         const i32x2 hh = __builtin_bit_cast(i32x2, hv);
                         lo[q] = hh[0]; hi[q] = hh[1];
@@ -715,7 +725,7 @@ __global__ __launch_bounds__(256, MINW) void mbconv_wave_kernel(WaveKArgs a) {
                             for (int e = 0; e < 4; ++e) y4[e] = accx[os][q][e] * mxp[2] + mxp[3];
                             if (!COSY_DBG(a.dbg & 512)) silu4<false>(y4);      // dbg 512: no SiLU (timing)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) sum[0] += y4[e];
+                            for (int e = 0; e < 4; ++e) { if constexpr (FULLW) sum[0] += y4[e]; else sum[0] += 16 * q + 4 * jq + e < a.Wo ? y4[e] : 0.f; }      // (this lane: pixels 16 q + 4 jq + e)
                             const t4 hv = t4{cvt(y4[0]), cvt(y4[1]), cvt(y4[2]), cvt(y4[3])};
                             const i32x2 hh = __builtin_bit_cast(i32x2, hv);
                             if (COSY_DBG(a.dbg & 256)) {                      // dbg 256: no permutation / transposition of the output row (timing)

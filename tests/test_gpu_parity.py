@@ -243,12 +243,14 @@ def test_fused_kernels_vs_storage_emulation(model, oracle, golden_sd, dtype, hw)
     assert (kinds[0] == 4) == (hw[1] in (256, 320)), kinds       # the stem + block-0 front: 256- and 320-pixel-wide crops (kernels_stem.hip), the unfused kernels elsewhere
     if hw in ((256, 256), (240, 320)):     # blocks 2-17 wave (240x320: block 2's 160-pixel rows are walked as 120-pixel columns), 19-25 small
         assert all(k in (1, 5) for k in kinds[2:18]) and all(k == (0 if pairs else 6 if hw == (256, 256) else 2) for k in kinds[19:26]) and kinds[18] == 0, kinds      # 6: the small kernel's matrix-pipe form (8x8 maps)
-        # 5 = the wave kernel with its depthwise taps on the matrix pipe (stride-1 blocks whose rows are whole 16-pixel segments: 3, 4, 6, 7, 9-17 at 256x256)
-        assert [i for i, k in enumerate(kinds) if k == 5] == ([3, 4, 6, 7] + list(range(9, 18)) if hw == (256, 256) else [3, 4]), kinds      # 240x320: the 80-pixel rows of blocks 3 / 4
+        # 5 = the wave kernel with its depthwise taps on the matrix pipe: every stride-1 wave block (3, 4, 6, 7, 9-17).  Round 6: also rows whose last 16-pixel segment
+        # is partial (240x320: the 30- and 15-pixel columns of blocks 6 / 7 and 9-17) -- the pixels beyond the row end are zeroed as tap operands, not summed, not stored
+        assert [i for i, k in enumerate(kinds) if k == 5] == [3, 4, 6, 7] + list(range(9, 18)), kinds
     if hw == (224, 224):                   # 56-pixel rows of blocks 3 / 4: no wave variant -> tiled; every other front has a !FULLW wave variant
-        assert [i for i, k in enumerate(kinds) if k == 3] == ([] if pairs else [3, 4]) and [i for i, k in enumerate(kinds) if k == 1] == [2] + list(range(5, 18)), kinds
+        assert [i for i, k in enumerate(kinds) if k == 3] == ([] if pairs else [3, 4]) and [i for i, k in enumerate(kinds) if k in (1, 5)] == [2] + list(range(5, 18)), kinds
+        assert [i for i, k in enumerate(kinds) if k == 5] == [6, 7] + list(range(9, 18)), kinds      # the stride-1 blocks among them: matrix-pipe taps on partial segments (28 / 14 pixels)
     if hw == (416, 416):                   # 208 / 104-pixel rows: the tiled kernel in all its k / stride forms (k3 s2, k3 s1, k5 s2)
-        assert [i for i, k in enumerate(kinds) if k == 3] == ([] if pairs else [2, 3, 4, 5]) and [i for i, k in enumerate(kinds) if k == 1] == list(range(8, 18)), kinds
+        assert [i for i, k in enumerate(kinds) if k == 3] == ([] if pairs else [2, 3, 4, 5]) and [i for i, k in enumerate(kinds) if k in (1, 5)] == list(range(8, 18)), kinds
     from cosypose_amd._lib import lib, check, ptr, stream
     check(lib().cosy_effnet_b3_set_input_nchw(h, ptr(dev(x)), B, stream()))
     tr = oracle.TorchRef(golden_sd)
