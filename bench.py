@@ -588,19 +588,46 @@ def main():
         roofline['next_instantiations'] = [line(n_, k_) for n_, k_ in sorted(members.items(), key=lambda kv: -kv[1]['ms']) if n_ != inst_name][:2]
         roofline['traffic'] = None
         # HBM bytes per launch from PMC counters cannot be measured from inside this process (rocprofv3 = separate process): taken from the
-        # newest profiles/r*_pmc_traffic.json that was collected for exactly these kernel sources and this dtype, else null
+        # newest profiles/r*_pmc_traffic.json that was collected for exactly these kernel sources and this dtype, else null.  rocprofv3 names an
+        # instantiation with ALL its template arguments, this table with the leading ones: match by prefix, launches-weighted over the matches.
         import glob
         note = 'HBM counters need rocprofv3 (separate process): see profiles/collect_all.sh'
+        tj_use = None
         if cfg_i == 1 and args.crop == '256x256' and (args.detections or 256) == 256:
             for tfile in sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
                 tj = json.load(open(tfile))
-                if tj.get('csrc_sha') == csrc_sha() and tj.get('dtype', 'bf16') == dtype and inst_name in tj.get('kernels', {}):
-                    t = tj['kernels'][inst_name]
-                    roofline['traffic'] = round(t['read_bytes'] + t['write_bytes'])
+                if tj.get('csrc_sha') == csrc_sha() and tj.get('dtype', 'bf16') == dtype:
+                    tj_use = tj
                     note = f"profiles/{os.path.basename(tfile)} (PMC passes of this command on kernel sources {tj['csrc_sha']})"
                     break
             else:
                 note = 'no profiles/r*_pmc_traffic.json was collected for these kernel sources: not reported'
+
+        def traffic_for(name):
+            if not tj_use or '<' not in name:
+                return None
+            stem = name[:-1]
+            hits = [v for k_, v in tj_use.get('kernels', {}).items() if k_ == name or k_.startswith(stem + ',')]
+            nl = sum(v['launches'] for v in hits)
+            return round(sum((v['read_bytes'] + v['write_bytes']) * v['launches'] for v in hits) / nl) if nl else None
+        roofline['traffic'] = traffic_for(inst_name)
+        for n_ in roofline['next_instantiations']:
+            n_['traffic'] = traffic_for(n_['kernel'])
+        # the other kernel families by time, each with its leading instantiation: the line always shows the fused MBConv fronts (mbconv_wave_kernel: the
+        # dominant family until round 5, 0.175 of the HBM roof on blocks 14-17 then) beside the 1x1-conv GEMMs, whichever of the two leads the build
+        others = []
+        for fn_, fk_ in sorted(fams.items(), key=lambda kv: -kv[1]['ms']):
+            if fn_ == fam_name or len(others) >= 2:
+                continue
+            mem_ = {n: k for n, k in kinds.items() if n.split('<')[0].split('+')[0] == fn_}
+            top_ = sorted(mem_.items(), key=lambda kv: -kv[1]['ms'])[:3]
+            insts_ = []
+            for n__, k__ in top_:
+                l__ = line(n__, k__)
+                l__['traffic'] = traffic_for(n__)
+                insts_.append(l__)
+            others.append(dict(family=line(fn_, fk_), instantiations=insts_))
+        roofline['other_families'] = others
         roofline['traffic_source'] = note
         roofline['backbone_ms_per_forward'] = round(total_ms / max(n_fw, 1), 3)
         roofline['launch'] = (f'{prof_bsz} crops per launch, timed with one HIP event per launch in a single-stream pass after the timed region' +
