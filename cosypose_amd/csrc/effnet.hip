@@ -276,7 +276,7 @@ static long build_weights(cosy_net* n, const float* p, Bump& bump, bool fill, hi
                     fold_bn(pe, b.cmid, b.cmid, sc0, bi0);
                     std::vector<float> b0l(b.cmid);
                     for (int c = 0; c < b.cmid; ++c) b0l[c] = (float)((double)bi0[c] * 1.4426950408889634);
-                    small_mx_pack_params(b0l.data(), w.data(), sc.data(), bi.data(), b.cmid, b.d.k, n->dtype, sp.data());
+                    small_mx_pack_params(b0l.data(), w.data(), sc.data(), bi.data(), b.cmid, b.d.k, n->dtype, sp.data(), small_mx_transposed(b.H, b.W));
                 }
                 b.wave_params = (float*)bump.take(sp.size());
                 if (fill) bump.stage(b.wave_params, sp.data(), sp.size());

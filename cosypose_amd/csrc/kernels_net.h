@@ -97,7 +97,8 @@ bool small_writes_chunked(int Cin, int Cmid, int H, int W, int Ho, int Wo, int k
 // small_mx_pack_params (log2(e) * BN0 bias, folded BatchNorm 1, Toeplitz tap fragments in the storage type); D chunked; partial has ONE tile per sample
 bool small_mx_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W);
 size_t small_mx_param_bytes(int Cmid, int k);
-void small_mx_pack_params(const float* b0l2e, const float* dww, const float* s1, const float* b1, int Cmid, int k, int dtype, void* dst);
+void small_mx_pack_params(const float* b0l2e, const float* dww, const float* s1, const float* b1, int Cmid, int k, int dtype, void* dst, int transposed = 0);
+bool small_mx_transposed(int H, int W);    // 7x10 maps: the kernel walks the map's columns (taps packed as w[kx][ky])
 void small_mx_kernel_name(int Cin, int k, int dtype, char* buf, size_t n);
 int launch_mbconv_small_mx(const FuseArgs& a, int dtype, hipStream_t s);
 // wave-autonomous variant (kernels_wave.hip): expanded rows in registers, no LDS ring / barriers; expand weights packed with

@@ -39,12 +39,16 @@ template <int CTRL> __device__ __forceinline__ float smx_dppf(float v) { return 
 struct SmxKArgs {
     const void* X; const void* Wp; const char* params; void* D; float* partial; const void* zeros;
     int Cin, Cmid, nkb_total, ncg, cpw, dbg;
+    // the map as the kernel walks it: NSEG segments of two 8-pixel walk rows; walk pixel (r, c) = map pixel r * Wm + c, or c * Wm + r for a transposed walk (7x10 maps:
+    // the 10 columns are the walk rows); cv = valid pixels of a walk row (8, or 7: the eighth is expanded from a clamped address, zeroed as a tap operand, left out of
+    // the squeeze sums and not stored); HW = pixels of the map
+    int HW, Wm, tr, cv;
 };
 enum { SMX_HDR = 1024 };       // bytes of a chunk's parameter header [b0 * log2 e 48][s1 48][b1 48] fp32 (padded to one DMA instruction)
 constexpr int smx_pbytes(int ks) { return SMX_HDR + 3 * ks * 2 * 512; }   // + [tile 3][ky][operand 2][lane 64] 8-byte Toeplitz fragments
 
-template <typename T, int KS, int KBN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void mbconv_small_mx_kernel(SmxKArgs a) {
+template <typename T, int KS, int KBN, int NSEG>
+__global__ __launch_bounds__(NSEG * 64) __attribute__((amdgpu_waves_per_eu(2, 3))) void mbconv_small_mx_kernel(SmxKArgs a) {
     using raw_t = typename DT<T>::raw_t;
     constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
     constexpr int NI = 3, CC = 48, LO = (KS - 1) / 2, PBYTES = smx_pbytes(KS), PJ = PBYTES / 1024;
@@ -53,10 +57,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     typedef f16_t tt4 __attribute__((ext_vector_type(4)));          // operands of the tap MFMAs: fp16 in both 16-bit modes (a register / LDS format between two MFMAs, not storage)
     typedef T out_t __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Eh = smem;                               // [6 segments][NI][64 lanes] 8 bytes
-    char* Wl = Eh + 6 * NI * 512;
+    char* Eh = smem;                               // [NSEG + 2 segments][NI][64 lanes] 8 bytes
+    char* Wl = Eh + (NSEG + 2) * NI * 512;
     char* Pl = Wl + NI * NF * 1024;
-    float* red = (float*)(Pl + 2 * PBYTES);        // [4 waves][48]
+    float* red = (float*)(Pl + 2 * PBYTES);        // [NSEG waves][48]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x / a.ncg, cg = blockIdx.x - b * a.ncg;
@@ -66,13 +70,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const int cb = lane >> 2, jq = lane & 3;       // small-MFMA roles: channel of the tile, quad (row jq >> 1 of the segment, half jq & 1)
 
     auto issue_w = [&](int ch) {
-        for (int blk = wave; blk < NI * NF; blk += 4) {
+        for (int blk = wave; blk < NI * NF; blk += NSEG) {
             const int ni = blk / NF, f = blk - ni * NF;
             const T* src = (const T*)a.Wp + (((size_t)(ch * NI + ni) * a.nkb_total + f / HL) * HL + f % HL) * 64 * EPL + lane * EPL;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(Wl + (size_t)blk * 1024), 16, 0, 0);
         }
-        for (int j = wave; j < PJ; j += 4) {
+        for (int j = wave; j < PJ; j += NSEG) {
             const char* src = a.params + (size_t)ch * PBYTES + (size_t)j * 1024 + lane * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(Pl + (size_t)(ch & 1) * PBYTES + (size_t)j * 1024), 16, 0, 0);
@@ -82,14 +86,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     // this wave's segment of the block input (rows 2 wave, 2 wave + 1) -> registers: the A operand (rows = pixels) of the expansion
     raw_t xf[KBN];
     {
-        const T* __restrict__ X = (const T*)a.X + ((size_t)b * 64 + wave * 16 + prow) * a.Cin;
+        const int xr = 2 * wave + (prow >> 3), xc = min(prow & 7, a.cv - 1);      // walk pixel of this lane's MFMA row (beyond the walk row: a clamped, valid address)
+        const T* __restrict__ X = (const T*)a.X + ((size_t)b * a.HW + (a.tr ? xc * a.Wm + xr : xr * a.Wm + xc)) * a.Cin;
 #pragma unroll
         for (int kb = 0; kb < KBN; ++kb) {
             const int k = kb * KB + kg * EPL;
             xf[kb] = *(const raw_t*)(k < a.Cin ? (const void*)(X + k) : a.zeros);
         }
     }
-    for (int i = tid; i < 6 * NI * 512 / 16; i += 256) *(f32x4*)(Eh + (size_t)i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};   // segments -1 and 4 are never written
+    for (int i = tid; i < (NSEG + 2) * NI * 512 / 16; i += NSEG * 64) *(f32x4*)(Eh + (size_t)i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};   // segments -1 and NSEG are never written
     const int bp_in = (cb + 16 * jq) * 4, bp_out = (4 * prow + kg) * 4;
     t4 ident;
 #pragma unroll
@@ -124,6 +129,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                     const float t = acc[ni][e];                             // = log2(e) * BN0(expand)
                     hv[e] = cvt_e(t * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-t)) * 0.6931471805599453f);      // silu
                 }
+                if (a.cv < 8 && (kg & 1)) hv[3] = (f16_t)0.f;         // this lane's pixels 4 kg .. 4 kg + 3 of the segment: the eighth pixel of a walk row pads its neighbours
                 hh[ni] = __builtin_bit_cast(smx_i32x2, hv);
             }
 #pragma unroll
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                 for (int e = 0; e < 4; ++e) {
                     float v = accx[ni][e] * s1 + b1;
                     v = v * sigmoid_t<T>(v);
-                    sum += v;
+                    sum += (e == 3 && a.cv < 8 && (jq & 1)) ? 0.f : v;          // (this lane's pixels 4 jq .. 4 jq + 3: the eighth pixel of a walk row is not part of the map)
                     hv[e] = cvt(v);
                 }
                 sum += smx_dppf<0xB1>(sum);                                 // the 4 quads of the segment (fixed order)
@@ -212,13 +218,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         }
         // Global stores count in vmcnt and retire in order with the loads: the wait for the next chunk's DMA comes BEFORE this chunk's stores
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!COSY_DBG(a.dbg & 1)) {
+        if (!COSY_DBG(a.dbg & 1) && (prow & 7) < a.cv) {
+            const int yr = 2 * wave + (prow >> 3), yc = prow & 7, ypix = a.tr ? yc * a.Wm + yr : yr * a.Wm + yc;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                *(out_t*)((T*)a.D + (((size_t)b * (a.Cmid >> 4) + ch * NI + ni) * 64 + wave * 16 + prow) * 16 + kg * 4) = yv[ni];
+                *(out_t*)((T*)a.D + (((size_t)b * (a.Cmid >> 4) + ch * NI + ni) * a.HW + ypix) * 16 + kg * 4) = yv[ni];
         }
         __syncthreads();   // red complete; everybody's DMA(ch+1) landed; all Eh / parameter reads of this chunk are done
-        if (tid < CC && !COSY_DBG(a.dbg & 1)) a.partial[(size_t)b * a.Cmid + ch * CC + tid] = ((red[tid] + red[CC + tid]) + red[2 * CC + tid]) + red[3 * CC + tid];
+        if (tid < CC && !COSY_DBG(a.dbg & 1)) {
+            float sm = ((red[tid] + red[CC + tid]) + red[2 * CC + tid]) + red[3 * CC + tid];
+            if constexpr (NSEG == 5) sm += red[4 * CC + tid];
+            a.partial[(size_t)b * a.Cmid + ch * CC + tid] = sm;
+        }
     }
 }
 
@@ -231,14 +242,17 @@ static inline uint16_t smx_bf16_bits(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
+bool small_mx_transposed(int H, int W) { return H == 7 && W == 10; }      // the map's columns are the walk rows
 static int smx_enabled() { static const int v = tune_int("COSY_SMALL_MX", 1); return v; }
 bool small_mx_supported(int Cin, int Cmid, int k, int s, int dtype, int H, int W) {
     const int kbn = cdiv(Cin, 32);
-    return smx_enabled() && dtype != COSY_F32 && H == 8 && W == 8 && s == 1 && (k == 3 || k == 5) && Cmid % 48 == 0 && (kbn == 8 || kbn == 12) && Cin % 8 == 0;
+    // 8x8 maps (256x256 crops); round 6: 7x10 (240x320: the ten columns walked as rows of 7 + 1 masked pixel) and 10x7 (320x240) maps: five segments, five waves
+    const bool map_ok = (H == 8 && W == 8) || (H == 7 && W == 10) || (H == 10 && W == 7);
+    return smx_enabled() && dtype != COSY_F32 && map_ok && s == 1 && (k == 3 || k == 5) && Cmid % 48 == 0 && (kbn == 8 || kbn == 12) && Cin % 8 == 0;
 }
 size_t small_mx_param_bytes(int Cmid, int k) { return (size_t)(Cmid / 48) * smx_pbytes(k); }
 // b0l2e: log2(e) * BN0 bias (its scale is folded into the expand weights); dww: fp32 taps [k*k][Cmid]; s1 / b1: folded BatchNorm 1
-void small_mx_pack_params(const float* b0l2e, const float* dww, const float* s1, const float* b1, int Cmid, int k, int dtype, void* dst) {
+void small_mx_pack_params(const float* b0l2e, const float* dww, const float* s1, const float* b1, int Cmid, int k, int dtype, void* dst, int transposed) {
     const int pb = smx_pbytes(k), lo = (k - 1) / 2;
     static const int off[2][4] = {{0, 1, 2, 3}, {-2, -1, 4, 5}};
     for (size_t i = 0; i < small_mx_param_bytes(Cmid, k); ++i) ((char*)dst)[i] = 0;
@@ -253,7 +267,7 @@ void small_mx_pack_params(const float* b0l2e, const float* dww, const float* s1,
                     for (int lane = 0; lane < 64; ++lane)
                         for (int q = 0; q < 4; ++q) {
                             const int i = lane & 3, cc = ch * 48 + ni * 16 + (lane >> 2), kx = off[m][q] - i + lo;
-                            const float w = (kx >= 0 && kx < k) ? dww[(size_t)(ky * k + kx) * Cmid + cc] : 0.f;
+                            const float w = (kx >= 0 && kx < k) ? dww[(size_t)(transposed ? kx * k + ky : ky * k + kx) * Cmid + cc] : 0.f;      // transposed walk: tap row = the map's kx
                             fr[((((size_t)ni * k + ky) * 2 + m) * 64 + lane) * 4 + q] = smx_f16_bits(w);      // fp16 in both 16-bit modes (the tap MFMAs' operand type)
                         }
     }
@@ -262,21 +276,26 @@ void small_mx_kernel_name(int Cin, int k, int dtype, char* buf, size_t n) {
     snprintf(buf, n, "mbconv_small_mx_kernel<%s, %d, %d>", dtype == COSY_BF16 ? "__bf16" : "_Float16", k, cdiv(Cin, 32));
 }
 
-template <typename T, int KS, int KBN>
-static int launch_smx_k(const SmxKArgs& k, int B, hipStream_t s) {
+template <typename T, int KS, int KBN, int NSEG>
+static int launch_smx_ks(const SmxKArgs& k, int B, hipStream_t s) {
     constexpr int HL = __is_same(T, bf16_t) ? 2 : 1;      // bf16: hi + lo weight fragments
-    const size_t lds = (size_t)6 * 3 * 512 + (size_t)3 * KBN * HL * 1024 + (size_t)2 * smx_pbytes(KS) + 4 * 48 * sizeof(float);
-    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)mbconv_small_mx_kernel<T, KS, KBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const size_t lds = (size_t)(NSEG + 2) * 3 * 512 + (size_t)3 * KBN * HL * 1024 + (size_t)2 * smx_pbytes(KS) + NSEG * 48 * sizeof(float);
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)mbconv_small_mx_kernel<T, KS, KBN, NSEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     COSY_CHECK_HIP(attr_rc);
-    hipLaunchKernelGGL((mbconv_small_mx_kernel<T, KS, KBN>), dim3((unsigned)(B * k.ncg)), dim3(256), lds, s, k);
+    hipLaunchKernelGGL((mbconv_small_mx_kernel<T, KS, KBN, NSEG>), dim3((unsigned)(B * k.ncg)), dim3(NSEG * 64), lds, s, k);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
+}
+template <typename T, int KS, int KBN>
+static int launch_smx_k(const SmxKArgs& k, int B, hipStream_t s) {
+    return k.HW == 64 ? launch_smx_ks<T, KS, KBN, 4>(k, B, s) : launch_smx_ks<T, KS, KBN, 5>(k, B, s);
 }
 template <typename T>
 static int launch_smx_t(const FuseArgs& a, hipStream_t s) {
     SmxKArgs k;
     k.X = a.X; k.Wp = a.Wp; k.params = (const char*)a.wparams; k.D = a.D; k.partial = a.partial; k.zeros = a.zeros;
     k.Cin = a.Cin; k.Cmid = a.Cmid; k.nkb_total = (cdiv(a.Cin, 32) + 1) & ~1;
+    k.HW = a.H * a.W; k.Wm = a.W; k.tr = small_mx_transposed(a.H, a.W); k.cv = a.H * a.W == 64 ? 8 : 7;
     const int nchunks = a.Cmid / 48;
     static const int cpw_target = tune_int("COSY_SMALL_CPW", 15);
     k.cpw = nchunks <= cpw_target ? nchunks : cdiv(nchunks, cdiv(nchunks, cpw_target));

@@ -242,7 +242,7 @@ def test_fused_kernels_vs_storage_emulation(model, oracle, golden_sd, dtype, hw)
     pairs = dtype == 'bf16'      # bf16: hi + lo weight pairs (round 6) in the GEMM and the wave fronts; the 8x8-map front carries them too but is slower than the unfused pair with its doubled weight ring (off), mbconv_small_kernel and the tiled front do not: their blocks run unfused
     assert (kinds[0] == 4) == (hw[1] in (256, 320)), kinds       # the stem + block-0 front: 256- and 320-pixel-wide crops (kernels_stem.hip), the unfused kernels elsewhere
     if hw in ((256, 256), (240, 320)):     # blocks 2-17 wave (240x320: block 2's 160-pixel rows are walked as 120-pixel columns), 19-25 small
-        assert all(k in (1, 5) for k in kinds[2:18]) and all(k == (0 if pairs else 6 if hw == (256, 256) else 2) for k in kinds[19:26]) and kinds[18] == 0, kinds      # 6: the small kernel's matrix-pipe form (8x8 maps)
+        assert all(k in (1, 5) for k in kinds[2:18]) and all(k == (0 if pairs else 6) for k in kinds[19:26]) and kinds[18] == 0, kinds      # 6: the small kernel's matrix-pipe form (8x8 maps; round 6: also the 7x10 maps of 240x320, walked by columns with the eighth pixel of a walk row masked)
         # 5 = the wave kernel with its depthwise taps on the matrix pipe: every stride-1 wave block (3, 4, 6, 7, 9-17).  Round 6: also rows whose last 16-pixel segment
         # is partial (240x320: the 30- and 15-pixel columns of blocks 6 / 7 and 9-17) -- the pixels beyond the row end are zeroed as tap operands, not summed, not stored
         assert [i for i, k in enumerate(kinds) if k == 5] == [3, 4, 6, 7] + list(range(9, 18)), kinds
