@@ -47,12 +47,17 @@ struct SmxKArgs {
 enum { SMX_HDR = 1024 };       // bytes of a chunk's parameter header [b0 * log2 e 48][s1 48][b1 48] fp32 (padded to one DMA instruction)
 constexpr int smx_pbytes(int ks) { return SMX_HDR + 3 * ks * 2 * 512; }   // + [tile 3][ky][operand 2][lane 64] 8-byte Toeplitz fragments
 
+// NSEG = 4: the 8x8 maps, wave w = segment w, three work units per wave and chunk (its segment x the chunk's three 16-channel tiles).
+// NSEG = 5 (round 6: the 7x10 / 10x7 maps of 240x320 / 320x240 crops): still FOUR waves -- a fifth wave would share a SIMD with another wave of its workgroup and
+// double that SIMD's share of every barrier-separated phase (measured: 95 us per block against 56 us on the 8x8 maps) -- wave w < 3 also owns the unit (segment 4, tile w):
+// 4 + 4 + 4 + 3 units.  Unit u < 3 = (segment wave, tile u); unit 3 = (segment 4, tile wave).
 template <typename T, int KS, int KBN, int NSEG>
-__global__ __launch_bounds__(NSEG * 64) __attribute__((amdgpu_waves_per_eu(2, 3))) void mbconv_small_mx_kernel(SmxKArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void mbconv_small_mx_kernel(SmxKArgs a) {
     using raw_t = typename DT<T>::raw_t;
     constexpr int EPL = DT<T>::EPL, KB = DT<T>::KB;
     constexpr int NI = 3, CC = 48, LO = (KS - 1) / 2, PBYTES = smx_pbytes(KS), PJ = PBYTES / 1024;
     constexpr int HL = __is_same(T, bf16_t) ? 2 : 1, NF = KBN * HL;      // weight fragments per 16-channel tile: [k-block][hi | lo]
+    constexpr int NU = NSEG == 5 ? 4 : 3;                                // work units per wave (the fourth: waves 0-2 only)
     typedef T t4 __attribute__((ext_vector_type(4)));
     typedef f16_t tt4 __attribute__((ext_vector_type(4)));          // operands of the tap MFMAs: fp16 in both 16-bit modes (a register / LDS format between two MFMAs, not storage)
     typedef T out_t __attribute__((ext_vector_type(4)));
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(NSEG * 64) __attribute__((amdgpu_waves_per_eu(2, 3)
     char* Eh = smem;                               // [NSEG + 2 segments][NI][64 lanes] 8 bytes
     char* Wl = Eh + (NSEG + 2) * NI * 512;
     char* Pl = Wl + NI * NF * 1024;
-    float* red = (float*)(Pl + 2 * PBYTES);        // [NSEG waves][48]
+    float* red = (float*)(Pl + 2 * PBYTES);        // [NSEG segments][48]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x / a.ncg, cg = blockIdx.x - b * a.ncg;
@@ -68,33 +73,38 @@ __global__ __launch_bounds__(NSEG * 64) __attribute__((amdgpu_waves_per_eu(2, 3)
     const int ch0 = cg * a.cpw, ch1 = min(nchunks, ch0 + a.cpw);
     const int prow = lane & 15, kg = lane >> 4;
     const int cb = lane >> 2, jq = lane & 3;       // small-MFMA roles: channel of the tile, quad (row jq >> 1 of the segment, half jq & 1)
+    const bool has4 = NSEG == 5 && wave < 3;       // this wave owns (segment 4, tile wave) as well
+    auto useg = [&](int u) -> int { return u < 3 ? wave : 4; };
+    auto utile = [&](int u) -> int { return u < 3 ? u : wave; };
 
     auto issue_w = [&](int ch) {
-        for (int blk = wave; blk < NI * NF; blk += NSEG) {
+        for (int blk = wave; blk < NI * NF; blk += 4) {
             const int ni = blk / NF, f = blk - ni * NF;
             const T* src = (const T*)a.Wp + (((size_t)(ch * NI + ni) * a.nkb_total + f / HL) * HL + f % HL) * 64 * EPL + lane * EPL;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(Wl + (size_t)blk * 1024), 16, 0, 0);
         }
-        for (int j = wave; j < PJ; j += NSEG) {
+        for (int j = wave; j < PJ; j += 4) {
             const char* src = a.params + (size_t)ch * PBYTES + (size_t)j * 1024 + lane * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(Pl + (size_t)(ch & 1) * PBYTES + (size_t)j * 1024), 16, 0, 0);
         }
     };
     issue_w(ch0);
-    // this wave's segment of the block input (rows 2 wave, 2 wave + 1) -> registers: the A operand (rows = pixels) of the expansion
-    raw_t xf[KBN];
-    {
-        const int xr = 2 * wave + (prow >> 3), xc = min(prow & 7, a.cv - 1);      // walk pixel of this lane's MFMA row (beyond the walk row: a clamped, valid address)
-        const T* __restrict__ X = (const T*)a.X + ((size_t)b * a.HW + (a.tr ? xc * a.Wm + xr : xr * a.Wm + xc)) * a.Cin;
+    // the segments of the block input this wave expands (walk rows 2 seg, 2 seg + 1) -> registers: the A operand (rows = pixels) of the expansion
+    auto walk_pix = [&](int seg, int c) -> int { const int r = 2 * seg + (prow >> 3); return a.tr ? c * a.Wm + r : r * a.Wm + c; };
+    raw_t xf[NU == 4 ? 2 : 1][KBN];
+#pragma unroll
+    for (int q = 0; q < (NU == 4 ? 2 : 1); ++q) {
+        const int seg = q == 0 ? wave : 4;
+        const T* __restrict__ X = (const T*)a.X + ((size_t)b * a.HW + walk_pix(seg, min(prow & 7, a.cv - 1))) * a.Cin;      // (beyond the walk row: a clamped, valid address)
 #pragma unroll
         for (int kb = 0; kb < KBN; ++kb) {
             const int k = kb * KB + kg * EPL;
-            xf[kb] = *(const raw_t*)(k < a.Cin ? (const void*)(X + k) : a.zeros);
+            xf[q][kb] = *(const raw_t*)(k < a.Cin ? (const void*)(X + k) : a.zeros);
         }
     }
-    for (int i = tid; i < (NSEG + 2) * NI * 512 / 16; i += NSEG * 64) *(f32x4*)(Eh + (size_t)i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};   // segments -1 and NSEG are never written
+    for (int i = tid; i < (NSEG + 2) * NI * 512 / 16; i += 256) *(f32x4*)(Eh + (size_t)i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};   // segments -1 and NSEG are never written
     const int bp_in = (cb + 16 * jq) * 4, bp_out = (4 * prow + kg) * 4;
     t4 ident;
 #pragma unroll
@@ -107,51 +117,52 @@ __global__ __launch_bounds__(NSEG * 64) __attribute__((amdgpu_waves_per_eu(2, 3)
     for (int ch = ch0; ch < ch1; ++ch) {
         const char* P = Pl + (size_t)(ch & 1) * PBYTES;
         const float* hdr = (const float*)P;
-        // ---- expansion (operands swapped) -> E in the storage type, in the small MFMA's lanes -> Eh[wave + 1].  The three tiles' MFMA chains advance
-        // together (k-block outer): with 2 waves per SIMD the chains' own latency is what a phase costs
+        // ---- expansion (operands swapped) -> E as fp16, in the small MFMA's lanes -> Eh[segment + 1].  The units' MFMA chains advance together
+        // (k-block outer): with 2 waves per SIMD the chains' own latency is what a phase costs
         if (!COSY_DBG(a.dbg & 2)) {
-            f32x4 acc[NI];
+            f32x4 acc[NU];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const float b0 = hdr[ni * 16 + prow];                      // log2(e) * BN0 bias of this lane's channel: the C operand of the first MFMA
-                acc[ni] = f32x4{b0, b0, b0, b0};
+            for (int u = 0; u < NU; ++u) {
+                const float b0 = hdr[utile(u) * 16 + prow];                // log2(e) * BN0 bias of this lane's channel: the C operand of the first MFMA
+                acc[u] = f32x4{b0, b0, b0, b0};
             }
 #pragma unroll
             for (int f = 0; f < NF; ++f)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) mma(acc[ni], xf[f / HL], *(const raw_t*)(Wl + (size_t)(ni * NF + f) * 1024 + lane * 16));
-            smx_i32x2 hh[NI];
+                for (int u = 0; u < NU; ++u)
+                    if (u < 3 || has4) mma(acc[u], xf[u < 3 ? 0 : (NU == 4 ? 1 : 0)][f / HL], *(const raw_t*)(Wl + (size_t)(utile(u) * NF + f) * 1024 + lane * 16));
+            smx_i32x2 hh[NU];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
+            for (int u = 0; u < NU; ++u) {
                 tt4 hv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float t = acc[ni][e];                             // = log2(e) * BN0(expand)
+                    const float t = acc[u][e];                              // = log2(e) * BN0(expand)
                     hv[e] = cvt_e(t * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-t)) * 0.6931471805599453f);      // silu
                 }
                 if (a.cv < 8 && (kg & 1)) hv[3] = (f16_t)0.f;         // this lane's pixels 4 kg .. 4 kg + 3 of the segment: the eighth pixel of a walk row pads its neighbours
-                hh[ni] = __builtin_bit_cast(smx_i32x2, hv);
+                hh[u] = __builtin_bit_cast(smx_i32x2, hv);
             }
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const smx_i32x2 w1 = smx_i32x2{__builtin_amdgcn_ds_bpermute(bp_in, hh[ni][0]), __builtin_amdgcn_ds_bpermute(bp_in, hh[ni][1])};
-                *(smx_i32x2*)(Eh + (size_t)((wave + 1) * NI + ni) * 512 + lane * 8) = w1;
+            for (int u = 0; u < NU; ++u) {
+                const smx_i32x2 w1 = smx_i32x2{__builtin_amdgcn_ds_bpermute(bp_in, hh[u][0]), __builtin_amdgcn_ds_bpermute(bp_in, hh[u][1])};      // (every lane takes part in the permutation)
+                if (u < 3 || has4) *(smx_i32x2*)(Eh + (size_t)((useg(u) + 1) * NI + utile(u)) * 512 + lane * 8) = w1;
             }
         }
         __syncthreads();                       // Eh complete; the weight buffer is free
         if (ch + 1 < ch1 && !COSY_DBG(a.dbg & 4)) issue_w(ch + 1);     // lands while the tap phase computes
-        // ---- taps: output segment = wave
-        out_t yv[NI];
+        // ---- taps: a unit's output segment
+        out_t yv[NU];
         if (!COSY_DBG(a.dbg & 1)) {
-            smx_i32x2 S[NI][3], Sw[NI][3];
+            smx_i32x2 S[NU][3], Sw[NU][3];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
+            for (int u = 0; u < NU; ++u)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) S[ni][q] = *(const smx_i32x2*)(Eh + (size_t)((wave + q) * NI + ni) * 512 + lane * 8);      // input segments wave - 1, wave, wave + 1
+                for (int q = 0; q < 3; ++q) S[u][q] = *(const smx_i32x2*)(Eh + (size_t)((useg(u) + q) * NI + utile(u)) * 512 + lane * 8);      // input segments seg - 1, seg, seg + 1
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
+            for (int u = 0; u < NU; ++u)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) Sw[ni][q] = smx_i32x2{smx_dpp<0x4E>(S[ni][q][0]), smx_dpp<0x4E>(S[ni][q][1])};             // rows of the segment swapped (quad_perm [2,3,0,1])
+                for (int q = 0; q < 3; ++q) Sw[u][q] = smx_i32x2{smx_dpp<0x4E>(S[u][q][0]), smx_dpp<0x4E>(S[u][q][1])};             // rows of the segment swapped (quad_perm [2,3,0,1])
             // every LDS read of the phase is issued up front (the Toeplitz fragments: 2 KS x 3 register pairs): a read's round trip is several hundred
             // cycles while the next chunk's DMA is writing into the LDS, and 2 waves per SIMD do not hide one per tap row
             tt4 A0[KS][NI], A1[KS][NI];
@@ -162,67 +173,80 @@ __global__ __launch_bounds__(NSEG * 64) __attribute__((amdgpu_waves_per_eu(2, 3)
                     A0[ky][ni] = *(const tt4*)(P + SMX_HDR + (size_t)((ni * KS + ky) * 2 + 0) * 512 + lane * 8);
                     A1[ky][ni] = *(const tt4*)(P + SMX_HDR + (size_t)((ni * KS + ky) * 2 + 1) * 512 + lane * 8);
                 }
-            float s1v[NI], b1v[NI];
+            // unit 3's tile is this wave's index: its fragments selected once (wave-uniform)
+            tt4 A0x[NU == 4 ? KS : 1], A1x[NU == 4 ? KS : 1];
+            if constexpr (NU == 4) {
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) { s1v[ni] = hdr[CC + ni * 16 + cb]; b1v[ni] = hdr[2 * CC + ni * 16 + cb]; }
+                for (int ky = 0; ky < KS; ++ky) {
+                    A0x[ky] = wave == 0 ? A0[ky][0] : wave == 1 ? A0[ky][1] : A0[ky][2];
+                    A1x[ky] = wave == 0 ? A1[ky][0] : wave == 1 ? A1[ky][1] : A1[ky][2];
+                }
+            }
+            float s1v[NU], b1v[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) { s1v[u] = hdr[CC + utile(u) * 16 + cb]; b1v[u] = hdr[2 * CC + utile(u) * 16 + cb]; }
             __builtin_amdgcn_sched_barrier(0);
-            f32x4 accx[NI];
+            f32x4 accx[NU];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) accx[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < NU; ++u) accx[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ky = 0; ky < KS; ++ky) {                              // tap row outer: the three tiles' accumulation chains advance together
+            for (int ky = 0; ky < KS; ++ky) {                              // tap row outer: the units' accumulation chains advance together
                 const int d = ky - LO;                                      // input row = output row + d
-                smx_i32x2 op[NI], w2[NI];
+                smx_i32x2 op[NU], w2[NU];
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    if (d == -2) op[ni] = S[ni][0];
-                    else if (d == 0) op[ni] = S[ni][1];
-                    else if (d == 2) op[ni] = S[ni][2];
-                    else if (d == -1) op[ni] = smx_i32x2{row0 ? Sw[ni][0][0] : Sw[ni][1][0], row0 ? Sw[ni][0][1] : Sw[ni][1][1]};
-                    else op[ni] = smx_i32x2{row0 ? Sw[ni][1][0] : Sw[ni][2][0], row0 ? Sw[ni][1][1] : Sw[ni][2][1]};
+                for (int u = 0; u < NU; ++u) {
+                    if (d == -2) op[u] = S[u][0];
+                    else if (d == 0) op[u] = S[u][1];
+                    else if (d == 2) op[u] = S[u][2];
+                    else if (d == -1) op[u] = smx_i32x2{row0 ? Sw[u][0][0] : Sw[u][1][0], row0 ? Sw[u][0][1] : Sw[u][1][1]};
+                    else op[u] = smx_i32x2{row0 ? Sw[u][1][0] : Sw[u][2][0], row0 ? Sw[u][1][1] : Sw[u][2][1]};
                     // halo along x: the other half of the same row (pixels 2, 3 of the left half / 0, 1 of the right half), zero at the row ends
                     // (the moves run in ALL lanes, the selects follow: a DPP move inside a divergent branch reads nothing from the lanes the branch switched off)
-                    const int hpm = smx_dpp<0xA0>(op[ni][1]), lnm = smx_dpp<0xF5>(op[ni][0]);       // quad_perm [0,0,2,2] / [1,1,3,3]
-                    w2[ni] = smx_i32x2{half0 ? 0 : hpm, half0 ? lnm : 0};
+                    const int hpm = smx_dpp<0xA0>(op[u][1]), lnm = smx_dpp<0xF5>(op[u][0]);       // quad_perm [0,0,2,2] / [1,1,3,3]
+                    w2[u] = smx_i32x2{half0 ? 0 : hpm, half0 ? lnm : 0};
                 }
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) accx[ni] = smx_mma4(A0[ky][ni], __builtin_bit_cast(tt4, op[ni]), accx[ni]);
+                for (int u = 0; u < NU; ++u)
+                    if (u < 3) accx[u] = smx_mma4(A0[ky][u < 3 ? u : 0], __builtin_bit_cast(tt4, op[u]), accx[u]);
+                    else if (has4) accx[u] = smx_mma4(A0x[NU == 4 ? ky : 0], __builtin_bit_cast(tt4, op[u]), accx[u]);
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) accx[ni] = smx_mma4(A1[ky][ni], __builtin_bit_cast(tt4, w2[ni]), accx[ni]);
+                for (int u = 0; u < NU; ++u)
+                    if (u < 3) accx[u] = smx_mma4(A1[ky][u < 3 ? u : 0], __builtin_bit_cast(tt4, w2[u]), accx[u]);
+                    else if (has4) accx[u] = smx_mma4(A1x[NU == 4 ? ky : 0], __builtin_bit_cast(tt4, w2[u]), accx[u]);
             }
-            smx_i32x2 hh[NI];
+            smx_i32x2 hh[NU];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const float s1 = s1v[ni], b1 = b1v[ni];
+            for (int u = 0; u < NU; ++u) {
+                const float s1 = s1v[u], b1 = b1v[u];
                 float sum = 0.f;
                 t4 hv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = accx[ni][e] * s1 + b1;
+                    float v = accx[u][e] * s1 + b1;
                     v = v * sigmoid_t<T>(v);
                     sum += (e == 3 && a.cv < 8 && (jq & 1)) ? 0.f : v;          // (this lane's pixels 4 jq .. 4 jq + 3: the eighth pixel of a walk row is not part of the map)
                     hv[e] = cvt(v);
                 }
                 sum += smx_dppf<0xB1>(sum);                                 // the 4 quads of the segment (fixed order)
                 sum += smx_dppf<0x4E>(sum);
-                if (jq == 0) red[wave * CC + ni * 16 + cb] = sum;
-                hh[ni] = __builtin_bit_cast(smx_i32x2, hv);
+                if (jq == 0 && (u < 3 || has4)) red[useg(u) * CC + utile(u) * 16 + cb] = sum;
+                hh[u] = __builtin_bit_cast(smx_i32x2, hv);
             }
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const smx_i32x2 back = smx_i32x2{__builtin_amdgcn_ds_bpermute(bp_out, hh[ni][0]), __builtin_amdgcn_ds_bpermute(bp_out, hh[ni][1])};
+            for (int u = 0; u < NU; ++u) {
+                const smx_i32x2 back = smx_i32x2{__builtin_amdgcn_ds_bpermute(bp_out, hh[u][0]), __builtin_amdgcn_ds_bpermute(bp_out, hh[u][1])};
                 const f32x4 tr = smx_mma16(__builtin_bit_cast(t4, back), ident, f32x4{0.f, 0.f, 0.f, 0.f});     // -> lane (pixel, 4 channels), exact
 #pragma unroll
-                for (int e = 0; e < 4; ++e) yv[ni][e] = (T)tr[e];
+                for (int e = 0; e < 4; ++e) yv[u][e] = (T)tr[e];
             }
         }
         // Global stores count in vmcnt and retire in order with the loads: the wait for the next chunk's DMA comes BEFORE this chunk's stores
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!COSY_DBG(a.dbg & 1) && (prow & 7) < a.cv) {
-            const int yr = 2 * wave + (prow >> 3), yc = prow & 7, ypix = a.tr ? yc * a.Wm + yr : yr * a.Wm + yc;
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                *(out_t*)((T*)a.D + (((size_t)b * (a.Cmid >> 4) + ch * NI + ni) * a.HW + ypix) * 16 + kg * 4) = yv[ni];
+            for (int u = 0; u < NU; ++u)
+                if (u < 3 || has4)
+                    *(out_t*)((T*)a.D + (((size_t)b * (a.Cmid >> 4) + ch * NI + utile(u)) * a.HW + walk_pix(useg(u), prow & 7)) * 16 + kg * 4) = yv[u];
         }
         __syncthreads();   // red complete; everybody's DMA(ch+1) landed; all Eh / parameter reads of this chunk are done
         if (tid < CC && !COSY_DBG(a.dbg & 1)) {
@@ -282,7 +306,7 @@ static int launch_smx_ks(const SmxKArgs& k, int B, hipStream_t s) {
     const size_t lds = (size_t)(NSEG + 2) * 3 * 512 + (size_t)3 * KBN * HL * 1024 + (size_t)2 * smx_pbytes(KS) + NSEG * 48 * sizeof(float);
     static const hipError_t attr_rc = hipFuncSetAttribute((const void*)mbconv_small_mx_kernel<T, KS, KBN, NSEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     COSY_CHECK_HIP(attr_rc);
-    hipLaunchKernelGGL((mbconv_small_mx_kernel<T, KS, KBN, NSEG>), dim3((unsigned)(B * k.ncg)), dim3(NSEG * 64), lds, s, k);
+    hipLaunchKernelGGL((mbconv_small_mx_kernel<T, KS, KBN, NSEG>), dim3((unsigned)(B * k.ncg)), dim3(256), lds, s, k);
     COSY_CHECK_HIP(hipGetLastError());
     return COSY_OK;
 }
