@@ -210,6 +210,35 @@ def _probe(model, h, x, layer, shape):
     return out.cpu().numpy()
 
 
+@pytest.mark.parametrize('hw', [(256, 256), (240, 320)], ids=['256x256', '240x320'])
+def test_stage_taps_read_every_activation_layout(model, hw):
+    """round 6: the per-stage probes of cosy_effnet_b3_forward (taps: mean, mean |x|, 14 strided samples of the stem, the 7 stage outputs and the head) in fp16, where
+    the stage outputs are stored in three layouts -- NHWC, chunked [sample][C/16][HW][16] (inputs of the matrix-pipe wave fronts) and chunked with the pixels of a row permuted
+    (inputs of the fp32-FMA fronts: blocks 2 / 5 / 8 at 256x256) -- against the same quantities computed here from the whole tensors (test probe -> fp32 NCHW copies).  The two
+    readers (taps_kernel, nhwc_to_nchw_kernel) index the layouts independently; the fp32 per-stage test above only ever sees NHWC."""
+    from cosypose_amd._lib import lib, check, ptr, stream
+    B = 3
+    x = np.random.RandomState(7 + hw[1]).random_sample((B, 6) + tuple(hw)).astype(np.float32)
+    h, plan = _block_plan(model, hw, 'fp16', B)
+    check(lib().cosy_effnet_b3_set_input_nchw(h, ptr(dev(x)), B, stream()))
+    pose = torch.empty(B, 9, device='cuda'); taps_d = torch.empty(B, 9, 16, device='cuda')
+    for slot, layer in enumerate([1, 4, 7, 12, 17, 23, 25], start=1):
+        Ho, Wo, C = plan[layer][2], plan[layer][3], plan[layer][6]
+        out = torch.empty((B, C, Ho, Wo), device='cuda')
+        check(lib().cosy_effnet_b3_set_probe(h, layer, ptr(out)))        # probe and taps of ONE forward: the same values, read by two kernels
+        try:
+            check(lib().cosy_effnet_b3_forward(h, B, None, ptr(pose), ptr(taps_d), stream()))
+            torch.cuda.synchronize()
+        finally:
+            check(lib().cosy_effnet_b3_set_probe(h, -2, None))
+        t = out.cpu().numpy().reshape(B, -1).astype(np.float64)
+        n = t.shape[1]
+        want = np.concatenate([t.mean(1, keepdims=True), np.abs(t).mean(1, keepdims=True), t[:, [(2 * j + 1) * n // 29 for j in range(14)]]], 1)
+        got = taps_d.cpu().numpy()[:, slot]
+        scale = np.abs(want).max()
+        assert np.abs(got - want).max() <= 1e-5 * scale, (layer, np.abs(got - want).max() / scale)
+
+
 # storage ulp relative to a value: bf16 has 8 significant bits, fp16 11
 ULP = {'bf16': 2.0 ** -7, 'fp16': 2.0 ** -10}
 L2_TOL = {'bf16': 6e-4, 'fp16': 4e-4}   # relative L2 per tensor, block-local comparison (measured worst: 3.4e-4 / 2.0e-4 -- block 13's project output at 416x416, whose
