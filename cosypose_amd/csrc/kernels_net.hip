@@ -14,6 +14,7 @@
 //   stem      : dense 3x3 stride-2 conv 6->40 + BN + SiLU.
 //   pool_fc   : global average pool + Linear(1536, 9).
 #include "net_device.h"
+#include <type_traits>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -207,35 +208,77 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
 
     constexpr bool HALF_GATE = sizeof(T) == 2 && !__is_same(T, bf16_t);   // fp16: the gate multiplies as packed halves
     int gsel = 0, grow[MI];
-    // chunked A ([sample][K/16][HW][16]): element offset of this lane's row at k = 0, per DMA slot
-    unsigned achunk[L];       // in 16-element chunk rows (32 bits: the launcher checks M * K / 16 < 2^32)
+    // The operands' DMA sources, one per DMA slot of this wave (slot i = block i * NWV + wave of a stage): a per-lane pointer that ADVANCES by a constant per
+    // stage.  (Round 6: the first version recomputed every source in the k-loop -- tile bounds, chunk arithmetic, block kind, ~250 mostly scalar / branch
+    // instructions per step and wave for 8-20 MFMAs; knock-out timing of the split-K tiles of blocks 19-25 showed the loop's SHELL at 60 % of a step,
+    // profiles/r06_gemm_kloop.txt.)  A rows beyond M and the k tail of the last k-block read the zero page; W is packed with zero padding.
+    const T* src[L];          // this lane's source of slot i in the NEXT stage to be issued
+    int sstep[L];             // its advance per stage in elements (0 for rows beyond M: they stay on the zero page)
 #pragma unroll
     for (int i = 0; i < L; ++i) {
-        const int m = min(m0 + (KG == 1 ? i * NWV + wave : (i * NWV + wave) % NB) * 16 + row, M - 1), bs = m / a.HW;
-        achunk[i] = a.a_chunked ? (unsigned)bs * (unsigned)((K + 15) >> 4) * (unsigned)a.HW + (unsigned)(m - bs * a.HW) : 0u;
+        const int sblk = i * NWV + wave, blk = KG == 1 ? sblk : sblk % NB, kofs = KG == 1 ? 0 : sblk / NB;
+        if (blk < NA) {
+            const int m = m0 + blk * 16 + row, k0 = kofs * KB + kg * EPL;
+            const bool rowok = m < M && sblk < SB;
+            const int mc = min(m, M - 1), bs = mc / a.HW;
+            const size_t o = a.a_chunked ? ((size_t)bs * (size_t)((K + 15) >> 4) * (size_t)a.HW + (size_t)(mc - bs * a.HW) + (size_t)(k0 >> 4) * (size_t)a.HW) * 16 + (k0 & 15)
+                                         : (size_t)mc * K + k0;
+            src[i] = rowok ? A + o : (const T*)a.zeros;
+            sstep[i] = rowok ? (a.a_chunked ? KG * KB * a.HW : KG * KB) : 0;
+        } else {
+            src[i] = Wp + (((size_t)(nt * NW + (blk - NA) / HL) * a.nkb_total + kofs) * HL + (blk - NA) % HL) * 64 * EPL + lane * EPL;
+            sstep[i] = KG * HL * 64 * EPL;
+        }
     }
-    auto issue = [&](int ks) {              // stage ks = the k-blocks ks * KG .. ks * KG + KG - 1
-        char* st = lds + (ks % NS) * SB * 1024;
+    const bool ktail = K % KB != 0;      // the last k-block is partly beyond K
+    // The k-loop of the 8- / 16-wave tiles is bound by SCALAR issue: a CU's four SIMDs share one scalar unit (one SALU instruction per SIMD every four cycles),
+    // and the general form below spends ~90 of them per step and wave on stage / validity / destination arithmetic -- 16 waves x 90 = ~1,450 cycles per step against
+    // 128 cycles of MFMAs per wave (knock-outs: profiles/r06_gemm_kloop.txt).  Stages whose k-blocks are all inside K (every stage but the last one or two) take
+    // issue_fast: no validity, no tail, the destination advances by a constant.
+    int wr_off = 0;                      // byte offset of the ring stage the next issue writes
+    bool slot_ok[L], slot_nt[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const int sblk = i * NWV + wave, blk = KG == 1 ? sblk : sblk % NB;
+        slot_ok[i] = sblk < SB; slot_nt[i] = a.a_nt && blk < NA;
+    }
+    auto issue_fast = [&]() {
 #pragma unroll
         for (int i = 0; i < L; ++i) {
-            const int sblk = i * NWV + wave, blk = KG == 1 ? sblk : sblk % NB, kb = KG == 1 ? ks : ks * KG + sblk / NB;     // (no division in the plain tiles: 5-9 us per launch)
-            const void* src = a.zeros;
-            char* dst = dummy;
-            if (kb < a.nkb_valid && sblk < SB) {
-                dst = st + sblk * 1024;
-                if (blk < NA) {
-                    const int m = m0 + blk * 16 + row, k = kb * KB + kg * EPL;
-                    if (m < M && k < K) src = a.a_chunked ? A + (size_t)(achunk[i] + (unsigned)(k >> 4) * (unsigned)a.HW) * 16 + (k & 15) : A + (size_t)m * K + k;
-                } else {
-                    src = Wp + (((size_t)(nt * NW + (blk - NA) / HL) * a.nkb_total + kb) * HL + (blk - NA) % HL) * 64 * EPL + lane * EPL;
-                }
+            if ((i + 1) * NWV <= SB || slot_ok[i]) {      // (compile-time true for every slot but a partly filled last one)
+                char* dst = lds + wr_off + (i * NWV + wave) * 1024;
+                if (slot_nt[i])
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 2);
+                else
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            } else {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a.zeros,
+                                                 (__attribute__((address_space(3))) void*)dummy, 16, 0, 0);      // (every wave issues L DMAs per stage: the counted wait)
             }
+            src[i] += sstep[i];
+        }
+        wr_off = wr_off + SB * 1024 == NS * SB * 1024 ? 0 : wr_off + SB * 1024;
+    };
+    auto issue = [&](int ks) {              // stage ks = the k-blocks ks * KG .. ks * KG + KG - 1; stages are issued in order, once each
+        char* st = lds + wr_off;
+        wr_off = wr_off + SB * 1024 == NS * SB * 1024 ? 0 : wr_off + SB * 1024;
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const int sblk = i * NWV + wave, blk = KG == 1 ? sblk : sblk % NB, kb = KG == 1 ? ks : ks * KG + sblk / NB;     // wave-uniform
+            const bool v = kb < a.nkb_valid && sblk < SB;
+            const T* p = src[i];
+            if (ktail && blk < NA && kb == a.nkb_valid - 1) p = kb * KB + kg * EPL < K ? p : (const T*)a.zeros;      // (per lane, last k-block only)
+            if (!v) p = (const T*)a.zeros;
+            char* dst = v ? st + sblk * 1024 : dummy;
             if (a.a_nt && blk < NA)     // wave-uniform
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 2);      // aux 2 = nt
             else
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            src[i] += sstep[i];
         }
     };
 
@@ -385,13 +428,15 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
     }
 
     const int nks = (a.nkb_valid + KG - 1) / KG;
-    for (int ks = 0; ks < nks; ++ks) {
+    const int n_clean = (a.nkb_valid - (ktail ? 1 : 0)) / KG;                  // stages 0 .. n_clean - 1: every k-block inside K, no tail block
+    const int n_fast = max(0, n_clean - (NS - 1));                             // steps whose issue (stage ks + NS - 1) is a clean stage
+    auto kstep = [&](const int ks, auto fastc) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * L) : "memory");  // stage ks has landed (this wave's part)
         __builtin_amdgcn_s_barrier();                                          // ... and everybody's; stage (ks-1)%NS is free
         asm volatile("" ::: "memory");
-        issue(ks + NS - 1);
+        if constexpr (decltype(fastc)::value) issue_fast(); else issue(ks + NS - 1);
         const int kb = ks * KG + kgp;                                          // this K-group's k-block of the stage
-        if (KG > 1 && kb >= a.nkb_valid) continue;                             // odd number of k-blocks: the last stage is half full (wave-uniform)
+        if (KG > 1 && kb >= a.nkb_valid) return;                               // odd number of k-blocks: the last stage is half full (wave-uniform)
         const char* st = lds + ((ks % NS) * SB + kgp * NB) * 1024;
         raw_t fw[NI], fa[MI], fwl[HL == 2 ? NI : 1];
 #pragma unroll
@@ -453,6 +498,11 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
                 mma(acc[mi][ni], fw[ni], fa[mi]);
                 if constexpr (HL == 2) mma(acc[mi][ni], fwl[ni], fa[mi]);
             }
+    };
+    {
+        int ks = 0;
+        for (; ks < n_fast; ++ks) kstep(ks, std::true_type{});
+        for (; ks < nks; ++ks) kstep(ks, std::false_type{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (KG > 1) {
