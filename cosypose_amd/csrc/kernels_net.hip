@@ -211,20 +211,20 @@ __global__ __launch_bounds__(NWV * 64, pw_bound_waves(NI, MI, NWV)) void pw_gemm
     // The operands' DMA sources, one per DMA slot of this wave (slot i = block i * NWV + wave of a stage): a per-lane pointer that ADVANCES by a constant per
     // stage.  (Round 6: the first version recomputed every source in the k-loop -- tile bounds, chunk arithmetic, block kind, ~250 mostly scalar / branch
     // instructions per step and wave for 8-20 MFMAs; knock-out timing of the split-K tiles of blocks 19-25 showed the loop's SHELL at 60 % of a step,
-    // profiles/r06_gemm_kloop.txt.)  A rows beyond M and the k tail of the last k-block read the zero page; W is packed with zero padding.
+    // profiles/r06_gemm_kloop.txt.)  Rows beyond M read the last row again (finite values into accumulator rows that are never stored), the k tail of the
+    // last k-block reads the zero page; W is packed with zero padding.
     const T* src[L];          // this lane's source of slot i in the NEXT stage to be issued
-    int sstep[L];             // its advance per stage in elements (0 for rows beyond M: they stay on the zero page)
+    int sstep[L];             // its advance per stage in elements (wave-uniform: a slot is an A block or a W block for the whole wave)
 #pragma unroll
     for (int i = 0; i < L; ++i) {
         const int sblk = i * NWV + wave, blk = KG == 1 ? sblk : sblk % NB, kofs = KG == 1 ? 0 : sblk / NB;
         if (blk < NA) {
             const int m = m0 + blk * 16 + row, k0 = kofs * KB + kg * EPL;
-            const bool rowok = m < M && sblk < SB;
             const int mc = min(m, M - 1), bs = mc / a.HW;
             const size_t o = a.a_chunked ? ((size_t)bs * (size_t)((K + 15) >> 4) * (size_t)a.HW + (size_t)(mc - bs * a.HW) + (size_t)(k0 >> 4) * (size_t)a.HW) * 16 + (k0 & 15)
                                          : (size_t)mc * K + k0;
-            src[i] = rowok ? A + o : (const T*)a.zeros;
-            sstep[i] = rowok ? (a.a_chunked ? KG * KB * a.HW : KG * KB) : 0;
+            src[i] = A + o;
+            sstep[i] = a.a_chunked ? KG * KB * a.HW : KG * KB;
         } else {
             src[i] = Wp + (((size_t)(nt * NW + (blk - NA) / HL) * a.nkb_total + kofs) * HL + (blk - NA) % HL) * 64 * EPL + lane * EPL;
             sstep[i] = KG * HL * 64 * EPL;
