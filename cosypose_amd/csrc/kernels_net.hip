@@ -58,8 +58,10 @@ PwCfg pw_choose_cfg_late(int K, int N, int HW, bool gated, int dtype) {
     // K >= 1024 (blocks 19-25 project): 16 waves in two K-groups (see the kernel); N = 384 as two 192-column tiles, so that 256 crops are
     // 256 workgroups = one per CU (three 128-column tiles are 384 = a second round on half the CUs)
     // Measured at 256 crops, fp16 (profiles/r04_gemm_splitk.txt): blocks 19-23 33.3 -> 28.4 us, block 24 41.5 -> 39.8, block 25 63.6 -> 57.2.
-    // A 128 x 256 full-N tile (A read once, 128 workgroups) took 65 us for block 19: what bounds these layers is the LDS-DMA rate of ONE CU
-    // (~25 GB/s: 32 KB per 1.3 us interval here, 16 KB per 0.75 us with 8 waves), not a chip-wide byte count -- fewer, larger tiles lose.
+    // A 128 x 256 full-N tile (A read once, 128 workgroups) took 65 us for block 19: these layers run at ~25 GB/s of operands per CU (32 KB per 1.3 us step here,
+    // 16 KB per 0.75 us with 8 waves), not at a chip-wide byte count -- fewer, larger tiles lose.  (Round 6: that rate is NOT the LDS-DMA path's, which fills at
+    // 137-144 GB/s per CU from the L2 -- profiles/r06_dma_rate.txt; a four-stage ring and an 8-wave 64 x 64-per-wave split-K tile were measured and lose too:
+    // profiles/r06_gemm_kloop.txt, r06_dead_ends.txt.)
     static const int pw16 = tune_int("COSY_PW16", 1);
     // Maps whose pixel count is not a multiple of 64 (240x320 crops: 8x10, 15x20, ...) take the row-side gate.  Measured there (256 crops, fp16,
     // profiles/r04_rowgate_tiles.txt): the split-K tile loses (blocks 19-23 51 -> 58 us, 24 / 25 51 / 79 -> 74 / 109); the 8-wave tile wins for
