@@ -491,12 +491,12 @@ __global__ __launch_bounds__(256, 4) void crop_pack_tile_kernel(T* __restrict__ 
     const bool xvalid = colok && tx.span >= 0;
     const int xf = wave_min_i(xvalid ? tx.first : 0x7fffffff), xl = wave_max_i(xvalid ? tx.first + tx.span : -1);
     const bool xwide = __ballot(colok && tx.span >= 4) != 0;        // entries wider than 4 pixels: per-pixel path
-    const int ncols = xl - xf + 1;
+    const int ncols = xl >= 0 ? xl - xf + 1 : 0;       // (no valid column in the tile: nothing is loaded, every pixel of it is zero)
     const float* bx = boxes + (size_t)b * 4;
     const float bin_h = fmaxf(bx[3] - bx[1], 1.f) / (float)PH;
     // passes: the fewest of 1 / 2 / 4 whose rows' window is expected to fit (checked per pass against the real entries)
     int np = 1;
-    while (np < 4 && ((int)((float)(CROP_TH / np) * bin_h) + 5) * ncols > CROP_LDS_PX) np *= 2;
+    while (np < 4 && ((int)fminf((float)(CROP_TH / np) * bin_h, 65536.f) + 5) * ncols > CROP_LDS_PX) np *= 2;      // (huge boxes: bounded before the conversion)
     const int rp = CROP_TH / np, rpw = rp / 4;                      // rows per pass, rows per wave and pass (4 / 2 / 1)
     const size_t HW = (size_t)PH * PW;
     for (int p = 0; p < np; ++p) {
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256, 4) void crop_pack_tile_kernel(T* __restrict__ 
         const bool yvalid = rok && tq.span >= 0;
         const int yf = wave_min_i(yvalid ? tq.first : 0x7fffffff), yl = wave_max_i(yvalid ? tq.first + tq.span : -1);
         const bool ywide = __ballot(rok && tq.span >= 4) != 0;
-        const int nrows = yl - yf + 1;
+        const int nrows = yl >= 0 ? yl - yf + 1 : 0;
         const bool any = xl >= 0 && yl >= 0;                        // else: no valid sample in the pass -> zeros
         const bool fits = any && nrows * ncols <= CROP_LDS_PX;
         // this lane's pixels: rows ph0 .. ph0 + rpw - 1 of column pw; their tap entries and render channels are requested first
